@@ -1,0 +1,325 @@
+/*
+ * isx_oracle.c -- CPU restatement of the reference's descriptor-extraction +
+ * retrieval arithmetic (maxgreat/Instance-Search), in plain scalar C99.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the
+ * __graft_entry__.smoke() check and bench.py's cpu_baseline leg may load it.
+ * The product path (instance-search_amd/) never links, imports or calls it.
+ *
+ * Parity status: PINNED.  Every function below is checked in
+ * tests/test_oracle_golden.py against fixtures produced by running the
+ * reference's own Python (imported in place from /root/reference with the
+ * harness-side shims of oracle/gen_golden.py) -- see tests/golden/.
+ * torch.mm / sort / topk / AvgPool2d live in PyTorch (un-pinned by the
+ * reference); at that boundary the oracle is pinned against torch 2.10 CPU fp32
+ * with the tolerances written in the tests.
+ *
+ * Conventions shared with the HIP library (include/isx.h):
+ *   - all matrices row-major contiguous, fp32; indices int64; labels int32
+ *   - canonical ranking order = (score descending, index ascending); -0.0 == +0.0
+ *   - canonical dot product = k-ordered fp32 fmaf chain starting from +0.0f
+ *     (this is what v_mfma_f32_32x32x2_f32 computes bit-for-bit)
+ *
+ * Citations are file:line under /root/reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ISXO_API __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------- keys ---- */
+
+/* Monotone map float -> uint32 (larger float => larger key); -0.0 folded to +0.0
+ * so that equal floats give equal keys.  NaNs are not produced on this path. */
+static inline uint32_t f32_orderable(float f) {
+    uint32_t u;
+    if (f == 0.0f) f = 0.0f; /* -0 -> +0 */
+    memcpy(&u, &f, 4);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+/* 64-bit ranking key: larger key = ranked earlier.  idx < 2^32. */
+static inline uint64_t rank_key(float score, uint64_t idx) {
+    return ((uint64_t)f32_orderable(score) << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)idx);
+}
+
+typedef struct { uint64_t key; float s; } kv_t;
+
+static int cmp_key_desc(const void* a, const void* b) {
+    uint64_t x = ((const kv_t*)a)->key, y = ((const kv_t*)b)->key;
+    return (x < y) - (x > y);
+}
+
+/* ----------------------------------------------------- NormalizeL2 / Shift -- */
+
+/* model/custom_modules.py:52-57  NormalizeL2Fun.forward:
+ *   norm2 = input.pow(2).sum(1).add_(eps); norm = norm2.pow(0.5); out = input / norm
+ * eps is added to the SQUARED norm, inside the sqrt.  The row sum is taken in
+ * double and rounded once (torch's fp32 CPU summation order is unspecified; any
+ * fp32 order lands within a few ulp of this). */
+ISXO_API void isxo_l2norm_rows(const float* x, int64_t B, int64_t D, float eps, float* y) {
+    for (int64_t b = 0; b < B; ++b) {
+        const float* r = x + b * D;
+        double ss = 0.0;
+        for (int64_t j = 0; j < D; ++j) ss += (double)r[j] * (double)r[j];
+        float n = sqrtf((float)ss + eps);
+        for (int64_t j = 0; j < D; ++j) y[b * D + j] = r[j] / n;
+    }
+}
+
+/* model/custom_modules.py:16-18  ShiftFun.forward: input + param (broadcast over rows) */
+ISXO_API void isxo_shift_rows(const float* x, const float* param, int64_t B, int64_t F, float* y) {
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t j = 0; j < F; ++j) y[b * F + j] = x[b * F + j] + param[j];
+}
+
+/* ------------------------------------------------------------- pooling ---- */
+
+/* model/siamese.py:49-54 (TuneClassif.forward with the classifier stripped,
+ * train/classif_finetune.py:87-90) followed by NormalizeL2Fun
+ * (train/classif_finetune.py:100): AvgPool2d over the whole HxW map (ResNet
+ * avgpool 7), view(B,-1), L2.  Pool = sequential fp32 sum (h-major) / (H*W),
+ * which is what torch's CPU avg_pool2d does. */
+ISXO_API void isxo_gap_l2(const float* fmap, int64_t B, int C, int H, int W, float eps, float* y) {
+    const int HW = H * W;
+    float* pooled = (float*)malloc(sizeof(float) * (size_t)C);
+    for (int64_t b = 0; b < B; ++b) {
+        for (int c = 0; c < C; ++c) {
+            const float* p = fmap + ((size_t)b * C + c) * HW;
+            float s = 0.0f;
+            for (int i = 0; i < HW; ++i) s += p[i];
+            pooled[c] = s / (float)HW;
+        }
+        isxo_l2norm_rows(pooled, 1, C, eps, y + (size_t)b * C);
+    }
+    free(pooled);
+}
+
+/* model/siamese.py:67-71  nn.AvgPool2d(feature_size2d, stride=1) on an NCHW map. */
+ISXO_API void isxo_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out) {
+    const int Ho = H - kh + 1, Wo = W - kw + 1;
+    for (int64_t bc = 0; bc < B * (int64_t)C; ++bc) {
+        const float* p = fmap + (size_t)bc * H * W;
+        float* o = out + (size_t)bc * Ho * Wo;
+        for (int i = 0; i < Ho; ++i)
+            for (int j = 0; j < Wo; ++j) {
+                float s = 0.0f;
+                for (int a = 0; a < kh; ++a)
+                    for (int b = 0; b < kw; ++b) s += p[(i + a) * W + (j + b)];
+                o[i * Wo + j] = s / (float)(kh * kw);
+            }
+    }
+}
+
+/* ------------------------------------------------------- region path ------ */
+
+/* train/classif_regions.py:118-128:
+ *   max_pred = out.max(1)            (max over classes)      -> (1,1,H',W')
+ *   max_pred1, max_i1 = max_pred.max(2)  (over rows, per column)
+ *   _, max_i2 = max_pred1.max(3)     (over columns)
+ *   i2 = max_i2[0]; i1 = max_i1[i2];  desc = NormalizeL2(out[:, :, i1, i2])
+ * Tie-break (first maximal index, as torch CPU max returns): smallest column,
+ * then smallest row inside that column.  loc = {i1 (row), i2 (col)}. */
+ISXO_API void isxo_best_location_desc(const float* cls, int K, int Hp, int Wp, float eps, float* desc, int64_t* loc) {
+    const int P = Hp * Wp;
+    float* mx = (float*)malloc(sizeof(float) * (size_t)P);
+    for (int p = 0; p < P; ++p) {
+        float m = cls[p];
+        for (int c = 1; c < K; ++c) { float v = cls[(size_t)c * P + p]; if (v > m) m = v; }
+        mx[p] = m;
+    }
+    int bi2 = 0, bi1 = 0; float best = 0.0f;
+    for (int j = 0; j < Wp; ++j) {
+        int i1 = 0; float cm = mx[j];
+        for (int i = 1; i < Hp; ++i) if (mx[i * Wp + j] > cm) { cm = mx[i * Wp + j]; i1 = i; }
+        if (j == 0 || cm > best) { best = cm; bi2 = j; bi1 = i1; }
+    }
+    float* v = (float*)malloc(sizeof(float) * (size_t)K);
+    for (int c = 0; c < K; ++c) v[c] = cls[(size_t)c * P + bi1 * Wp + bi2];
+    isxo_l2norm_rows(v, 1, K, eps, desc);
+    loc[0] = bi1; loc[1] = bi2;
+    free(v); free(mx);
+}
+
+/* model/siamese.py:191-194:  c_maxv = c.max(1).view(-1); k = min(len, self.k); topk(k)
+ * flat index is row-major over (H',W').  Returns the number of regions written.
+ * Canonical order: (score desc, flat index asc). */
+ISXO_API int isxo_region_topk(const float* cls, int K, int Hp, int Wp, int k, int64_t* flat_idx, float* score) {
+    const int P = Hp * Wp;
+    kv_t* kv = (kv_t*)malloc(sizeof(kv_t) * (size_t)P);
+    float* mx = (float*)malloc(sizeof(float) * (size_t)P);
+    for (int p = 0; p < P; ++p) {
+        float m = cls[p];
+        for (int c = 1; c < K; ++c) { float v = cls[(size_t)c * P + p]; if (v > m) m = v; }
+        mx[p] = m; kv[p].key = rank_key(m, (uint64_t)p);
+    }
+    qsort(kv, (size_t)P, sizeof(kv_t), cmp_key_desc);
+    int kk = k < P ? k : P;
+    for (int i = 0; i < kk; ++i) {
+        int64_t p = (int64_t)(0xFFFFFFFFu - (uint32_t)(kv[i].key & 0xFFFFFFFFu));
+        flat_idx[i] = p; score[i] = mx[p];
+    }
+    free(kv); free(mx);
+    return kk;
+}
+
+/* model/siamese.py:199-219: window (row,col) = (idx // W', idx % W');
+ *   region = x[:, :, row:row+kh, col:col+kw].contiguous().view(1,-1)   (C,h,w order)
+ *   feature_reduc1[0:2] = NormalizeL2 -> Shift        (the Linear follows in the caller)
+ * rows is (k, C*kh*kw); shift may be NULL (= zeros, its initial value, custom_modules.py:35-36). */
+ISXO_API void isxo_region_gather_l2(const float* fmap, int C, int Hf, int Wf, int kh, int kw,
+                                    const int64_t* flat_idx, int k, int Wp,
+                                    const float* shift, float eps, float* rows) {
+    const size_t F = (size_t)C * kh * kw;
+    float* tmp = (float*)malloc(sizeof(float) * F);
+    for (int r = 0; r < k; ++r) {
+        int row = (int)(flat_idx[r] / Wp), col = (int)(flat_idx[r] % Wp);
+        size_t o = 0;
+        for (int c = 0; c < C; ++c)
+            for (int a = 0; a < kh; ++a)
+                for (int b = 0; b < kw; ++b)
+                    tmp[o++] = fmap[((size_t)c * Hf + (row + a)) * Wf + (col + b)];
+        isxo_l2norm_rows(tmp, 1, (int64_t)F, eps, rows + (size_t)r * F);
+        if (shift) for (size_t j = 0; j < F; ++j) rows[(size_t)r * F + j] += shift[j];
+    }
+    free(tmp);
+}
+
+/* ------------------------------------------------------------ retrieval --- */
+
+/* test/classif_finetune_test.py:82  sim = torch.mm(test_emb, ref_emb.t()).
+ * Canonical summation: k-ordered fp32 fmaf chain (see header). */
+/* target_clones: use the hardware FMA where the host has it (the libm fmaf
+ * software path gives the same bits, only slower). */
+__attribute__((target_clones("fma", "default")))
+static float dot_fma(const float* q, const float* g, int D) {
+    float acc = 0.0f;
+    for (int k = 0; k < D; ++k) acc = fmaf(q[k], g[k], acc);
+    return acc;
+}
+
+ISXO_API void isxo_cosine_sim(const float* Q, int64_t M, const float* G, int64_t N, int D, float* sim) {
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t j = 0; j < N; ++j) sim[i * N + j] = dot_fma(Q + i * D, G + j * D, D);
+}
+
+/* Fused form of  torch.mm -> (sort | topk): per query the k best gallery rows in
+ * canonical order, global index = idx_base + local row.  Entries beyond N are
+ * (-inf, -1). */
+ISXO_API void isxo_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N, int D, int k,
+                               int64_t idx_base, float* top_score, int64_t* top_idx) {
+    kv_t* kv = (kv_t*)malloc(sizeof(kv_t) * (size_t)(N > 0 ? N : 1));
+    float* s = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1));
+    for (int64_t i = 0; i < M; ++i) {
+        for (int64_t j = 0; j < N; ++j) { s[j] = dot_fma(Q + i * D, G + j * D, D); kv[j].key = rank_key(s[j], (uint64_t)j); }
+        qsort(kv, (size_t)N, sizeof(kv_t), cmp_key_desc);
+        for (int t = 0; t < k; ++t) {
+            if (t < N) {
+                int64_t j = (int64_t)(0xFFFFFFFFu - (uint32_t)(kv[t].key & 0xFFFFFFFFu));
+                top_score[i * k + t] = s[j]; top_idx[i * k + t] = idx_base + j;
+            } else { top_score[i * k + t] = -INFINITY; top_idx[i * k + t] = -1; }
+        }
+    }
+    free(kv); free(s);
+}
+
+/* utils/metrics.py:33  `_, ranked_list = sim[i].sort(dim=0, descending=True)` made
+ * deterministic: full ranking of every row in canonical order. */
+ISXO_API void isxo_rank_full(const float* sim, int64_t M, int64_t N, int64_t* ranked) {
+    kv_t* kv = (kv_t*)malloc(sizeof(kv_t) * (size_t)(N > 0 ? N : 1));
+    for (int64_t i = 0; i < M; ++i) {
+        for (int64_t j = 0; j < N; ++j) kv[j].key = rank_key(sim[i * N + j], (uint64_t)j);
+        qsort(kv, (size_t)N, sizeof(kv_t), cmp_key_desc);
+        for (int64_t j = 0; j < N; ++j) ranked[i * N + j] = (int64_t)(0xFFFFFFFFu - (uint32_t)(kv[j].key & 0xFFFFFFFFu));
+    }
+    free(kv);
+}
+
+/* Same ranking restricted to the first k entries (what torch.topk / max / kthvalue
+ * consumers need): utils/metrics.py:10-13. */
+ISXO_API void isxo_topk_rows(const float* sim, int64_t M, int64_t N, int k, int64_t idx_base,
+                             float* top_score, int64_t* top_idx) {
+    kv_t* kv = (kv_t*)malloc(sizeof(kv_t) * (size_t)(N > 0 ? N : 1));
+    for (int64_t i = 0; i < M; ++i) {
+        for (int64_t j = 0; j < N; ++j) kv[j].key = rank_key(sim[i * N + j], (uint64_t)j);
+        qsort(kv, (size_t)N, sizeof(kv_t), cmp_key_desc);
+        for (int t = 0; t < k; ++t) {
+            if (t < N) {
+                int64_t j = (int64_t)(0xFFFFFFFFu - (uint32_t)(kv[t].key & 0xFFFFFFFFu));
+                top_score[i * k + t] = sim[i * N + j]; top_idx[i * k + t] = idx_base + j;
+            } else { top_score[i * k + t] = -INFINITY; top_idx[i * k + t] = -1; }
+        }
+    }
+    free(kv);
+}
+
+/* utils/metrics.py:25-45  avg_precision (Oxford-buildings trapezoid AP):
+ *   n_pos = #gallery with the query's label - (kth-1); None (here NaN) if <= 0
+ *   walk EVERY rank n; the first kth-1 ranks are skipped entirely;
+ *   recall = hits/float(n_pos); precision = hits/(j+1.0)
+ *   ap += (recall-old_recall) * ((old_precision+precision)/2.0), old_precision0 = 1
+ * All in float64, same operation order as the Python. */
+ISXO_API void isxo_average_precision(const int64_t* ranked, int64_t M, int64_t N,
+                                     const int32_t* qlab, const int32_t* glab, int kth, double* ap_out) {
+    for (int64_t i = 0; i < M; ++i) {
+        int64_t n_pos = 0;
+        for (int64_t j = 0; j < N; ++j) n_pos += (glab[j] == qlab[i]);
+        n_pos -= (kth - 1);
+        if (n_pos <= 0) { ap_out[i] = NAN; continue; }
+        double old_recall = 0.0, old_precision = 1.0, ap = 0.0;
+        int64_t hits = 0, j = 0;
+        for (int64_t n = 0; n < N; ++n) {
+            if (n + 1 < kth) continue;
+            if (glab[ranked[i * N + n]] == qlab[i]) hits += 1;
+            double recall = (double)hits / (double)n_pos;
+            double precision = (double)hits / ((double)j + 1.0);
+            ap += (recall - old_recall) * ((old_precision + precision) / 2.0);
+            old_recall = recall; old_precision = precision;
+            j += 1;
+        }
+        ap_out[i] = ap;
+    }
+}
+
+/* Multi-GPU merge (no reference counterpart: the reference is single-device,
+ * test/classif_finetune_test.py:82).  P per-shard lists (P,M,k), each already in
+ * canonical order with GLOBAL indices -> the k best of the union, canonical
+ * order; (-inf,-1) padding entries sort last. */
+ISXO_API void isxo_topk_merge(const float* scores, const int64_t* idx, int P, int64_t M, int k,
+                              float* out_s, int64_t* out_i) {
+    const size_t T = (size_t)P * k;
+    kv_t* kv = (kv_t*)malloc(sizeof(kv_t) * (T ? T : 1));
+    for (int64_t m = 0; m < M; ++m) {
+        size_t n = 0;
+        for (int p = 0; p < P; ++p)
+            for (int t = 0; t < k; ++t) {
+                size_t o = ((size_t)p * M + m) * k + t;
+                if (idx[o] < 0) continue;
+                kv[n].key = rank_key(scores[o], (uint64_t)idx[o]); kv[n].s = scores[o]; ++n;
+            }
+        qsort(kv, n, sizeof(kv_t), cmp_key_desc);
+        for (int t = 0; t < k; ++t) {
+            if ((size_t)t < n) {
+                out_s[m * k + t] = kv[t].s;
+                out_i[m * k + t] = (int64_t)(0xFFFFFFFFu - (uint32_t)(kv[t].key & 0xFFFFFFFFu));
+            } else { out_s[m * k + t] = -INFINITY; out_i[m * k + t] = -1; }
+        }
+    }
+    free(kv);
+}
+
+/* utils/train_siamese.py:74-76  sum_pos / sum_neg statistics of test_descriptor_net:
+ * sum of sim over label-equal pairs and over the rest (float64 accumulation;
+ * the reference adds 0-dim fp32 tensors one by one -- tolerance in the test). */
+ISXO_API void isxo_masked_sums(const float* sim, int64_t M, int64_t N, const int32_t* qlab,
+                               const int32_t* glab, double* sum_pos, double* sum_all) {
+    double sp = 0.0, sa = 0.0;
+    for (int64_t i = 0; i < M; ++i)
+        for (int64_t j = 0; j < N; ++j) {
+            double v = (double)sim[i * N + j];
+            sa += v; if (qlab[i] == glab[j]) sp += v;
+        }
+    *sum_pos = sp; *sum_all = sa;
+}

@@ -1,0 +1,164 @@
+"""ctypes/numpy front-end of the CPU oracle (oracle/isx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Nothing under instance-search_amd/ imports it.
+
+Every function takes/returns numpy arrays (fp32 C-contiguous, int64 indices,
+int32 labels) and forwards to the C restatement; see the C file for the
+reference citations (file:line) of each function.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libisx_oracle.so")
+_lib = None
+
+F32P = C.POINTER(C.c_float)
+I64P = C.POINTER(C.c_int64)
+I32P = C.POINTER(C.c_int32)
+F64P = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    """(Re)build libisx_oracle.so with gcc if missing or stale."""
+    src = os.path.join(_HERE, "isx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libisx_oracle.so"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def l2norm_rows(x, eps=1e-10):
+    x = _f32(x); B, D = x.shape; y = np.empty_like(x)
+    lib().isxo_l2norm_rows(_p(x, F32P), C.c_int64(B), C.c_int64(D), C.c_float(eps), _p(y, F32P))
+    return y
+
+
+def shift_rows(x, param):
+    x = _f32(x); param = _f32(param); y = np.empty_like(x)
+    lib().isxo_shift_rows(_p(x, F32P), _p(param, F32P), C.c_int64(x.shape[0]), C.c_int64(x.shape[1]), _p(y, F32P))
+    return y
+
+
+def gap_l2(fmap, eps=1e-10):
+    fmap = _f32(fmap); B, Cc, H, W = fmap.shape; y = np.empty((B, Cc), np.float32)
+    lib().isxo_gap_l2(_p(fmap, F32P), C.c_int64(B), Cc, H, W, C.c_float(eps), _p(y, F32P))
+    return y
+
+
+def boxpool_s1(fmap, kh, kw):
+    fmap = _f32(fmap); B, Cc, H, W = fmap.shape
+    out = np.empty((B, Cc, H - kh + 1, W - kw + 1), np.float32)
+    lib().isxo_boxpool_s1(_p(fmap, F32P), C.c_int64(B), Cc, H, W, kh, kw, _p(out, F32P))
+    return out
+
+
+def best_location_desc(cls, eps=1e-10):
+    cls = _f32(cls); K, Hp, Wp = cls.shape[-3:]
+    desc = np.empty((K,), np.float32); loc = np.empty((2,), np.int64)
+    lib().isxo_best_location_desc(_p(cls, F32P), K, Hp, Wp, C.c_float(eps), _p(desc, F32P), _p(loc, I64P))
+    return desc, loc
+
+
+def region_topk(cls, k):
+    cls = _f32(cls); K, Hp, Wp = cls.shape[-3:]
+    idx = np.empty((k,), np.int64); sc = np.empty((k,), np.float32)
+    lib().isxo_region_topk.restype = C.c_int
+    n = lib().isxo_region_topk(_p(cls, F32P), K, Hp, Wp, k, _p(idx, I64P), _p(sc, F32P))
+    return idx[:n].copy(), sc[:n].copy()
+
+
+def region_gather_l2(fmap, kh, kw, flat_idx, Wp, shift=None, eps=1e-10):
+    fmap = _f32(fmap); Cc, Hf, Wf = fmap.shape[-3:]
+    flat_idx = np.ascontiguousarray(flat_idx, np.int64); k = flat_idx.shape[0]
+    rows = np.empty((k, Cc * kh * kw), np.float32)
+    sp = None
+    if shift is not None:
+        shift = _f32(shift); sp = _p(shift, F32P)
+    lib().isxo_region_gather_l2(_p(fmap, F32P), Cc, Hf, Wf, kh, kw, _p(flat_idx, I64P), k, Wp, sp,
+                                C.c_float(eps), _p(rows, F32P))
+    return rows
+
+
+def cosine_sim(Q, G):
+    Q = _f32(Q); G = _f32(G); M, D = Q.shape; N = G.shape[0]
+    sim = np.empty((M, N), np.float32)
+    lib().isxo_cosine_sim(_p(Q, F32P), C.c_int64(M), _p(G, F32P), C.c_int64(N), D, _p(sim, F32P))
+    return sim
+
+
+def cosine_topk(Q, G, k, idx_base=0):
+    Q = _f32(Q); G = _f32(G); M, D = Q.shape; N = G.shape[0]
+    ts = np.empty((M, k), np.float32); ti = np.empty((M, k), np.int64)
+    lib().isxo_cosine_topk(_p(Q, F32P), C.c_int64(M), _p(G, F32P), C.c_int64(N), D, k, C.c_int64(idx_base),
+                           _p(ts, F32P), _p(ti, I64P))
+    return ts, ti
+
+
+def rank_full(sim):
+    sim = _f32(sim); M, N = sim.shape; r = np.empty((M, N), np.int64)
+    lib().isxo_rank_full(_p(sim, F32P), C.c_int64(M), C.c_int64(N), _p(r, I64P))
+    return r
+
+
+def topk_rows(sim, k, idx_base=0):
+    sim = _f32(sim); M, N = sim.shape
+    ts = np.empty((M, k), np.float32); ti = np.empty((M, k), np.int64)
+    lib().isxo_topk_rows(_p(sim, F32P), C.c_int64(M), C.c_int64(N), k, C.c_int64(idx_base), _p(ts, F32P), _p(ti, I64P))
+    return ts, ti
+
+
+def average_precision(ranked, qlab, glab, kth=1):
+    ranked = np.ascontiguousarray(ranked, np.int64); M, N = ranked.shape
+    qlab = np.ascontiguousarray(qlab, np.int32); glab = np.ascontiguousarray(glab, np.int32)
+    ap = np.empty((M,), np.float64)
+    lib().isxo_average_precision(_p(ranked, I64P), C.c_int64(M), C.c_int64(N), _p(qlab, I32P), _p(glab, I32P), kth,
+                                 _p(ap, F64P))
+    return ap
+
+
+def mean_avg_precision(ap):
+    """utils/metrics.py:48-55: plain sequential Python sum over the non-skipped queries."""
+    vals = [float(a) for a in ap if not np.isnan(a)]
+    return sum(vals) / float(len(vals))
+
+
+def topk_merge(scores, idx):
+    scores = _f32(scores); idx = np.ascontiguousarray(idx, np.int64); P, M, k = scores.shape
+    os_ = np.empty((M, k), np.float32); oi = np.empty((M, k), np.int64)
+    lib().isxo_topk_merge(_p(scores, F32P), _p(idx, I64P), P, C.c_int64(M), k, _p(os_, F32P), _p(oi, I64P))
+    return os_, oi
+
+
+def masked_sums(sim, qlab, glab):
+    sim = _f32(sim); M, N = sim.shape
+    qlab = np.ascontiguousarray(qlab, np.int32); glab = np.ascontiguousarray(glab, np.int32)
+    sp = C.c_double(); sa = C.c_double()
+    lib().isxo_masked_sums(_p(sim, F32P), C.c_int64(M), C.c_int64(N), _p(qlab, I32P), _p(glab, I32P),
+                           C.byref(sp), C.byref(sa))
+    return sp.value, sa.value
+
+
+def precision1(top_idx, qlab, glab, kth=1):
+    """utils/metrics.py:8-19 on a canonical top-k list: the hit is the kth ranked item."""
+    hit = np.asarray(glab)[np.asarray(top_idx)[:, max(kth, 1) - 1]]
+    correct = int((hit == np.asarray(qlab)).sum())
+    return correct / float(len(qlab)), correct, len(qlab), hit
