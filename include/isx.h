@@ -1,0 +1,138 @@
+/*
+ * isx.h -- C ABI of libisx.so: the MI355X (gfx950) descriptor-pooling and
+ * nearest-neighbour retrieval kernels behind the Python surface of
+ * maxgreat/Instance-Search (model/custom_modules, model/siamese,
+ * train/<approach>.py::get_embeddings, utils/metrics, test/<approach>_test.py).
+ *
+ * The reference has no FFI of its own: every entry below replaces a run of stock
+ * torch calls in the reference's Python; the file:line it replaces is cited per
+ * entry (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller, row-major contiguous;
+ *     fp32 values, int64 indices, int32 labels, fp64 AP values
+ *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and
+ *     returns; no allocation, no synchronisation, no global state: safe to capture
+ *     in a hipGraph and re-entrant from several host threads on distinct streams
+ *   - return 0 = ISX_OK, <0 = error; isx_last_error() gives a thread-local message
+ *   - canonical ranking order everywhere: (score DESCENDING, index ASCENDING),
+ *     -0.0 == +0.0; gallery indices must be < 2^32
+ *   - canonical dot product: k-ordered fp32 fma chain from +0.0f, which is what
+ *     v_mfma_f32_32x32x2_f32 computes bit for bit
+ */
+#ifndef ISX_H_
+#define ISX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISX_OK 0
+#define ISX_ERR_ARG (-1)       /* bad shape / pointer / unsupported size */
+#define ISX_ERR_WORKSPACE (-2) /* workspace too small */
+#define ISX_ERR_HIP (-3)       /* a HIP launch failed */
+
+typedef void* isx_stream_t; /* hipStream_t */
+
+const char* isx_last_error(void);
+int isx_version(void);
+
+/* ---- descriptor head ------------------------------------------------------- */
+
+/* model/custom_modules.py:52-57 NormalizeL2Fun.forward: y = x / sqrt(sum_j x_j^2 + eps),
+ * eps INSIDE the sqrt.  x, y: (B, D).  In-place (y == x) allowed. */
+int isx_l2norm_rows(const float* x, int64_t B, int64_t D, float eps, float* y, isx_stream_t stream);
+
+/* model/siamese.py:110-113 feature_reduc1[0:2] = NormalizeL2 -> Shift
+ * (custom_modules.py:52-57 then :16-18): y = x / sqrt(sum x^2 + eps) + shift.
+ * shift: (F) or NULL.  x, y: (B, F). */
+int isx_l2norm_shift_rows(const float* x, const float* shift, int64_t B, int64_t F, float eps, float* y,
+                          isx_stream_t stream);
+
+/* model/siamese.py:49-54 TuneClassif.forward with the classifier stripped
+ * (train/classif_finetune.py:87-90) + NormalizeL2Fun (:100): global average pool over
+ * the whole HxW map, flatten, L2.  fmap: (B,C,H,W) NCHW; y: (B,C). */
+int isx_gap_l2(const float* fmap, int64_t B, int C, int H, int W, float eps, float* y, isx_stream_t stream);
+
+/* model/siamese.py:67-71 nn.AvgPool2d(feature_size2d, stride=1) of TuneClassifSub /
+ * RegionDescriptorNet.  fmap: (B,C,H,W); out: (B,C,H-kh+1,W-kw+1). */
+int isx_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out,
+                   isx_stream_t stream);
+
+/* ---- region path ----------------------------------------------------------- */
+
+/* train/classif_regions.py:118-128: class-max map, spatial arg-max (smallest column,
+ * then smallest row on ties), gather the K class scores there, L2.
+ * cls: (B,K,Hp,Wp); desc: (B,K); loc: (B,2) = {row i1, col i2}. */
+int isx_best_location_desc(const float* cls, int64_t B, int K, int Hp, int Wp, float eps, float* desc,
+                           int64_t* loc, isx_stream_t stream);
+
+/* model/siamese.py:191-194: c_maxv = c.max(1).view(-1); topk(min(len,k)) in canonical
+ * order.  cls: (K,Hp,Wp) of ONE image; flat_idx, score: (k); entries past Hp*Wp are
+ * (-1, -inf).  Hp*Wp <= 4096. */
+int isx_region_topk(const float* cls, int K, int Hp, int Wp, int k, int64_t* flat_idx, float* score,
+                    isx_stream_t stream);
+
+/* model/siamese.py:199-219: for each of the k windows (row,col) = (idx / Wp, idx % Wp):
+ * x[:, :, row:row+kh, col:col+kw] flattened (C,h,w) -> NormalizeL2 -> Shift.
+ * fmap: (C,Hf,Wf) of ONE image; rows: (k, C*kh*kw); shift (C*kh*kw) or NULL.
+ * Windows with flat_idx < 0 produce zero rows. */
+int isx_region_gather_l2(const float* fmap, int C, int Hf, int Wf, int kh, int kw, const int64_t* flat_idx, int k,
+                         int Wp, const float* shift, float eps, float* rows, isx_stream_t stream);
+
+/* ---- retrieval ------------------------------------------------------------- */
+
+/* test/classif_finetune_test.py:82 (and classif_regions_test.py:73,
+ * siamese_descriptor_test.py:77, siamese_regions_test.py:76, utils/train_siamese.py:53,70)
+ * sim = torch.mm(Q, G.t()).  Q: (M,D); G: (N,D); sim: (M,N).  fp32 MFMA. */
+int isx_cosine_sim(const float* Q, int64_t M, const float* G, int64_t N, int D, float* sim, isx_stream_t stream);
+
+/* Fused torch.mm -> sort/topk/max (same call sites + utils/metrics.py:10-13,33): the k
+ * best gallery rows per query in canonical order, never materialising more than a
+ * column chunk of the (M,N) matrix.  top_idx = idx_base + row of G.  Entries past N
+ * are (-inf, -1).  1 <= k <= 1024.  ws from isx_cosine_topk_workspace (any size >= the
+ * minimum it documents works; larger = fewer, bigger chunks). */
+size_t isx_cosine_topk_workspace(int64_t M, int64_t N, int D, int k);
+int isx_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N, int D, int k, int64_t idx_base,
+                    float* top_score, int64_t* top_idx, void* ws, size_t ws_bytes, isx_stream_t stream);
+
+/* utils/metrics.py:10-13 sim.max(1) / sim.kthvalue(...) on a materialised matrix: the k
+ * best columns per row, canonical order.  sim: (M,N).  1 <= k <= 1024. */
+int isx_topk_rows(const float* sim, int64_t M, int64_t N, int k, int64_t idx_base, float* top_score,
+                  int64_t* top_idx, isx_stream_t stream);
+
+/* utils/metrics.py:33 `_, ranked_list = sim[i].sort(dim=0, descending=True)` for every
+ * row, made deterministic (canonical order).  ranked: (M,N) int64. */
+size_t isx_rank_full_workspace(int64_t M, int64_t N);
+int isx_rank_full(const float* sim, int64_t M, int64_t N, int64_t* ranked, void* ws, size_t ws_bytes,
+                  isx_stream_t stream);
+
+/* utils/metrics.py:25-45 avg_precision for every query (Oxford trapezoid AP, float64,
+ * same operation order as the Python loop).  ap[i] = NaN where the reference returns
+ * None (n_pos <= 0).  ranked: (M,N); qlab: (M); glab: (N). */
+int isx_average_precision(const int64_t* ranked, int64_t M, int64_t N, const int32_t* qlab, const int32_t* glab,
+                          int kth, double* ap, isx_stream_t stream);
+
+/* utils/train_siamese.py:74-76 sum_pos / (sum_neg + sum_pos) of test_descriptor_net, per
+ * query row (the host adds the M row values in order, which keeps the result
+ * deterministic): out[2*i] = sum_j sim[i][j] over label-equal pairs, out[2*i+1] = sum_j
+ * sim[i][j] over all j; float64.  out: (M,2). */
+int isx_masked_sums(const float* sim, int64_t M, int64_t N, const int32_t* qlab, const int32_t* glab, double* out,
+                    isx_stream_t stream);
+
+/* ---- multi-GPU (no reference counterpart: one torch.mm on one device,
+ *      test/classif_finetune_test.py:82; BASELINE config 5 shards the gallery rows) --- */
+
+/* Merge P per-shard canonical top-k lists (after the RCCL all-gather) into the global
+ * top-k.  scores, idx: (P,M,k) with GLOBAL indices, (-inf,-1) padding allowed;
+ * out: (M,k).  P*k <= 4096. */
+int isx_topk_merge(const float* scores, const int64_t* idx, int P, int64_t M, int k, float* out_s, int64_t* out_i,
+                   isx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISX_H_ */

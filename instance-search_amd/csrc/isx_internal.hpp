@@ -1,0 +1,20 @@
+// isx_internal.hpp -- launchers shared between translation units of libisx.
+#pragma once
+#include "isx_common.hpp"
+
+namespace isx {
+
+// C[m][n] = sum_k Q[m][k] * G[n][k]  (k-ordered fp32 fma chain), C row stride ldc.
+int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
+                       hipStream_t st);
+
+// Per-row running top-k over a score chunk.  sim: (M, Nc) with row stride ld; column j
+// of the chunk is gallery row col_base + j.  carry: (M, k) u64 keys (canonical order,
+// 0 = empty); read unless `first`, written unless `emit`.  With `emit` the final
+// (score, idx_base + index) lists are written instead.
+int launch_select(const float* sim, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k, uint64_t* carry,
+                  bool first, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx, hipStream_t st);
+
+constexpr int kSelectMaxK = 1024;
+
+}  // namespace isx

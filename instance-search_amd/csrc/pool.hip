@@ -1,0 +1,293 @@
+// pool.hip -- descriptor-head kernels: L2 row normalisation (+Shift), fused global
+// average pool + L2, stride-1 box pooling.  All HBM-bound: coalesced 16 B/lane loads,
+// LDS staging where a thread must walk a strided segment, wave-shuffle reductions.
+//
+// Reference behaviour restated (paths under the reference repo):
+//   model/custom_modules.py:52-57  NormalizeL2Fun.forward
+//   model/custom_modules.py:16-18  ShiftFun.forward
+//   model/siamese.py:49-54         TuneClassif.forward (AvgPool2d(7) -> view)
+//   model/siamese.py:67-71         nn.AvgPool2d(feature_size2d, stride=1)
+#include "isx_common.hpp"
+
+namespace isx {
+
+// ------------------------------------------------------------------ l2norm ----
+// One wave per row, the row cached in registers (D <= 64*4*ITERS, 16-B aligned rows).
+template <int ITERS>
+__global__ __launch_bounds__(256) void l2norm_rows_wave_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ shift, int64_t B, int D,
+                                                               float eps, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+    const int nv = D >> 2;
+    float4 v[ITERS];
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = lane + i * 64;
+        v[i] = (c < nv) ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        ss += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    }
+    ss = wave_sum(ss);
+    const float n = sqrtf(ss + eps);
+    float4* yr = reinterpret_cast<float4*>(y + row * D);
+    const float4* sh = reinterpret_cast<const float4*>(shift);
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nv) {
+            float4 o = make_float4(v[i].x / n, v[i].y / n, v[i].z / n, v[i].w / n);
+            if (shift) { float4 s = sh[c]; o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w; }
+            yr[c] = o;
+        }
+    }
+}
+
+// One 1024-thread block per row, two passes (the second re-reads the row from L2);
+// any D, any alignment when VEC == false.
+template <bool VEC>
+__global__ __launch_bounds__(1024) void l2norm_rows_block_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ shift, int64_t D, float eps,
+                                                                 float* __restrict__ y) {
+    __shared__ float red[16];
+    const float* xr = x + (int64_t)blockIdx.x * D;
+    float* yr = y + (int64_t)blockIdx.x * D;
+    float ss = 0.0f;
+    if (VEC) {
+        const float4* x4 = reinterpret_cast<const float4*>(xr);
+        for (int64_t c = threadIdx.x; c < (D >> 2); c += 1024) {
+            float4 v = x4[c];
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+    } else {
+        for (int64_t c = threadIdx.x; c < D; c += 1024) ss += xr[c] * xr[c];
+    }
+    ss = block_sum<1024>(ss, red);
+    const float n = sqrtf(ss + eps);
+    if (VEC) {
+        const float4* x4 = reinterpret_cast<const float4*>(xr);
+        const float4* s4 = reinterpret_cast<const float4*>(shift);
+        float4* y4 = reinterpret_cast<float4*>(yr);
+        for (int64_t c = threadIdx.x; c < (D >> 2); c += 1024) {
+            float4 v = x4[c];
+            float4 o = make_float4(v.x / n, v.y / n, v.z / n, v.w / n);
+            if (shift) { float4 s = s4[c]; o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w; }
+            y4[c] = o;
+        }
+    } else {
+        for (int64_t c = threadIdx.x; c < D; c += 1024) yr[c] = xr[c] / n + (shift ? shift[c] : 0.0f);
+    }
+}
+
+// ------------------------------------------------------------------- gap_l2 ---
+// One 256-thread block per image.  Channels are processed in passes of CP channels:
+// the CP*HW floats of a pass are contiguous in NCHW, so they are streamed into LDS
+// with 16-B coalesced loads; thread c then sums its channel's HW values IN ORDER (the
+// summation order of torch's CPU avg_pool2d, so pooled values are bit-identical to
+// the oracle's).  LDS channel stride is HW|1 (odd) -> conflict-free ds_read_b32.
+// Pooled values stay in registers (<= MAXP passes); sum of squares by butterfly.
+constexpr int kGapThreads = 256;
+constexpr int kGapMaxPasses = 16;
+
+template <bool VEC>
+__global__ __launch_bounds__(kGapThreads) void gap_l2_kernel(const float* __restrict__ fmap, int C, int HW, int CP,
+                                                            int stride, float eps, float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    __shared__ float red[kGapThreads / 64];
+    const int tid = threadIdx.x;
+    const float* img = fmap + (int64_t)blockIdx.x * C * HW;
+    const float inv_div = (float)HW;
+    float pooled[kGapMaxPasses];
+    float ss = 0.0f;
+    const int passes = (C + CP - 1) / CP;
+#pragma unroll 1
+    for (int p = 0; p < passes; ++p) {
+        const int c0 = p * CP;
+        const int nch = min(CP, C - c0);
+        const int nel = nch * HW;
+        const float* src = img + (int64_t)c0 * HW;
+        __syncthreads();   // previous pass fully consumed
+        if (VEC && stride == HW) {
+            // linear image: float4 copy (src 16-B aligned: host checked (CP*HW)%4==0)
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            float4* d4 = reinterpret_cast<float4*>(lds);
+            const int nv = nel >> 2;
+            for (int i = tid; i < nv; i += kGapThreads) d4[i] = s4[i];
+            for (int i = (nv << 2) + tid; i < nel; i += kGapThreads) lds[i] = src[i];
+        } else if (VEC) {
+            const float4* s4 = reinterpret_cast<const float4*>(src);
+            const int nv = nel >> 2;
+            for (int i = tid; i < nv; i += kGapThreads) {
+                float4 v = s4[i];
+                int e = i << 2;
+                int ch = e / HW, off = e - ch * HW;
+                float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lds[ch * stride + off] = vv[j];
+                    if (++off == HW) { off = 0; ++ch; }
+                }
+            }
+            for (int i = (nv << 2) + tid; i < nel; i += kGapThreads) { int ch = i / HW; lds[ch * stride + (i - ch * HW)] = src[i]; }
+        } else {
+            for (int i = tid; i < nel; i += kGapThreads) { int ch = i / HW; lds[ch * stride + (i - ch * HW)] = src[i]; }
+        }
+        __syncthreads();
+        float s = 0.0f;
+        if (tid < nch) {
+            const float* r = lds + tid * stride;
+            for (int i = 0; i < HW; ++i) s += r[i];
+            s = s / inv_div;
+        }
+        // static register index (guide rule 20): unrolled select
+#pragma unroll
+        for (int q = 0; q < kGapMaxPasses; ++q) if (q == p) pooled[q] = s;
+        ss += s * s;
+    }
+    ss = block_sum<kGapThreads>(ss, red);
+    const float n = sqrtf(ss + eps);
+    float* yr = y + (int64_t)blockIdx.x * C;
+#pragma unroll
+    for (int q = 0; q < kGapMaxPasses; ++q) {
+        const int c = q * CP + tid;
+        if (q < passes && tid < CP && c < C) yr[c] = pooled[q] / n;
+    }
+}
+
+// Fallback for huge maps / channel counts: wave per (image, channel) sum, pooled written
+// to y, then the row kernel normalises in place.
+__global__ __launch_bounds__(256) void gap_only_kernel(const float* __restrict__ fmap, int64_t BC, int HW,
+                                                       float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t bc = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bc >= BC) return;
+    const float* p = fmap + bc * HW;
+    float s = 0.0f;
+    for (int i = lane; i < HW; i += 64) s += p[i];
+    s = wave_sum(s);
+    if (lane == 0) y[bc] = s / (float)HW;
+}
+
+// ---------------------------------------------------------------- boxpool_s1 --
+// PP whole (b,c) planes per block staged in LDS; each thread produces outputs by an
+// in-order kh x kw walk (bit-identical to torch's CPU avg_pool2d).
+__global__ __launch_bounds__(256) void boxpool_s1_kernel(const float* __restrict__ fmap, int64_t BC, int H, int W, int kh,
+                                                         int kw, int PP, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int HWi = H * W, Ho = H - kh + 1, Wo = W - kw + 1, HWo = Ho * Wo;
+    const int64_t p0 = (int64_t)blockIdx.x * PP;
+    const int np = (int)min((int64_t)PP, BC - p0);
+    const float* src = fmap + p0 * HWi;
+    for (int i = threadIdx.x; i < np * HWi; i += 256) lds[i] = src[i];
+    __syncthreads();
+    const float div = (float)(kh * kw);
+    float* dst = out + p0 * HWo;
+    for (int o = threadIdx.x; o < np * HWo; o += 256) {
+        const int pl = o / HWo, r = o - pl * HWo, i = r / Wo, j = r - i * Wo;
+        const float* b = lds + pl * HWi + i * W + j;
+        float s = 0.0f;
+        for (int a = 0; a < kh; ++a)
+            for (int c = 0; c < kw; ++c) s += b[a * W + c];
+        dst[o] = s / div;
+    }
+}
+
+__global__ __launch_bounds__(256) void boxpool_s1_direct_kernel(const float* __restrict__ fmap, int64_t total, int H, int W,
+                                                                int kh, int kw, float* __restrict__ out) {
+    const int Ho = H - kh + 1, Wo = W - kw + 1, HWo = Ho * Wo;
+    for (int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x; o < total; o += (int64_t)gridDim.x * 256) {
+        const int64_t pl = o / HWo;
+        const int r = (int)(o - pl * HWo), i = r / Wo, j = r - i * Wo;
+        const float* b = fmap + pl * H * W + i * W + j;
+        float s = 0.0f;
+        for (int a = 0; a < kh; ++a)
+            for (int c = 0; c < kw; ++c) s += b[a * W + c];
+        out[o] = s / (float)(kh * kw);
+    }
+}
+
+}  // namespace isx
+
+using namespace isx;
+
+static int launch_l2norm(const float* x, const float* shift, int64_t B, int64_t D, float eps, float* y, hipStream_t st) {
+    if (B == 0 || D == 0) return ISX_OK;
+    const bool aligned = (D % 4 == 0) && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)shift) % 16 == 0);
+    if (aligned && D <= 64 * 4 * 8) {
+        const unsigned grid = (unsigned)((B + 3) / 4);
+        if (D <= 256) hipLaunchKernelGGL(l2norm_rows_wave_kernel<1>, dim3(grid), dim3(256), 0, st, x, shift, B, (int)D, eps, y);
+        else if (D <= 512) hipLaunchKernelGGL(l2norm_rows_wave_kernel<2>, dim3(grid), dim3(256), 0, st, x, shift, B, (int)D, eps, y);
+        else if (D <= 1024) hipLaunchKernelGGL(l2norm_rows_wave_kernel<4>, dim3(grid), dim3(256), 0, st, x, shift, B, (int)D, eps, y);
+        else hipLaunchKernelGGL(l2norm_rows_wave_kernel<8>, dim3(grid), dim3(256), 0, st, x, shift, B, (int)D, eps, y);
+    } else if (aligned) {
+        hipLaunchKernelGGL(l2norm_rows_block_kernel<true>, dim3((unsigned)B), dim3(1024), 0, st, x, shift, D, eps, y);
+    } else {
+        hipLaunchKernelGGL(l2norm_rows_block_kernel<false>, dim3((unsigned)B), dim3(1024), 0, st, x, shift, D, eps, y);
+    }
+    ISX_CHECK_LAUNCH("isx_l2norm_rows");
+    return ISX_OK;
+}
+
+ISX_API int isx_l2norm_rows(const float* x, int64_t B, int64_t D, float eps, float* y, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && D >= 0 && B < (1ll << 31), "isx_l2norm_rows: bad shape B=%lld D=%lld", (long long)B, (long long)D);
+    ISX_REQUIRE((x && y) || B * D == 0, "isx_l2norm_rows: null pointer");
+    return launch_l2norm(x, nullptr, B, D, eps, y, (hipStream_t)stream);
+}
+
+ISX_API int isx_l2norm_shift_rows(const float* x, const float* shift, int64_t B, int64_t F, float eps, float* y,
+                                  isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && F >= 0 && B < (1ll << 31), "isx_l2norm_shift_rows: bad shape B=%lld F=%lld", (long long)B, (long long)F);
+    ISX_REQUIRE((x && y) || B * F == 0, "isx_l2norm_shift_rows: null pointer");
+    return launch_l2norm(x, shift, B, F, eps, y, (hipStream_t)stream);
+}
+
+ISX_API int isx_gap_l2(const float* fmap, int64_t B, int C, int H, int W, float eps, float* y, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && B < (1ll << 31), "isx_gap_l2: bad shape B=%lld C=%d H=%d W=%d", (long long)B, C, H, W);
+    ISX_REQUIRE(fmap && y, "isx_gap_l2: null pointer");
+    if (B == 0) return ISX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int HW = H * W;
+    const int stride = HW | 1;
+    const size_t budget = 52 * 1024;   // 3 blocks per CU
+    int CP = kGapThreads;
+    while (CP > 32 && (size_t)CP * stride * 4 > budget) CP >>= 1;
+    const bool fits = (size_t)CP * stride * 4 <= budget && (C + CP - 1) / CP <= kGapMaxPasses;
+    if (!fits) {
+        const int64_t BC = B * C;
+        hipLaunchKernelGGL(gap_only_kernel, dim3((unsigned)((BC + 3) / 4)), dim3(256), 0, st, fmap, BC, HW, y);
+        ISX_CHECK_LAUNCH("isx_gap_l2(pool)");
+        return launch_l2norm(y, nullptr, B, C, eps, y, st);
+    }
+    const bool vec = ((uintptr_t)fmap % 16 == 0) && (((int64_t)C * HW) % 4 == 0) && (((int64_t)CP * HW) % 4 == 0);
+    const size_t lds = (size_t)CP * stride * 4;
+    if (vec) hipLaunchKernelGGL(gap_l2_kernel<true>, dim3((unsigned)B), dim3(kGapThreads), lds, st, fmap, C, HW, CP, stride, eps, y);
+    else hipLaunchKernelGGL(gap_l2_kernel<false>, dim3((unsigned)B), dim3(kGapThreads), lds, st, fmap, C, HW, CP, stride, eps, y);
+    ISX_CHECK_LAUNCH("isx_gap_l2");
+    return ISX_OK;
+}
+
+ISX_API int isx_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out,
+                           isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && kh <= H && kw <= W,
+                "isx_boxpool_s1: bad shape B=%lld C=%d H=%d W=%d k=%dx%d", (long long)B, C, H, W, kh, kw);
+    ISX_REQUIRE(fmap && out, "isx_boxpool_s1: null pointer");
+    if (B == 0) return ISX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t BC = B * C;
+    const size_t plane = (size_t)H * W * 4;
+    if (plane <= 48 * 1024) {
+        int PP = (int)((48 * 1024) / plane);
+        if (PP > 64) PP = 64;
+        const int64_t grid = (BC + PP - 1) / PP;
+        ISX_REQUIRE(grid < (1ll << 31), "isx_boxpool_s1: too many planes");
+        hipLaunchKernelGGL(boxpool_s1_kernel, dim3((unsigned)grid), dim3(256), (size_t)PP * plane, st, fmap, BC, H, W, kh, kw, PP, out);
+    } else {
+        const int64_t total = BC * (H - kh + 1) * (W - kw + 1);
+        const unsigned grid = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+        hipLaunchKernelGGL(boxpool_s1_direct_kernel, dim3(grid), dim3(256), 0, st, fmap, total, H, W, kh, kw, out);
+    }
+    ISX_CHECK_LAUNCH("isx_boxpool_s1");
+    return ISX_OK;
+}

@@ -1,0 +1,256 @@
+// rank.hip -- full canonical ranking of every query row, Oxford-style average precision
+// and the label-masked similarity sums of the evaluator.
+//
+// Reference behaviour restated:
+//   utils/metrics.py:33      `_, ranked_list = sim[i].sort(dim=0, descending=True)`
+//   utils/metrics.py:25-45   avg_precision (trapezoid AP in float64, rank by rank)
+//   utils/train_siamese.py:74-76  sum_pos / sum_neg statistics
+//
+// Ranking = bitonic sort of u64 keys (orderable(score) << 32 | ~index), descending: the
+// canonical (score desc, index asc) order with no ties left.  Rows up to 4096 columns
+// are sorted entirely in LDS by one workgroup; longer rows sort 4096-key tiles in LDS
+// and finish the large strides with coalesced global compare-exchange passes.
+#include "isx_common.hpp"
+
+namespace isx {
+
+constexpr int RK_TILE = 4096;
+constexpr int RK_THREADS = 256;
+
+// strides < tile inside a tile whose first key has global position gbase; sizes from
+// size_lo to size_hi (inclusive), for size > tile only strides <= tile/2 are done.
+__device__ __forceinline__ void bitonic_tile(uint64_t* keys, int tile, int64_t gbase, int64_t size_lo, int64_t size_hi) {
+    for (int64_t size = size_lo; size <= size_hi; size <<= 1) {
+        int s0 = (int)(size >> 1 < tile ? size >> 1 : tile >> 1);
+        for (int stride = s0; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < (tile >> 1); t += RK_THREADS) {
+                const int lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+                const bool desc = (((gbase + lo) & size) == 0);
+                const uint64_t a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) { keys[lo] = b; keys[hi] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// N2 <= RK_TILE: one workgroup per row does everything.
+__global__ __launch_bounds__(RK_THREADS) void rank_small_kernel(const float* __restrict__ sim, int64_t N, int N2,
+                                                                int64_t* __restrict__ ranked) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    const int64_t row = blockIdx.x;
+    for (int j = threadIdx.x; j < N2; j += RK_THREADS) keys[j] = (j < N) ? rank_key(sim[row * N + j], (uint32_t)j) : 0ull;
+    bitonic_tile(keys, N2, 0, 2, N2);
+    for (int j = threadIdx.x; j < N; j += RK_THREADS) ranked[row * N + j] = key_idx(keys[j]);
+}
+
+// Large rows, phase 1: build keys and sort each RK_TILE tile (alternating directions).
+__global__ __launch_bounds__(RK_THREADS) void rank_tile_sort_kernel(const float* __restrict__ sim, int64_t N, int64_t N2,
+                                                                    uint64_t* __restrict__ gkeys) {
+    __shared__ __attribute__((aligned(16))) uint64_t keys[RK_TILE];
+    const int64_t row = blockIdx.y, gbase = (int64_t)blockIdx.x * RK_TILE;
+    for (int j = threadIdx.x; j < RK_TILE; j += RK_THREADS) {
+        const int64_t g = gbase + j;
+        keys[j] = (g < N) ? rank_key(sim[row * N + g], (uint32_t)g) : 0ull;
+    }
+    bitonic_tile(keys, RK_TILE, gbase, 2, RK_TILE);
+    uint64_t* dst = gkeys + row * N2 + gbase;
+    for (int j = threadIdx.x; j < RK_TILE; j += RK_THREADS) dst[j] = keys[j];
+}
+
+// One global compare-exchange pass at distance `stride` (>= RK_TILE) of merge level `size`.
+__global__ __launch_bounds__(RK_THREADS) void rank_global_step_kernel(uint64_t* __restrict__ gkeys, int64_t N2, int64_t size,
+                                                                      int64_t stride) {
+    const int64_t row = blockIdx.y;
+    uint64_t* k = gkeys + row * N2;
+    const int64_t t = (int64_t)blockIdx.x * RK_THREADS + threadIdx.x;   // pair index < N2/2
+    const int64_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+    const bool desc = ((lo & size) == 0);
+    const uint64_t a = k[lo], b = k[hi];
+    if ((a < b) == desc) { k[lo] = b; k[hi] = a; }
+}
+
+// Remaining strides (< RK_TILE) of merge level `size`, tile by tile in LDS.
+__global__ __launch_bounds__(RK_THREADS) void rank_tile_finish_kernel(uint64_t* __restrict__ gkeys, int64_t N2, int64_t size) {
+    __shared__ __attribute__((aligned(16))) uint64_t keys[RK_TILE];
+    const int64_t row = blockIdx.y, gbase = (int64_t)blockIdx.x * RK_TILE;
+    uint64_t* src = gkeys + row * N2 + gbase;
+    for (int j = threadIdx.x; j < RK_TILE; j += RK_THREADS) keys[j] = src[j];
+    bitonic_tile(keys, RK_TILE, gbase, size, size);
+    for (int j = threadIdx.x; j < RK_TILE; j += RK_THREADS) src[j] = keys[j];
+}
+
+__global__ __launch_bounds__(RK_THREADS) void rank_emit_kernel(const uint64_t* __restrict__ gkeys, int64_t N, int64_t N2,
+                                                               int64_t* __restrict__ ranked) {
+    const int64_t row = blockIdx.y;
+    const int64_t j = (int64_t)blockIdx.x * RK_THREADS + threadIdx.x;
+    if (j < N) ranked[row * N + j] = key_idx(gkeys[row * N2 + j]);
+}
+
+// ------------------------------------------------------------ average precision --
+constexpr int AP_PER_THREAD = 8;
+constexpr int AP_CHUNK = RK_THREADS * AP_PER_THREAD;
+
+__global__ __launch_bounds__(RK_THREADS) void average_precision_kernel(const int64_t* __restrict__ ranked, int64_t N,
+                                                                       const int32_t* __restrict__ qlab,
+                                                                       const int32_t* __restrict__ glab, int kth,
+                                                                       double* __restrict__ ap_out) {
+    __shared__ double terms[AP_CHUNK];
+    __shared__ int wsum[RK_THREADS / 64];
+    __shared__ int chunk_hits_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row = blockIdx.x;
+    const int32_t q = qlab[row];
+    const int64_t* rk = ranked + row * N;
+
+    // n_pos = #gallery items with the query's label - (kth - 1)     (metrics.py:27-28)
+    int cnt = 0;
+    for (int64_t j = tid; j < N; j += RK_THREADS) cnt += (glab[j] == q);
+    cnt = wave_sum(cnt);
+    if (lane == 0) wsum[wave] = cnt;
+    __syncthreads();
+    int64_t n_pos = 0;
+    for (int i = 0; i < RK_THREADS / 64; ++i) n_pos += wsum[i];
+    n_pos -= (kth - 1);
+    if (n_pos <= 0) {                                        // metrics.py:29-30 -> None
+        if (tid == 0) ap_out[row] = __longlong_as_double(0x7FF8000000000000ll);
+        return;
+    }
+    const double dn = (double)n_pos;
+    double ap = 0.0;                                         // thread 0's sequential accumulator
+    int64_t hits_before = 0;                                 // uniform: hits in earlier chunks
+    const int64_t skip = kth - 1;                            // ranks n < skip are ignored entirely
+
+    for (int64_t c0 = skip; c0 < N; c0 += AP_CHUNK) {
+        const int64_t n0 = c0 + (int64_t)tid * AP_PER_THREAD;
+        bool hit[AP_PER_THREAD];
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < AP_PER_THREAD; ++e) {
+            const int64_t n = n0 + e;
+            hit[e] = (n < N) && (glab[rk[n < N ? n : 0]] == q);
+            c += hit[e] ? 1 : 0;
+        }
+        // block exclusive scan of c
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        __syncthreads();                                     // previous chunk's terms consumed
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int wbase = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < RK_THREADS / 64; ++i) { if (i < wave) wbase += wsum[i]; tot += wsum[i]; }
+        int pos = wbase + incl - c;                          // hits before this thread inside the chunk
+#pragma unroll
+        for (int e = 0; e < AP_PER_THREAD; ++e) {
+            if (hit[e]) {
+                const int64_t j = n0 + e - skip;             // position in the counted list (metrics.py:43)
+                const int64_t h = hits_before + pos;         // intersect_size before this rank
+                const double recall = (double)(h + 1) / dn;
+                const double old_recall = (double)h / dn;
+                const double precision = (double)(h + 1) / ((double)j + 1.0);
+                const double old_precision = (j == 0) ? 1.0 : (double)h / (((double)j - 1.0) + 1.0);
+                terms[pos] = (recall - old_recall) * ((old_precision + precision) / 2.0);
+                ++pos;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) for (int i = 0; i < tot; ++i) ap += terms[i];   // rank order, like the Python loop
+        hits_before += tot;
+    }
+    if (tid == 0) ap_out[row] = ap;
+}
+
+// Per-row label-masked sums: out[row*2] = sum_j sim[row][j] * [glab[j]==qlab[row]], out[row*2+1] = sum_j sim[row][j]
+__global__ __launch_bounds__(RK_THREADS) void masked_row_sums_kernel(const float* __restrict__ sim, int64_t N,
+                                                                     const int32_t* __restrict__ qlab,
+                                                                     const int32_t* __restrict__ glab, double* __restrict__ out) {
+    __shared__ double red[2][RK_THREADS / 64];
+    const int64_t row = blockIdx.x;
+    const int32_t q = qlab[row];
+    double sp = 0.0, sa = 0.0;
+    for (int64_t j = threadIdx.x; j < N; j += RK_THREADS) {
+        const double v = (double)sim[row * N + j];
+        sa += v;
+        if (glab[j] == q) sp += v;
+    }
+    sp = wave_sum(sp); sa = wave_sum(sa);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sp; red[1][threadIdx.x >> 6] = sa; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0, b = 0.0;
+        for (int i = 0; i < RK_THREADS / 64; ++i) { a += red[0][i]; b += red[1][i]; }
+        out[row * 2] = a; out[row * 2 + 1] = b;
+    }
+}
+
+static int64_t pow2_at_least(int64_t v) { int64_t p = 2; while (p < v) p <<= 1; return p; }
+
+}  // namespace isx
+
+using namespace isx;
+
+ISX_API size_t isx_rank_full_workspace(int64_t M, int64_t N) {
+    if (M <= 0 || N <= 0) return 256;
+    const int64_t N2 = pow2_at_least(N);
+    if (N2 <= RK_TILE) return 256;
+    return (size_t)M * (size_t)N2 * 8;
+}
+
+ISX_API int isx_rank_full(const float* sim, int64_t M, int64_t N, int64_t* ranked, void* ws, size_t ws_bytes,
+                          isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && N >= 0 && N <= 0x7FFFFFFFll && M < 65536 * 32768ll, "isx_rank_full: bad shape M=%lld N=%lld", (long long)M, (long long)N);
+    if (M == 0 || N == 0) return ISX_OK;
+    ISX_REQUIRE(sim && ranked, "isx_rank_full: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N2 = pow2_at_least(N);
+    if (N2 <= RK_TILE) {
+        ISX_REQUIRE(M < (1ll << 31), "isx_rank_full: too many rows");
+        hipLaunchKernelGGL(rank_small_kernel, dim3((unsigned)M), dim3(RK_THREADS), (size_t)N2 * 8, st, sim, N, (int)N2, ranked);
+        ISX_CHECK_LAUNCH("isx_rank_full(small)");
+        return ISX_OK;
+    }
+    if (!ws || ws_bytes < (size_t)M * (size_t)N2 * 8 || ((uintptr_t)ws % 16) != 0) {
+        isx_set_error("isx_rank_full: workspace of %zu bytes too small (need %zu)", ws_bytes, (size_t)M * (size_t)N2 * 8);
+        return ISX_ERR_WORKSPACE;
+    }
+    uint64_t* keys = (uint64_t*)ws;
+    // grid.y is limited to 65535: walk the rows in slabs
+    for (int64_t r0 = 0; r0 < M; r0 += 32768) {
+        const unsigned rows = (unsigned)(M - r0 < 32768 ? M - r0 : 32768);
+        const float* s = sim + r0 * N;
+        uint64_t* kk = keys + r0 * N2;
+        const dim3 tgrid((unsigned)(N2 / RK_TILE), rows);
+        hipLaunchKernelGGL(rank_tile_sort_kernel, tgrid, dim3(RK_THREADS), 0, st, s, N, N2, kk);
+        for (int64_t size = 2 * RK_TILE; size <= N2; size <<= 1) {
+            for (int64_t stride = size >> 1; stride >= RK_TILE; stride >>= 1)
+                hipLaunchKernelGGL(rank_global_step_kernel, dim3((unsigned)(N2 / 2 / RK_THREADS), rows), dim3(RK_THREADS), 0, st, kk, N2, size, stride);
+            hipLaunchKernelGGL(rank_tile_finish_kernel, tgrid, dim3(RK_THREADS), 0, st, kk, N2, size);
+        }
+        hipLaunchKernelGGL(rank_emit_kernel, dim3((unsigned)((N + RK_THREADS - 1) / RK_THREADS), rows), dim3(RK_THREADS), 0, st, kk, N, N2, ranked + r0 * N);
+    }
+    ISX_CHECK_LAUNCH("isx_rank_full");
+    return ISX_OK;
+}
+
+ISX_API int isx_average_precision(const int64_t* ranked, int64_t M, int64_t N, const int32_t* qlab, const int32_t* glab,
+                                  int kth, double* ap, isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && N >= 0 && kth >= 1 && M < (1ll << 31), "isx_average_precision: bad shape M=%lld N=%lld kth=%d", (long long)M, (long long)N, kth);
+    if (M == 0) return ISX_OK;
+    ISX_REQUIRE(qlab && ap && ((ranked && glab) || N == 0), "isx_average_precision: null pointer");
+    hipLaunchKernelGGL(average_precision_kernel, dim3((unsigned)M), dim3(RK_THREADS), 0, (hipStream_t)stream, ranked, N, qlab, glab, kth, ap);
+    ISX_CHECK_LAUNCH("isx_average_precision");
+    return ISX_OK;
+}
+
+ISX_API int isx_masked_sums(const float* sim, int64_t M, int64_t N, const int32_t* qlab, const int32_t* glab, double* out,
+                            isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && N >= 0 && M < (1ll << 31), "isx_masked_sums: bad shape M=%lld N=%lld", (long long)M, (long long)N);
+    if (M == 0) return ISX_OK;
+    ISX_REQUIRE(qlab && out && ((sim && glab) || N == 0), "isx_masked_sums: null pointer");
+    hipLaunchKernelGGL(masked_row_sums_kernel, dim3((unsigned)M), dim3(RK_THREADS), 0, (hipStream_t)stream, sim, N, qlab, glab, out);
+    ISX_CHECK_LAUNCH("isx_masked_sums");
+    return ISX_OK;
+}

@@ -1,0 +1,171 @@
+// select.hip -- canonical top-k selection over score rows and the multi-shard merge.
+//
+// Replaces the reference's  sim.max(1) / sim.kthvalue / sim[i].sort(descending)  consumers
+// (utils/metrics.py:10-13,33) for the top of the ranking, with a DEFINED tie-break
+// (score desc, index asc).  Every candidate is a single u64 key
+// (orderable(score) << 32 | ~index), so "k best" = "k largest keys" and ties cannot occur.
+//
+// One 256-thread workgroup per query row.  Scores stream from HBM/L2 in 16-B loads;
+// candidates beating the current k-th key are appended to a 2048-entry LDS buffer
+// (wave prefix by shuffles + one LDS atomic per wave); when the buffer could
+// overflow it is bitonic-sorted and cut back to k, which also tightens the threshold.
+#include "isx_internal.hpp"
+
+namespace isx {
+
+constexpr int SEL_THREADS = 256;
+constexpr int SEL_CAP = 2048;
+constexpr int SEL_STRIP = SEL_THREADS * 4;
+
+__device__ __forceinline__ int wave_excl_prefix(int v, int lane, int& total) {
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __restrict__ sim, int64_t Nc, int64_t ld,
+                                                             uint32_t col_base, int k, uint64_t* __restrict__ carry,
+                                                             int first, int emit, int64_t idx_base,
+                                                             float* __restrict__ top_score, int64_t* __restrict__ top_idx) {
+    __shared__ __attribute__((aligned(16))) uint64_t buf[SEL_CAP];
+    __shared__ int cnt_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t row = blockIdx.x;
+    const float* r = sim + row * ld;
+
+    for (int i = tid; i < SEL_CAP; i += SEL_THREADS) buf[i] = (!first && i < k) ? carry[row * k + i] : 0ull;
+    if (tid == 0) cnt_s = first ? 0 : k;
+    __syncthreads();
+    uint64_t thr = first ? 0ull : buf[k - 1];   // k-th best so far (0 = fewer than k real entries)
+    bool dirty = false;
+
+    for (int64_t s0 = 0; s0 < Nc; s0 += SEL_STRIP) {
+        // make room for a full strip.  cnt_s is stable here (last update precedes the
+        // previous barrier); the barrier below keeps this strip's atomics behind every read.
+        const int cnt_now = cnt_s;
+        __syncthreads();
+        if (cnt_now + SEL_STRIP > SEL_CAP) {
+            bitonic_sort_desc<SEL_THREADS>(buf, SEL_CAP);
+            for (int i = k + tid; i < SEL_CAP; i += SEL_THREADS) buf[i] = 0ull;
+            if (tid == 0) cnt_s = k;
+            __syncthreads();
+            thr = buf[k - 1];
+        }
+        const int64_t j0 = s0 + (int64_t)tid * 4;
+        uint64_t key[4];
+        bool take[4];
+        int c = 0;
+        if (VEC && j0 + 3 < Nc) {
+            const float4 v = *reinterpret_cast<const float4*>(r + j0);
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                key[q] = rank_key(vv[q], col_base + (uint32_t)(j0 + q));
+                take[q] = key[q] > thr;
+                c += take[q] ? 1 : 0;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool in = (j0 + q < Nc);
+                key[q] = in ? rank_key(r[in ? j0 + q : 0], col_base + (uint32_t)(j0 + q)) : 0ull;
+                take[q] = in && key[q] > thr;
+                c += take[q] ? 1 : 0;
+            }
+        }
+        int total;
+        const int pre = wave_excl_prefix(c, lane, total);
+        int base = 0;
+        if (lane == 0 && total > 0) base = atomicAdd(&cnt_s, total);
+        base = __shfl(base, 0, 64);
+        int off = base + pre;
+        // static register indexing only (runtime-indexed arrays would go to scratch)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (take[q]) buf[off++] = key[q];
+        dirty = dirty || (__syncthreads_or(total > 0) != 0);
+    }
+    __syncthreads();
+    if (dirty || first) {
+        bitonic_sort_desc<SEL_THREADS>(buf, SEL_CAP);
+    }
+    if (emit) {
+        for (int i = tid; i < k; i += SEL_THREADS) {
+            const uint64_t kk = buf[i];
+            top_score[row * k + i] = kk ? key_score(kk) : -INFINITY;
+            top_idx[row * k + i] = kk ? (idx_base + (int64_t)key_idx(kk)) : -1;
+        }
+    } else {
+        for (int i = tid; i < k; i += SEL_THREADS) carry[row * k + i] = buf[i];
+    }
+}
+
+int launch_select(const float* sim, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k, uint64_t* carry,
+                  bool first, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx, hipStream_t st) {
+    if (M == 0) return ISX_OK;
+    if (M >= (1ll << 31)) { isx_set_error("select: too many rows"); return ISX_ERR_ARG; }
+    const bool vec = sim && ((uintptr_t)sim % 16 == 0) && (ld % 4 == 0);
+    if (vec) hipLaunchKernelGGL(select_kernel<true>, dim3((unsigned)M), dim3(SEL_THREADS), 0, st, sim, Nc, ld, (uint32_t)col_base, k,
+                                carry, first ? 1 : 0, emit ? 1 : 0, idx_base, top_score, top_idx);
+    else hipLaunchKernelGGL(select_kernel<false>, dim3((unsigned)M), dim3(SEL_THREADS), 0, st, sim, Nc, ld, (uint32_t)col_base, k,
+                            carry, first ? 1 : 0, emit ? 1 : 0, idx_base, top_score, top_idx);
+    ISX_CHECK_LAUNCH("select");
+    return ISX_OK;
+}
+
+// Merge of P per-shard lists: one workgroup per query, keys rebuilt from (score, global
+// index), bitonic sort of next_pow2(P*k) <= 4096 keys in LDS.
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float* __restrict__ scores, const int64_t* __restrict__ idx, int P,
+                                                         int64_t M, int k, int n2, float* __restrict__ out_s,
+                                                         int64_t* __restrict__ out_i) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    const int64_t m = blockIdx.x;
+    const int T = P * k;
+    for (int t = threadIdx.x; t < n2; t += 256) {
+        uint64_t key = 0;
+        if (t < T) {
+            const int p = t / k, j = t - p * k;
+            const int64_t o = ((int64_t)p * M + m) * k + j;
+            const int64_t gi = idx[o];
+            if (gi >= 0) key = rank_key(scores[o], (uint32_t)gi);
+        }
+        keys[t] = key;
+    }
+    bitonic_sort_desc<256>(keys, n2);
+    for (int i = threadIdx.x; i < k; i += 256) {
+        const uint64_t kk = keys[i];
+        out_s[m * k + i] = kk ? key_score(kk) : -INFINITY;
+        out_i[m * k + i] = kk ? (int64_t)key_idx(kk) : -1;
+    }
+}
+
+}  // namespace isx
+
+using namespace isx;
+
+ISX_API int isx_topk_rows(const float* sim, int64_t M, int64_t N, int k, int64_t idx_base, float* top_score,
+                          int64_t* top_idx, isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && N >= 0 && N <= 0x7FFFFFFFll, "isx_topk_rows: bad shape M=%lld N=%lld", (long long)M, (long long)N);
+    ISX_REQUIRE(k >= 1 && k <= kSelectMaxK, "isx_topk_rows: k=%d outside [1,%d]", k, kSelectMaxK);
+    ISX_REQUIRE(idx_base >= 0 && idx_base + N <= 0xFFFFFFFFll, "isx_topk_rows: gallery indices must stay below 2^32");
+    ISX_REQUIRE((top_score && top_idx && (sim || N == 0)) || M == 0, "isx_topk_rows: null pointer");
+    return launch_select(sim, M, N, N, 0, k, nullptr, true, true, idx_base, top_score, top_idx, (hipStream_t)stream);
+}
+
+ISX_API int isx_topk_merge(const float* scores, const int64_t* idx, int P, int64_t M, int k, float* out_s, int64_t* out_i,
+                           isx_stream_t stream) {
+    ISX_REQUIRE(P >= 1 && M >= 0 && k >= 1 && M < (1ll << 31), "isx_topk_merge: bad shape P=%d M=%lld k=%d", P, (long long)M, k);
+    ISX_REQUIRE((int64_t)P * k <= 4096, "isx_topk_merge: P*k=%lld exceeds 4096", (long long)P * k);
+    ISX_REQUIRE((scores && idx && out_s && out_i) || M == 0, "isx_topk_merge: null pointer");
+    if (M == 0) return ISX_OK;
+    const int n2 = next_pow2(P * k < 2 ? 2 : P * k);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)M), dim3(256), (size_t)n2 * 8, (hipStream_t)stream, scores, idx, P, M, k, n2,
+                       out_s, out_i);
+    ISX_CHECK_LAUNCH("isx_topk_merge");
+    return ISX_OK;
+}

@@ -1,0 +1,185 @@
+"""Thin torch-tensor wrappers over the C ABI (include/isx.h).  One function per entry.
+
+All tensors must live on the GPU; work is enqueued on torch's current stream.  These are
+the only places the product path touches ctypes."""
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+EPS = 1e-10  # model/custom_modules.py:48 NormalizeL2Fun(eps=1e-10)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _lib.IsxError("%s must be a CUDA tensor (libisx has no CPU path)" % name)
+    if t.dtype != torch.float32:
+        raise _lib.IsxError("%s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _typed(t, dtype, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _lib.IsxError("%s must be a CUDA tensor" % name)
+    return t.to(dtype).contiguous()
+
+
+def l2norm_rows(x, eps=EPS, out=None):
+    x = _f32(x, "x")
+    B, D = x.shape
+    y = torch.empty_like(x) if out is None else out
+    check(lib().isx_l2norm_rows(x.data_ptr(), B, D, eps, y.data_ptr(), _stream()), "isx_l2norm_rows")
+    return y
+
+
+def l2norm_shift_rows(x, shift=None, eps=EPS):
+    x = _f32(x, "x")
+    B, F = x.shape
+    sp = 0
+    if shift is not None:
+        shift = _f32(shift, "shift")
+        assert shift.numel() == F
+        sp = shift.data_ptr()
+    y = torch.empty_like(x)
+    check(lib().isx_l2norm_shift_rows(x.data_ptr(), sp, B, F, eps, y.data_ptr(), _stream()), "isx_l2norm_shift_rows")
+    return y
+
+
+def gap_l2(fmap, eps=EPS, out=None):
+    fmap = _f32(fmap, "fmap")
+    B, Cc, H, W = fmap.shape
+    y = torch.empty((B, Cc), device=fmap.device, dtype=torch.float32) if out is None else out
+    assert y.is_contiguous() and y.shape == (B, Cc)
+    check(lib().isx_gap_l2(fmap.data_ptr(), B, Cc, H, W, eps, y.data_ptr(), _stream()), "isx_gap_l2")
+    return y
+
+
+def boxpool_s1(fmap, kh, kw):
+    fmap = _f32(fmap, "fmap")
+    B, Cc, H, W = fmap.shape
+    out = torch.empty((B, Cc, H - kh + 1, W - kw + 1), device=fmap.device, dtype=torch.float32)
+    check(lib().isx_boxpool_s1(fmap.data_ptr(), B, Cc, H, W, kh, kw, out.data_ptr(), _stream()), "isx_boxpool_s1")
+    return out
+
+
+def best_location_desc(cls, eps=EPS):
+    cls = _f32(cls, "cls")
+    B, K, Hp, Wp = cls.shape
+    desc = torch.empty((B, K), device=cls.device, dtype=torch.float32)
+    loc = torch.empty((B, 2), device=cls.device, dtype=torch.int64)
+    check(lib().isx_best_location_desc(cls.data_ptr(), B, K, Hp, Wp, eps, desc.data_ptr(), loc.data_ptr(), _stream()),
+          "isx_best_location_desc")
+    return desc, loc
+
+
+def region_topk(cls, k):
+    cls = _f32(cls, "cls")
+    K, Hp, Wp = cls.shape[-3:]
+    idx = torch.empty((k,), device=cls.device, dtype=torch.int64)
+    sc = torch.empty((k,), device=cls.device, dtype=torch.float32)
+    check(lib().isx_region_topk(cls.data_ptr(), K, Hp, Wp, k, idx.data_ptr(), sc.data_ptr(), _stream()), "isx_region_topk")
+    return idx, sc
+
+
+def region_gather_l2(fmap, kh, kw, flat_idx, Wp, shift=None, eps=EPS):
+    fmap = _f32(fmap, "fmap")
+    Cc, Hf, Wf = fmap.shape[-3:]
+    flat_idx = _typed(flat_idx, torch.int64, "flat_idx")
+    k = flat_idx.numel()
+    rows = torch.empty((k, Cc * kh * kw), device=fmap.device, dtype=torch.float32)
+    sp = 0
+    if shift is not None:
+        shift = _f32(shift, "shift")
+        sp = shift.data_ptr()
+    check(lib().isx_region_gather_l2(fmap.data_ptr(), Cc, Hf, Wf, kh, kw, flat_idx.data_ptr(), k, Wp, sp, eps,
+                                     rows.data_ptr(), _stream()), "isx_region_gather_l2")
+    return rows
+
+
+def cosine_sim(Q, G, out=None):
+    Q, G = _f32(Q, "Q"), _f32(G, "G")
+    M, D = Q.shape
+    N = G.shape[0]
+    assert G.shape[1] == D
+    sim = torch.empty((M, N), device=Q.device, dtype=torch.float32) if out is None else out
+    check(lib().isx_cosine_sim(Q.data_ptr(), M, G.data_ptr(), N, D, sim.data_ptr(), _stream()), "isx_cosine_sim")
+    return sim
+
+
+def cosine_topk_workspace(M, N, D, k):
+    return lib().isx_cosine_topk_workspace(M, N, D, k)
+
+
+def cosine_topk(Q, G, k, idx_base=0, ws=None, out=None):
+    """(top_score (M,k) f32, top_idx (M,k) i64), canonical order.  `ws`: optional uint8 CUDA
+    tensor reused across calls (sized by cosine_topk_workspace or larger/smaller)."""
+    Q, G = _f32(Q, "Q"), _f32(G, "G")
+    M, D = Q.shape
+    N = G.shape[0]
+    assert G.shape[1] == D
+    if ws is None:
+        ws = torch.empty((cosine_topk_workspace(M, N, D, k),), device=Q.device, dtype=torch.uint8)
+    if out is None:
+        ts = torch.empty((M, k), device=Q.device, dtype=torch.float32)
+        ti = torch.empty((M, k), device=Q.device, dtype=torch.int64)
+    else:
+        ts, ti = out
+    check(lib().isx_cosine_topk(Q.data_ptr(), M, G.data_ptr(), N, D, k, idx_base, ts.data_ptr(), ti.data_ptr(),
+                                ws.data_ptr(), ws.numel(), _stream()), "isx_cosine_topk")
+    return ts, ti
+
+
+def topk_rows(sim, k, idx_base=0):
+    sim = _f32(sim, "sim")
+    M, N = sim.shape
+    ts = torch.empty((M, k), device=sim.device, dtype=torch.float32)
+    ti = torch.empty((M, k), device=sim.device, dtype=torch.int64)
+    check(lib().isx_topk_rows(sim.data_ptr(), M, N, k, idx_base, ts.data_ptr(), ti.data_ptr(), _stream()), "isx_topk_rows")
+    return ts, ti
+
+
+def rank_full(sim):
+    sim = _f32(sim, "sim")
+    M, N = sim.shape
+    ranked = torch.empty((M, N), device=sim.device, dtype=torch.int64)
+    nb = lib().isx_rank_full_workspace(M, N)
+    ws = torch.empty((nb,), device=sim.device, dtype=torch.uint8)
+    check(lib().isx_rank_full(sim.data_ptr(), M, N, ranked.data_ptr(), ws.data_ptr(), nb, _stream()), "isx_rank_full")
+    return ranked
+
+
+def average_precision(ranked, qlab, glab, kth=1):
+    ranked = _typed(ranked, torch.int64, "ranked")
+    M, N = ranked.shape
+    qlab = _typed(qlab, torch.int32, "qlab")
+    glab = _typed(glab, torch.int32, "glab")
+    ap = torch.empty((M,), device=ranked.device, dtype=torch.float64)
+    check(lib().isx_average_precision(ranked.data_ptr(), M, N, qlab.data_ptr(), glab.data_ptr(), kth, ap.data_ptr(),
+                                      _stream()), "isx_average_precision")
+    return ap
+
+
+def masked_sums(sim, qlab, glab):
+    sim = _f32(sim, "sim")
+    M, N = sim.shape
+    qlab = _typed(qlab, torch.int32, "qlab")
+    glab = _typed(glab, torch.int32, "glab")
+    out = torch.empty((M, 2), device=sim.device, dtype=torch.float64)
+    check(lib().isx_masked_sums(sim.data_ptr(), M, N, qlab.data_ptr(), glab.data_ptr(), out.data_ptr(), _stream()),
+          "isx_masked_sums")
+    return out
+
+
+def topk_merge(scores, idx):
+    scores = _f32(scores, "scores")
+    idx = _typed(idx, torch.int64, "idx")
+    P, M, k = scores.shape
+    os_ = torch.empty((M, k), device=scores.device, dtype=torch.float32)
+    oi = torch.empty((M, k), device=scores.device, dtype=torch.int64)
+    check(lib().isx_topk_merge(scores.data_ptr(), idx.data_ptr(), P, M, k, os_.data_ptr(), oi.data_ptr(), _stream()),
+          "isx_topk_merge")
+    return os_, oi

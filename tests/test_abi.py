@@ -1,0 +1,53 @@
+"""CPU-side checks of the drop-in boundary: libisx.so loads and exports exactly what
+include/isx.h declares; argument validation works without touching a GPU."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "isx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(isx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from isx import _lib
+    lib = _lib.lib()
+    names = _declared()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "libisx.so does not export %s" % n
+    assert sorted(_lib.EXPORTS) == names, "binding table and header disagree"
+    assert lib.isx_version() >= 100
+
+
+def test_argument_validation_without_gpu():
+    from isx import _lib
+    lib = _lib.lib()
+    # bad shapes are rejected on the host before any launch
+    assert lib.isx_cosine_sim(None, -1, None, 4, 8, None, None) == -1
+    assert b"bad shape" in lib.isx_last_error()
+    assert lib.isx_cosine_topk(None, 4, None, 4, 8, 0, 0, None, None, None, 0, None) == -1
+    assert lib.isx_region_topk(None, 4, 100, 100, 3, None, None, None) == -1
+    assert b"4096" in lib.isx_last_error()
+    assert lib.isx_topk_merge(None, None, 8, 4, 1024, None, None, None) == -1
+    # empty problems are no-ops
+    assert lib.isx_l2norm_rows(None, 0, 16, 1e-10, None, None) == 0
+    assert lib.isx_cosine_sim(None, 0, None, 0, 8, None, None) == 0
+    # workspace queries are pure host arithmetic
+    assert lib.isx_cosine_topk_workspace(1000, 10000, 2048, 100) >= 1000 * 100 * 8 + 1000 * 10000 * 4
+    assert lib.isx_rank_full_workspace(10, 100) == 256
+    assert lib.isx_rank_full_workspace(10, 10000) == 10 * 16384 * 8
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from isx import ops, _lib
+    with pytest.raises(_lib.IsxError):
+        ops.l2norm_rows(torch.zeros(2, 8))
+    with pytest.raises(_lib.IsxError):
+        ops.cosine_sim(torch.zeros(2, 8), torch.zeros(3, 8))

@@ -1,0 +1,298 @@
+"""HIP kernels (through the C ABI) vs the CPU oracle on the same seeded inputs, and vs the
+golden vectors produced by the reference.  Integer / index / rank outputs: bit-exact.
+Cosine scores: bit-exact vs the oracle's fma chain, <= 1e-5 vs torch.mm goldens.
+Other fp32 outputs: rtol 2e-6 (summation-order slack only)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=2e-6, atol=2e-7)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from isx import ops as o
+    return o
+
+
+# ------------------------------------------------------------------ descriptor head
+@pytest.mark.parametrize("B,D", [(1, 1), (7, 37), (5, 64), (33, 256), (9, 464), (64, 2048), (3, 9216), (2, 100352), (3, 100353)])
+def test_l2norm_rows(ops, B, D):
+    rng = np.random.default_rng(B * 1000 + D)
+    x = rng.standard_normal((B, D), dtype=np.float32)
+    x[0] = 0.0
+    y = host(ops.l2norm_rows(dev(x)))
+    np.testing.assert_allclose(y, O.l2norm_rows(x), **TOL)
+    assert (y[0] == 0).all()
+    sh = rng.standard_normal((D,), dtype=np.float32) * 0.1
+    y2 = host(ops.l2norm_shift_rows(dev(x), dev(sh)))
+    np.testing.assert_allclose(y2, O.shift_rows(O.l2norm_rows(x), sh), rtol=2e-6, atol=1e-7)
+
+
+def test_l2norm_golden(ops, golden):
+    g = golden("l2norm_shift.npz")
+    np.testing.assert_allclose(host(ops.l2norm_rows(dev(g["x"]))), g["y"], **TOL)
+    np.testing.assert_allclose(host(ops.l2norm_rows(dev(g["x_wide"]))), g["y_wide"], **TOL)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(1, 4, 1, 1), (3, 16, 4, 4), (2, 24, 7, 7), (5, 256, 6, 6), (4, 2048, 7, 7), (2, 2048, 14, 14),
+                                     (3, 30, 5, 3), (2, 2048, 3, 5), (1, 8, 40, 40), (2, 5000, 2, 2)])
+def test_gap_l2(ops, B, C, H, W):
+    rng = np.random.default_rng(C + H)
+    f = np.maximum(rng.standard_normal((B, C, H, W), dtype=np.float32), 0)    # post-ReLU like
+    y = host(ops.gap_l2(dev(f)))
+    np.testing.assert_allclose(y, O.gap_l2(f), **TOL)
+
+
+def test_gap_l2_golden(ops, golden):
+    g = golden("gap_l2.npz")
+    np.testing.assert_allclose(host(ops.gap_l2(dev(g["fmap"]))), g["desc"], **TOL)
+    np.testing.assert_allclose(host(ops.gap_l2(dev(g["fmap7"]))), g["desc7"], **TOL)
+
+
+@pytest.mark.parametrize("B,C,H,W,kh,kw", [(1, 16, 7, 5, 3, 3), (2, 2048, 14, 14, 7, 7), (1, 256, 13, 13, 6, 6), (1, 3, 7, 7, 7, 7),
+                                           (1, 2, 120, 130, 7, 7)])
+def test_boxpool_s1(ops, B, C, H, W, kh, kw):
+    rng = np.random.default_rng(H * W)
+    f = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    np.testing.assert_array_equal(host(ops.boxpool_s1(dev(f), kh, kw)), O.boxpool_s1(f, kh, kw))   # same summation order
+
+
+def test_boxpool_golden(ops, golden):
+    g = golden("classif_sub.npz")
+    np.testing.assert_allclose(host(ops.boxpool_s1(dev(g["fmap_r"]), 3, 3)), g["pooled_r"], **TOL)
+
+
+# ------------------------------------------------------------------ region path
+def test_best_location(ops, golden):
+    g = golden("best_location.npz")
+    for t in list(range(4)) + ["_r"]:
+        m = g["map%s" % t] if t != "_r" else g["map_r"]
+        d, loc = ops.best_location_desc(dev(m[None]))
+        want_loc = g["locs"][t] if t != "_r" else g["loc_r"]
+        assert tuple(host(loc)[0]) == tuple(want_loc)
+        np.testing.assert_allclose(host(d)[0], g["desc%s" % t] if t != "_r" else g["desc_r"], **TOL)
+    rng = np.random.default_rng(1)
+    cls = rng.standard_normal((6, 464, 8, 8), dtype=np.float32)
+    cls[2, :, 5, 2] = cls[2, :, 1, 6]            # tie between two locations: smallest column wins
+    cls[2, 7, 5, 2] = cls[2, 7, 1, 6] = 50.0
+    d, loc = ops.best_location_desc(dev(cls))
+    for b in range(6):
+        od, ol = O.best_location_desc(cls[b])
+        assert tuple(host(loc)[b]) == tuple(ol)
+        np.testing.assert_allclose(host(d)[b], od, **TOL)
+    assert tuple(host(loc)[2]) == (5, 2)
+
+
+@pytest.mark.parametrize("K,Hp,Wp,k", [(9, 5, 3, 3), (9, 5, 3, 40), (464, 8, 8, 6), (17, 1, 1, 6), (5, 60, 60, 10)])
+def test_region_topk_and_gather(ops, K, Hp, Wp, k):
+    rng = np.random.default_rng(K + Hp)
+    cls = rng.standard_normal((K, Hp, Wp), dtype=np.float32)
+    if Hp * Wp > 4:
+        cls[:, 1, 1] = cls[:, 0, 0]              # tie
+    idx, sc = ops.region_topk(dev(cls), k)
+    oi, osc = O.region_topk(cls, k)
+    n = len(oi)
+    np.testing.assert_array_equal(host(idx)[:n], oi)
+    np.testing.assert_array_equal(host(sc)[:n], osc)
+    assert (host(idx)[n:] == -1).all()
+    C, fs = 12, 3
+    fmap = rng.standard_normal((C, Hp + fs - 1, Wp + fs - 1), dtype=np.float32)
+    sh = rng.standard_normal((C * fs * fs,), dtype=np.float32) * 0.05
+    rows = host(ops.region_gather_l2(dev(fmap), fs, fs, idx, Wp, dev(sh)))
+    np.testing.assert_allclose(rows[:n], O.region_gather_l2(fmap, fs, fs, oi, Wp, sh), rtol=2e-6, atol=1e-7)
+    assert (rows[n:] == 0).all()
+
+
+def test_region_descriptor_golden(ops, golden):
+    g = golden("region_desc.npz")
+    for tag, k in (("k3", 3), ("k40", 40)):
+        cls = g["cls_" + tag][0]
+        idx, _ = ops.region_topk(dev(cls), k)
+        n = min(k, cls.shape[1] * cls.shape[2])
+        np.testing.assert_array_equal(host(idx)[:n], g["idx_" + tag])
+        rows = ops.region_gather_l2(dev(g["fmap_" + tag][0]), 3, 3, idx[:n], cls.shape[2], dev(g["shift_" + tag]))
+        acc = (rows @ dev(g["w_" + tag]).t() + dev(g["b_" + tag])).sum(0, keepdim=True)
+        np.testing.assert_allclose(host(ops.l2norm_rows(acc)), g["desc_" + tag], rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ retrieval
+def unit(rng, n, d):
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    return O.l2norm_rows(x)
+
+
+@pytest.mark.parametrize("M,N,D", [(1, 1, 1), (3, 5, 2), (100, 100, 9216), (7, 300, 464), (50, 1000, 311), (33, 129, 17),
+                                   (128, 128, 32), (130, 257, 2048), (256, 1000, 2048), (5, 2000, 36), (64, 64, 31)])
+def test_cosine_sim_bitexact(ops, M, N, D):
+    rng = np.random.default_rng(M * N + D)
+    Q, G = unit(rng, M, D), unit(rng, N, D)
+    sim = host(ops.cosine_sim(dev(Q), dev(G)))
+    np.testing.assert_array_equal(sim, O.cosine_sim(Q, G))        # MFMA fp32 == k-ordered fma chain
+    ref = (Q.astype(np.float64) @ G.astype(np.float64).T)
+    assert np.abs(sim - ref).max() <= 1e-5
+
+
+def test_cosine_sim_mfma_layout(ops):
+    # A = I against an ASYMMETRIC B catches swapped row/col maps (guide section 3)
+    n = 128
+    Q = np.eye(n, dtype=np.float32)
+    G = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 251) - 100.0
+    np.testing.assert_array_equal(host(ops.cosine_sim(dev(Q), dev(G))), G.T)
+    np.testing.assert_array_equal(host(ops.cosine_sim(dev(G), dev(Q))), G)
+
+
+def test_cosine_golden(ops, golden):
+    g = golden("synthetic_retrieval.npz")
+    for n in (100, 1000):
+        t = "_n%d" % n
+        sim = ops.cosine_sim(dev(g["Q" + t]), dev(g["G" + t]))
+        assert np.abs(host(sim) - g["sim" + t]).max() <= 1e-5      # vs torch.mm fp32 of the reference run
+        ranked = ops.rank_full(sim)
+        ap = host(ops.average_precision(ranked, dev(g["qlab" + t]), dev(g["glab" + t])))
+        assert abs(O.mean_avg_precision(ap) - float(g["map" + t])) <= 1e-4
+        # on the reference's own score matrix the whole metric chain is bit-exact
+        ranked = ops.rank_full(dev(g["sim" + t]))
+        ap = host(ops.average_precision(ranked, dev(g["qlab" + t]), dev(g["glab" + t])))
+        assert O.mean_avg_precision(ap) == float(g["map" + t])
+        ts, ti = ops.topk_rows(dev(g["sim" + t]), 1)
+        assert O.precision1(host(ti), g["qlab" + t], g["glab" + t])[:3] == tuple(g["p1" + t])
+
+
+@pytest.mark.parametrize("M,N,D,k", [(1, 1, 8, 1), (4, 50, 16, 100), (37, 1000, 64, 10), (100, 5000, 128, 100), (16, 20000, 32, 1024),
+                                     (300, 3000, 2048, 100)])
+def test_cosine_topk(ops, M, N, D, k):
+    rng = np.random.default_rng(N + k)
+    Q, G = unit(rng, M, D), unit(rng, N, D)
+    if N > 40:
+        G[N // 2] = G[3]                          # duplicated gallery rows -> exact score ties
+        G[N - 1] = G[3]
+    os_, oi = O.cosine_topk(Q, G, k, idx_base=11)
+    ts, ti = ops.cosine_topk(dev(Q), dev(G), k, idx_base=11)
+    np.testing.assert_array_equal(host(ti), oi)
+    np.testing.assert_array_equal(host(ts), os_)
+    # a tiny workspace forces many column chunks + carry merging: same answer
+    small = torch.empty((((M * k * 8 + 255) // 256) * 256 + M * 256 * 4,), dtype=torch.uint8, device="cuda")
+    ts2, ti2 = ops.cosine_topk(dev(Q), dev(G), k, idx_base=11, ws=small)
+    np.testing.assert_array_equal(host(ti2), oi)
+    np.testing.assert_array_equal(host(ts2), os_)
+
+
+def test_topk_rows_adversarial(ops):
+    # ascending scores: every element beats the running threshold (worst case for the filter)
+    M, N, k = 3, 10000, 100
+    sim = np.tile(np.linspace(-1, 1, N, dtype=np.float32), (M, 1))
+    sim[1] = sim[1, ::-1]
+    sim[2] = 0.25                                   # all tied: index order decides
+    ts, ti = ops.topk_rows(dev(sim), k, idx_base=0)
+    os_, oi = O.topk_rows(sim, k)
+    np.testing.assert_array_equal(host(ti), oi)
+    np.testing.assert_array_equal(host(ts), os_)
+    assert (host(ti)[2] == np.arange(k)).all()
+
+
+@pytest.mark.parametrize("M,N", [(1, 1), (5, 24), (12, 40), (3, 4096), (4, 4097), (6, 10000), (2, 70000)])
+def test_rank_full_and_ap(ops, M, N):
+    rng = np.random.default_rng(N)
+    sim = (np.round(rng.random((M, N)) * 50) / 50).astype(np.float32) if N < 100 else rng.standard_normal((M, N), dtype=np.float32)
+    if N > 10:
+        sim[:, 7] = sim[:, 2]
+    ranked = ops.rank_full(dev(sim))
+    np.testing.assert_array_equal(host(ranked), O.rank_full(sim))
+    L = max(1, N // 10)
+    gl = (np.arange(N) % L).astype(np.int32)
+    ql = (np.arange(M) % (L + 1)).astype(np.int32)     # label L absent from the gallery -> NaN (skipped)
+    for kth in (1, 2, 3):
+        ap = host(ops.average_precision(ranked, dev(ql), dev(gl), kth))
+        want = O.average_precision(O.rank_full(sim), ql, gl, kth)
+        np.testing.assert_array_equal(np.isnan(ap), np.isnan(want))
+        np.testing.assert_array_equal(ap[~np.isnan(ap)], want[~np.isnan(want)])     # float64, bit-exact
+
+
+def test_metrics_golden(ops, golden):
+    g = golden("metrics.npz")
+    sim, ql, gl = g["sim"], g["qlab"], g["glab"]
+    ranked = ops.rank_full(dev(sim))
+    ts, ti = ops.topk_rows(dev(sim), 3)
+    for kth in (1, 2, 3):
+        ap = host(ops.average_precision(ranked, dev(ql), dev(gl), kth))
+        ref = g["ap_kth%d" % kth]
+        np.testing.assert_array_equal(np.isnan(ap), np.isnan(ref))
+        np.testing.assert_array_equal(ap[~np.isnan(ap)], ref[~np.isnan(ref)])
+        assert O.mean_avg_precision(ap) == float(g["map_kth%d" % kth])
+        p1, c, t, hit = O.precision1(host(ti), ql, gl, kth)
+        assert (p1, c, t) == tuple(g["p1_kth%d" % kth])
+        np.testing.assert_array_equal(host(ts)[:, kth - 1], g["p1_maxsim_kth%d" % kth])
+    apt = host(ops.average_precision(ops.rank_full(dev(g["tie_sim"])), dev(g["tie_qlab"]), dev(g["tie_glab"])))
+    np.testing.assert_array_equal(apt, g["tie_ap"])
+
+
+def test_masked_sums(ops):
+    rng = np.random.default_rng(5)
+    sim = rng.standard_normal((20, 777), dtype=np.float32)
+    ql = (np.arange(20) % 5).astype(np.int32)
+    gl = (np.arange(777) % 5).astype(np.int32)
+    out = host(ops.masked_sums(dev(sim), dev(ql), dev(gl)))
+    sp, sa = O.masked_sums(sim, ql, gl)
+    assert abs(out[:, 0].sum() - sp) < 1e-9 and abs(out[:, 1].sum() - sa) < 1e-9
+
+
+@pytest.mark.parametrize("P,k", [(2, 10), (8, 100), (8, 512), (3, 1)])
+def test_topk_merge(ops, P, k):
+    rng = np.random.default_rng(P * k)
+    M, N, D = 9, 4000, 32
+    Q, G = unit(rng, M, D), unit(rng, N, D)
+    G[100] = G[3900]                               # cross-shard tie
+    bounds = np.linspace(0, N, P + 1).astype(int)
+    parts = [O.cosine_topk(Q, G[a:b], k, idx_base=a) for a, b in zip(bounds[:-1], bounds[1:])]
+    S, I = np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts])
+    ms, mi = ops.topk_merge(dev(S), dev(I))
+    fs, fi = O.cosine_topk(Q, G, k)
+    np.testing.assert_array_equal(host(mi), fi)
+    np.testing.assert_array_equal(host(ms), fs)
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE sizes)
+def test_full_size_properties(ops):
+    """1k x 100k x 2048 (config 3 scale) and a 10k-query slab: size-independent checks --
+    sortedness, idempotence, shard-merge invariance, sampled rows against the oracle."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M, N, D, k = 1000, 100000, 2048, 100
+    G = torch.randn(N, D, device="cuda", generator=g)
+    Q = torch.randn(M, D, device="cuda", generator=g)
+    G, Q = ops.l2norm_rows(G), ops.l2norm_rows(Q)
+    assert torch.allclose((G * G).sum(1), torch.ones(N, device="cuda"), atol=1e-5)
+    ts, ti = ops.cosine_topk(Q, G, k)
+    assert bool((ts[:, :-1] >= ts[:, 1:]).all())                                   # sorted
+    tie = ts[:, :-1] == ts[:, 1:]
+    assert bool((ti[:, :-1][tie] < ti[:, 1:][tie]).all())                          # ties by ascending index
+    assert int(ti.min()) >= 0 and int(ti.max()) < N
+    # idempotence: scores recomputed from the returned indices reproduce the list
+    rows = [0, 1, 499, 999]
+    sub = ops.cosine_sim(Q[rows], G)
+    s2, i2 = ops.topk_rows(sub, k)
+    assert torch.equal(i2, ti[rows]) and torch.equal(s2, ts[rows])
+    # oracle on sampled rows (full 2048-d dot products on the CPU)
+    os_, oi = O.cosine_topk(host(Q[rows]), host(G), k)
+    np.testing.assert_array_equal(host(ti[rows]), oi)
+    np.testing.assert_array_equal(host(ts[rows]), os_)
+    # shard invariance: 8 row shards + merge == unsharded
+    P = 8
+    parts = [ops.cosine_topk(Q, G[p * N // P:(p + 1) * N // P], k, idx_base=p * N // P) for p in range(P)]
+    ms, mi = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(mi, ti) and torch.equal(ms, ts)
+    # self-retrieval: each gallery row's best match is itself with score ~1
+    s1, i1 = ops.cosine_topk(G[:2000], G, 1)
+    assert torch.equal(i1[:, 0], torch.arange(2000, device="cuda"))
+    assert bool(((s1[:, 0] - 1).abs() < 1e-5).all())
