@@ -34,17 +34,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
                                                              int first, int emit, int64_t idx_base,
                                                              float* __restrict__ top_score, int64_t* __restrict__ top_idx) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[SEL_CAP];
-    __shared__ int cnt_s;
+    __shared__ int cnt_s, dirty_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t row = blockIdx.x;
     const float* r = sim + row * ld;
 
     for (int i = tid; i < SEL_CAP; i += SEL_THREADS) buf[i] = (!first && i < k) ? carry[row * k + i] : 0ull;
-    if (tid == 0) cnt_s = first ? 0 : k;
+    if (tid == 0) { cnt_s = first ? 0 : k; dirty_s = 0; }
     __syncthreads();
     uint64_t thr = first ? 0ull : buf[k - 1];   // k-th best so far (0 = fewer than k real entries)
-    bool dirty = false;
-
     for (int64_t s0 = 0; s0 < Nc; s0 += SEL_STRIP) {
         // make room for a full strip.  cnt_s is stable here (last update precedes the
         // previous barrier); the barrier below keeps this strip's atomics behind every read.
@@ -82,16 +80,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
         int total;
         const int pre = wave_excl_prefix(c, lane, total);
         int base = 0;
-        if (lane == 0 && total > 0) base = atomicAdd(&cnt_s, total);
+        if (lane == 0 && total > 0) { base = atomicAdd(&cnt_s, total); dirty_s = 1; }
         base = __shfl(base, 0, 64);
         int off = base + pre;
         // static register indexing only (runtime-indexed arrays would go to scratch)
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (take[q]) buf[off++] = key[q];
-        dirty = dirty || (__syncthreads_or(total > 0) != 0);
+        __syncthreads();   // appends + cnt_s visible before the next strip (unconditional barrier)
     }
-    __syncthreads();
-    if (dirty || first) {
+    if (dirty_s != 0 || first) {
         bitonic_sort_desc<SEL_THREADS>(buf, SEL_CAP);
     }
     if (emit) {
