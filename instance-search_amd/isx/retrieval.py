@@ -1,0 +1,111 @@
+"""Row-sharded gallery search across the GPUs of one node (BASELINE config 5).
+
+The reference is single-device (one torch.mm, test/classif_finetune_test.py:82); this is the
+MI355X-native extension the north star asks for.  One process per GPU; rank p holds gallery
+rows [lo_p, hi_p) (contiguous split).  A search is
+    1. local fused cosine top-k on the shard with idx_base = lo_p     (libisx isx_cosine_topk)
+    2. ONE all-gather of the (M,k) fp32 scores and (M,k) int64 global indices over RCCL/xGMI
+       (12 B per entry: 12 MB per rank at M = 10k, k = 100 -- tiny next to the GEMM)
+    3. canonical merge of the P*k candidates per query                  (libisx isx_topk_merge)
+The canonical comparator (score desc, GLOBAL index asc) makes the result independent of P and
+of the gather order: sharded == unsharded bit for bit (tests/test_distributed.py).
+
+CPU tensors (gloo, used by the world_size-2 CPU tests and the reference's --device=-1 mode) go
+through the same driver with torch doing the local top-k / merge arithmetic.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_rows, world_size, rank):
+    """Contiguous split: the first n_rows % world_size ranks hold one extra row."""
+    q, r = divmod(n_rows, world_size)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def _canonical_topk_cpu(scores, idx, k):
+    """k best (score desc, idx asc) per row of candidate lists; idx < 0 marks padding."""
+    s = scores.clone()
+    s[idx < 0] = float('-inf')
+    big = torch.iinfo(torch.int64).max
+    order = torch.where(idx < 0, torch.full_like(idx, big), idx).argsort(dim=1, stable=True)      # by index asc
+    s1, i1 = s.gather(1, order), idx.gather(1, order)
+    order2 = s1.sort(dim=1, descending=True, stable=True).indices                                  # then score desc (stable)
+    return s1.gather(1, order2)[:, :k], i1.gather(1, order2)[:, :k]
+
+
+def local_topk(Q, G, k, idx_base=0, ws=None):
+    """Canonical top-k of Q @ G.T on one shard, global indices."""
+    M = Q.size(0)
+    if Q.is_cuda:
+        from . import ops
+        return ops.cosine_topk(Q, G, k, idx_base=idx_base, ws=ws)
+    sim = Q @ G.t()
+    n = G.size(0)
+    order = sim.sort(dim=1, descending=True, stable=True)
+    s, i = order.values[:, :k], order.indices[:, :k] + idx_base
+    if n < k:
+        s = torch.cat([s, sim.new_full((M, k - n), float('-inf'))], 1)
+        i = torch.cat([i, i.new_full((M, k - n), -1)], 1)
+    return s.contiguous(), i.contiguous()
+
+
+def merge_topk(scores, idx):
+    """(P,M,k) per-shard lists -> (M,k) global list."""
+    P, M, k = scores.shape
+    if scores.is_cuda:
+        from . import ops
+        return ops.topk_merge(scores, idx)
+    return _canonical_topk_cpu(scores.permute(1, 0, 2).reshape(M, P * k), idx.permute(1, 0, 2).reshape(M, P * k), k)
+
+
+class ShardedGallery(object):
+    """This rank's slice of a row-sharded descriptor gallery."""
+
+    def __init__(self, shard, idx_base, group=None):
+        self.shard = shard.contiguous()
+        self.idx_base = int(idx_base)
+        self.group = group
+        self._ws = None
+
+    @classmethod
+    def from_full(cls, gallery, group=None):
+        """Slice a replicated gallery tensor by rank (tests / small galleries)."""
+        ws = dist.get_world_size(group) if dist.is_initialized() else 1
+        rk = dist.get_rank(group) if dist.is_initialized() else 0
+        lo, hi = shard_bounds(gallery.size(0), ws, rk)
+        return cls(gallery[lo:hi], lo, group)
+
+    def _workspace(self, M, k):
+        if not self.shard.is_cuda:
+            return None
+        from . import ops
+        need = ops.cosine_topk_workspace(M, self.shard.size(0), self.shard.size(1), k)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty((need,), dtype=torch.uint8, device=self.shard.device)
+        return self._ws
+
+    def search(self, Q, k):
+        """Global canonical top-k for the (replicated) query block Q: (scores (M,k), idx (M,k))."""
+        s, i = local_topk(Q, self.shard, k, self.idx_base, self._workspace(Q.size(0), k))
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return s, i
+        P = dist.get_world_size(self.group)
+        all_s = torch.empty((P,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+        all_i = torch.empty((P,) + tuple(i.shape), dtype=i.dtype, device=i.device)
+        # concatenated (P*M, k) views: the layout both RCCL and gloo accept for an all-gather
+        dist.all_gather_into_tensor(all_s.view(-1, s.size(1)), s, group=self.group)
+        dist.all_gather_into_tensor(all_i.view(-1, i.size(1)), i, group=self.group)
+        return merge_topk(all_s, all_i)
+
+
+def gather_queries(q_local, group=None):
+    """Data-parallel extraction -> replicated query block: all-gather the per-rank descriptor
+    rows (rank order), equal row counts per rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return q_local
+    P = dist.get_world_size(group)
+    out = torch.empty((P * q_local.size(0), q_local.size(1)), dtype=q_local.dtype, device=q_local.device)
+    dist.all_gather_into_tensor(out, q_local.contiguous(), group=group)
+    return out

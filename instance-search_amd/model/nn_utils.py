@@ -1,0 +1,85 @@
+"""Backbone surgery helpers -- same names and behaviour as the reference's
+model/nn_utils.py (extract_layers :56-71, convolutionalize :26-39, get_feature_size :42-53,
+set_untrained_blocks :6-23, set_net_train :160-163), written against isx.backbones instead
+of torchvision.  The BN copy/replace helpers (:74-134) are training-time surgery and are
+out of scope."""
+import torch
+import torch.nn as nn
+
+from isx import backbones as models
+
+
+def set_untrained_blocks(containers, n):
+    """n < 0 freezes everything; otherwise the first n parameterised modules (counted across
+    the containers in order) are frozen and the rest left trainable."""
+    params_of = lambda m: list(m.parameters())
+    for seq in containers:
+        for m in seq:
+            for p in params_of(m):
+                p.requires_grad = n >= 0
+    frozen = 0
+    for seq in containers:
+        for m in seq:
+            if frozen >= n:
+                break
+            ps = params_of(m)
+            if not ps:
+                continue            # parameter-free modules do not count
+            for p in ps:
+                p.requires_grad = False
+            frozen += 1
+
+
+def convolutionalize(fc, in_size2d):
+    """Linear(C*h*w -> out) as Conv2d(C -> out, kernel (h, w)): weight rows are viewed
+    (C, h, w), i.e. channel-major then h then w."""
+    kh, kw = in_size2d
+    if fc.in_features % (kh * kw) != 0:
+        raise ValueError('FC in_feature size {0} is not divisible by in_size2d {1}'.format(fc.in_features, in_size2d))
+    cin = fc.in_features // (kh * kw)
+    conv = nn.Conv2d(cin, fc.out_features, (kh, kw), bias=fc.bias is not None)
+    with torch.no_grad():
+        conv.weight.copy_(fc.weight.reshape(fc.out_features, cin, kh, kw))
+        if fc.bias is not None:
+            conv.bias.copy_(fc.bias)
+    return conv.to(fc.weight.device)
+
+
+def get_feature_size(seq, factor=1, default=-1):
+    """Output width of the last conv-like / linear module of `seq` (conv widths times `factor`)."""
+    size = default
+    for m in seq:
+        if isinstance(m, models.Bottleneck):
+            size = m.conv3.out_channels * factor
+        elif isinstance(m, models.BasicBlock):
+            size = m.conv2.out_channels * factor
+        elif isinstance(m, nn.Conv2d):
+            size = m.out_channels * factor
+        elif isinstance(m, nn.Linear):
+            size = m.out_features
+    return size
+
+
+def extract_layers(net):
+    """(features, feature_reduc, classifier) of a backbone."""
+    if all(hasattr(net, a) for a in ('features', 'feature_reduc', 'classifier')):
+        return net.features, net.feature_reduc, net.classifier
+    if isinstance(net, models.ResNet):
+        stem = [net.conv1, net.bn1, net.relu, net.maxpool]
+        blocks = [b for layer in (net.layer1, net.layer2, net.layer3, net.layer4) for b in layer]
+        return nn.Sequential(*(stem + blocks)), nn.Sequential(net.avgpool), nn.Sequential(net.fc)
+    return net.features, nn.Sequential(), net.classifier
+
+
+def set_batch_norm_train(seq, train):
+    for m in seq.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.train(mode=train)
+
+
+def set_net_train(net, train, bn_train=False):
+    """train/eval switch; in train mode BatchNorm (only net.features has any) stays frozen
+    unless bn_train."""
+    net.train(mode=train)
+    if train and not bn_train:
+        set_batch_norm_train(net.features, False)

@@ -1,0 +1,188 @@
+"""The four network wrappers of the reference (model/siamese.py) with the same constructor
+signatures, attributes and state-dict keys:
+
+  TuneClassif          (:10-54)    classifier fine-tuned from a backbone
+  TuneClassifSub       (:57-89)    same, fully convolutional: a class-score MAP per image
+  DescriptorNet        (:92-130)   global siamese descriptor: features -> L2 -> Shift -> Linear -> L2
+  RegionDescriptorNet  (:133-231)  descriptor summed over the k best-classified windows
+
+Backbone convolutions run through PyTorch-ROCm.  Everything after the last conv runs in the
+hand-written HIP kernels of libisx when the tensors are on the GPU and no autograd graph is
+being recorded (inference, the path this repo accelerates); with autograd or on CPU the
+same arithmetic runs as plain torch modules.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .custom_modules import NormalizeL2, Shift
+from .nn_utils import convolutionalize, extract_layers, get_feature_size, set_untrained_blocks
+
+
+def _fast(x):
+    """HIP path: GPU tensor, inference."""
+    return x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad)
+
+
+class BoxPool(nn.AvgPool2d):
+    """nn.AvgPool2d(feature_size2d, stride=1) (reference model/siamese.py:67-71, 166-170) backed
+    by libisx `isx_boxpool_s1` on the GPU."""
+
+    def forward(self, x):
+        if _fast(x) and self.stride in (1, (1, 1)) and self.padding in (0, (0, 0)):
+            from isx import ops
+            kh, kw = self.kernel_size if isinstance(self.kernel_size, tuple) else (self.kernel_size,) * 2
+            return ops.boxpool_s1(x.float(), kh, kw)
+        return super().forward(x)
+
+
+def _pool_factor(reduc):
+    f = 1
+    for m in reduc:
+        ks = m.kernel_size
+        f *= ks[0] * ks[1] if isinstance(ks, tuple) else ks * ks
+    return f
+
+
+def _convolutionalize_classifier(classifier, feature_size2d, has_reduc):
+    """Every Linear becomes a conv; only the first one, and only when no pooling precedes it
+    (AlexNet-like), takes the full feature window -- the others are 1x1."""
+    seen = 0
+    for name, m in list(classifier._modules.items()):
+        if isinstance(m, nn.Linear):
+            size2d = (1, 1) if (has_reduc or seen > 0) else tuple(feature_size2d)
+            classifier._modules[name] = convolutionalize(m, size2d)
+            seen += 1
+
+
+class TuneClassif(nn.Module):
+    def __init__(self, net, num_classes, untrained=-1, reduc=True):
+        super().__init__()
+        self.features, self.feature_reduc, self.classifier = extract_layers(net)
+        set_untrained_blocks([self.features, self.classifier], untrained)
+        # the last classifier module becomes Linear(in, num_classes) unless it already is one
+        names = list(self.classifier._modules)
+        last = self.classifier._modules[names[-1]]
+        if not isinstance(last, nn.Linear) or last.out_features != num_classes:
+            self.classifier._modules[names[-1]] = nn.Linear(last.in_features, num_classes)
+        self.feature_size = num_classes
+        if not reduc:
+            # drop the spatial reduction: the first FC then sees every location
+            factor = _pool_factor(self.feature_reduc)
+            first = self.classifier._modules[names[0]]
+            self.classifier._modules[names[0]] = nn.Linear(first.in_features * factor, first.out_features)
+            self.feature_reduc = nn.Sequential()
+
+    def forward(self, x):
+        x = self.features(x)
+        x = self.feature_reduc(x)
+        return self.classifier(x.view(x.size(0), -1))
+
+
+class TuneClassifSub(TuneClassif):
+    def __init__(self, net, num_classes, feature_size2d, untrained=-1):
+        super().__init__(net, num_classes, untrained, reduc=True)
+        has_reduc = len(self.feature_reduc) > 0
+        if has_reduc:
+            self.feature_reduc = nn.Sequential(BoxPool(tuple(feature_size2d), stride=1))
+        _convolutionalize_classifier(self.classifier, feature_size2d, has_reduc)
+
+    def forward_single(self, x):
+        return self.classifier(self.feature_reduc(self.features(x)))
+
+    def forward(self, *scales):
+        return [self.forward_single(x) for x in scales]
+
+
+def _descriptor_head(in_features, out_features):
+    return nn.Sequential(NormalizeL2(), Shift(in_features), nn.Linear(in_features, out_features))
+
+
+def _apply_head(head, rows):
+    """feature_reduc1 on (R, F) rows: NormalizeL2 -> Shift -> Linear; fused prologue on the GPU."""
+    if _fast(rows):
+        from isx import ops
+        lin = head[2]
+        return F.linear(ops.l2norm_shift_rows(rows.float(), head[1].param.detach()), lin.weight, lin.bias)
+    return head(rows)
+
+
+class DescriptorNet(nn.Module):
+    def __init__(self, net, feature_dim, feature_size2d, untrained=-1):
+        super().__init__()
+        self.features, _, classifier = extract_layers(net)
+        set_untrained_blocks([self.features], untrained)
+        in_features = get_feature_size(self.features, feature_size2d[0] * feature_size2d[1])
+        self.feature_size = feature_dim if feature_dim > 0 else get_feature_size(classifier)
+        self.feature_reduc1 = _descriptor_head(in_features, self.feature_size)
+        self.feature_reduc2 = NormalizeL2()
+
+    def forward_single(self, x):
+        x = self.features(x)
+        x = x.reshape(x.size(0), -1)
+        return self.feature_reduc2(_apply_head(self.feature_reduc1, x))
+
+    def forward(self, x1, x2=None, x3=None):
+        if self.training and x3 is not None:
+            return self.forward_single(x1), self.forward_single(x2), self.forward_single(x3)
+        if self.training:
+            return self.forward_single(x1), self.forward_single(x2)
+        return self.forward_single(x1)
+
+
+class RegionDescriptorNet(nn.Module):
+    def __init__(self, net, k, feature_dim, feature_size2d, untrained=-1):
+        super().__init__()
+        self.k = k
+        self.feature_size2d = tuple(feature_size2d)
+        self.features, self.feature_reduc, self.classifier = extract_layers(net)
+        in_features = get_feature_size(self.features, feature_size2d[0] * feature_size2d[1])
+        # (the reference's feature_dim <= 0 branch names an undefined variable, model/siamese.py:158;
+        #  the evident intent -- the classifier's width -- is implemented instead)
+        self.feature_size = feature_dim if feature_dim > 0 else get_feature_size(self.classifier)
+        has_reduc = len(self.feature_reduc) > 0
+        if has_reduc:
+            self.feature_reduc = nn.Sequential(BoxPool(self.feature_size2d, stride=1))
+        _convolutionalize_classifier(self.classifier, self.feature_size2d, has_reduc)
+        set_untrained_blocks([self.features, self.classifier], untrained)
+        self.feature_reduc1 = _descriptor_head(in_features, self.feature_size)
+        self.feature_reduc2 = NormalizeL2()
+
+    def _single_image(self, x, c):
+        """x: (1,C,Hf,Wf) feature map, c: (1,n_cls,H',W') class-score map of ONE image."""
+        kh, kw = self.feature_size2d
+        n_loc = c.size(2) * c.size(3)
+        k = min(n_loc, self.k)
+        if _fast(x):
+            from isx import ops
+            flat_idx, _ = ops.region_topk(c[0].float(), k)
+            rows = ops.region_gather_l2(x[0].float(), kh, kw, flat_idx, c.size(3), self.feature_reduc1[1].param.detach())
+            lin = self.feature_reduc1[2]
+            acc = F.linear(rows, lin.weight, lin.bias).sum(0, keepdim=True)
+        else:
+            c_maxv = c.max(1)[0].view(-1)
+            # canonical tie-break (score desc, index asc): a stable descending sort
+            flat_idx = c_maxv.sort(descending=True, stable=True)[1][:k]
+            acc = x.new_zeros(1, self.feature_size)
+            for i in flat_idx.tolist():
+                r, col = i // c.size(3), i % c.size(3)
+                region = x[:, :, r:r + kh, col:col + kw].reshape(1, -1)
+                acc = acc + self.feature_reduc1(region)
+        cls_out = c.new_zeros(1, c.size(1), self.k)
+        cls_out[0, :, :k] = c[0].reshape(c.size(1), -1)[:, flat_idx]
+        return self.feature_reduc2(acc), cls_out
+
+    def forward_single(self, x):
+        # the reference handles one image per call (model/siamese.py:184); a batch is walked image
+        # by image here (feature maps of one batch share a shape, the top-k windows do not)
+        x = self.features(x)
+        c = self.classifier(self.feature_reduc(x))
+        outs = [self._single_image(x[b:b + 1], c[b:b + 1]) for b in range(x.size(0))]
+        return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
+
+    def forward(self, x1, x2=None, x3=None):
+        if self.training and x3 is not None:
+            return self.forward_single(x1), self.forward_single(x2), self.forward_single(x3)
+        if self.training:
+            return self.forward_single(x1), self.forward_single(x2)
+        return self.forward_single(x1)[0]

@@ -1,0 +1,150 @@
+"""Shared plumbing of the four evaluation entry points: dataset loading (image folder as in
+the reference, or the in-memory synthetic source), the retrieval evaluation itself and the
+getopt front-end."""
+from __future__ import print_function
+
+import getopt
+import os
+import sys
+import traceback
+
+import torch
+
+from train.global_p import image_sizes, match_label_functions, mean_std_files
+from utils import (check_bool, check_file, check_folder, check_int, check_model, get_images_labels, log_detail,
+                   mean_avg_precision, parse_dataset_id, precision1, read_mean_std, similarity_matrix, synthetic_image_set)
+
+SYNTHETIC = 'synthetic:'
+
+
+def imread_rgb(fname):
+    from PIL import Image
+    return Image.open(fname).convert('RGB')
+
+
+def to_normalised_tensor(img, mean, std):
+    """ToTensor + Normalize (reference test/*_test.py:65): HWC uint8 -> CHW float in [0,1], per-channel."""
+    import numpy as np
+    x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+    m = torch.tensor(list(mean)).view(-1, 1, 1)
+    s = torch.tensor(list(std)).view(-1, 1, 1)
+    return (x - m) / s
+
+
+def is_synthetic(dataset_full):
+    return dataset_full.startswith(SYNTHETIC)
+
+
+def synthetic_spec(dataset_full):
+    """'synthetic:<dataset id>[:n=100][:q=20][:labels=10][:size=224]' -> (id, dict)."""
+    parts = dataset_full[len(SYNTHETIC):].split(':')
+    opts = dict(n=100, q=20, labels=10, size=224)
+    for p in parts[1:]:
+        k, v = p.split('=')
+        opts[k] = int(v)
+    return parts[0], opts
+
+
+def dataset_id_of(dataset_full):
+    return synthetic_spec(dataset_full)[0] if is_synthetic(dataset_full) else parse_dataset_id(dataset_full)
+
+
+def load_sets(dataset_full, labels):
+    """(test_set, test_train_set) as lists of (normalised tensor, label, path); fills `labels`
+    with the sorted label set of the reference (gallery) images; queries whose label is
+    unknown are dropped (reference test/classif_finetune_test.py:62-73)."""
+    if is_synthetic(dataset_full):
+        _, o = synthetic_spec(dataset_full)
+        size = (3, o['size'], o['size'])
+        ref = synthetic_image_set(o['n'], o['labels'], size, seed=1234, prefix='synthetic/ref')
+        qry = synthetic_image_set(o['q'], o['labels'], size, seed=4321, prefix='synthetic/test')
+        labels.extend(sorted(set(lab for _, lab, _ in ref)))
+        return [t for t in qry if t[1] in labels], ref
+    dataset_id = parse_dataset_id(dataset_full)
+    match = match_label_functions[dataset_id]
+    ref_files = get_images_labels(dataset_full, match)
+    qry_files = get_images_labels(dataset_full + '/test', match)
+    labels.extend(sorted(set(lab for _, lab in ref_files)))
+    mean, std = read_mean_std(mean_std_files[dataset_id])
+    load = lambda f: to_normalised_tensor(imread_rgb(f), mean, std)
+    ref = [(load(f), lab, f) for f, lab in ref_files]
+    qry = [(load(f), lab, f) for f, lab in qry_files if lab in labels]
+    return qry, ref
+
+
+def evaluate_retrieval(test_embeddings, ref_embeddings, test_set, ref_set, device, labels, dba):
+    """sim -> P@1 + mAP, the reference's result line, then the optional DBA pass.  Returns the
+    (prec1, mAP) pair of the plain pass (the reference returns nothing; the prints are the API)."""
+    sim = similarity_matrix(test_embeddings, ref_embeddings)
+    prec1, c, t, _, _ = precision1(sim, test_set, ref_set)
+    mAP = mean_avg_precision(sim, test_set, ref_set)
+    print('Descriptor (TEST): {0} / {1} - acc: {2:.4f} - mAP:{3:.4f}'.format(c, t, prec1, mAP))
+    if dba == 0:
+        return prec1, mAP
+    from .instance_avg import instance_avg
+    print('Testing using instance feature augmentation')
+    dba_embeddings, dba_set = instance_avg(device, ref_embeddings, ref_set, labels, dba)
+    sim = similarity_matrix(test_embeddings, dba_embeddings)
+    p1d, c, t, _, _ = precision1(sim, test_set, dba_set)
+    mAPd = mean_avg_precision(sim, test_set, dba_set)
+    print('Descriptor (TEST DBA k={4}): {0} / {1} - acc: {2:.4f} - mAP:{3:.4f}'.format(c, t, p1d, mAPd, dba))
+    return prec1, mAP
+
+
+def run_cli(argv, usage, spec, required, main, P):
+    """getopt front-end shared by the four scripts.  `spec`: option name -> (kind, label) with
+    kind in {'dataset','model','file','int','bool'}; returns after calling main(**values)."""
+    try:
+        opts, _ = getopt.getopt(argv, '', ['help'] + [name + '=' for name in spec])
+    except getopt.GetoptError:
+        usage()
+        sys.exit(2)
+    values = dict((name.replace('-', '_'), None) for name in spec)
+    values['dba'] = -1 if 'dba' in spec else None
+    for opt, arg in opts:
+        if opt == '--help':
+            usage()
+            sys.exit()
+        name = opt[2:]
+        kind, label = spec[name]
+        if kind == 'dataset':
+            val = arg if is_synthetic(arg) else check_folder(arg, label, True, usage)
+        elif kind == 'model':
+            val = check_model(arg, usage)
+        elif kind == 'file':
+            val = check_file(arg, label, True, usage)
+        elif kind == 'int':
+            val = check_int(arg, label, usage)
+        else:
+            val = check_bool(arg, label, usage)
+        values[name.replace('-', '_')] = val
+    if any(values[r] is None for r in required):
+        print('One or more required arguments is missing.')
+        usage()
+        sys.exit(2)
+    if 'dba' not in spec:
+        values.pop('dba', None)
+    device = values['device']
+    try:
+        if device >= 0:
+            with torch.cuda.device(device):
+                main(**values)
+        else:
+            main(**values)
+    except Exception:
+        log_detail(P, None, traceback.format_exc())
+        raise
+
+
+def usage_text(script, lines):
+    print('Usage: ' + script + ' [options]')
+    print('Options:\n\tRequired:\n' + ''.join(lines) + '--help\t\tShow this help\n')
+
+
+O_DATASET = ('--dataset=\t<path>\tThe path to the dataset containing all reference images. It should contain a '
+             'sub-folder "test" containing all test images (or synthetic:<id>[:n=..][:q=..][:labels=..])\n')
+O_MODEL = '--model=\t<name>\tAlexNet, ResNet152 or ResNet50 to specify the type of model.\n'
+O_DEVICE = '--device=\t<int>\tThe GPU device used for testing. If negative, CPU is used.\n'
+O_DBA = ('--dba=\t<int>\tUse DBA with given k. If k = 0, do not use DBA. If k<0, use all neighbors within the '
+         'same instance.\n')
+O_BATCH = '--batch=\t<int>\tThe batch size to use.\n'

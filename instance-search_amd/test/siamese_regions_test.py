@@ -1,0 +1,49 @@
+"""Evaluation entry point of the region siamese descriptor approach (reference
+test/siamese_regions_test.py): descriptor summed over the k best-classified windows."""
+from __future__ import print_function
+
+import sys
+
+from model.nn_utils import set_net_train
+from train.global_p import feature_sizes, image_sizes
+from train.siamese_regions import P, get_embeddings, get_siamese_net, labels
+from . import _common as C
+
+
+def usage():
+    C.usage_text(sys.argv[0], [
+        C.O_DATASET, C.O_MODEL,
+        '--weights=\t<file>\tThe filename containing weights of a network trained as region siamese descriptor.\n',
+        C.O_DEVICE, '--feature-dim=\t<int>\tThe dimension of the descriptor.\n',
+        '--regions-k=\t<int>\tThe number of regions to use.\n', C.O_DBA])
+
+
+def main(dataset_full, model, weights, device, feature_dim, regions_k, dba):
+    dataset_id = C.dataset_id_of(dataset_full)
+    del labels[:]
+    print('Loading and transforming train/test sets.')
+    test_set, test_train_set = C.load_sets(dataset_full, labels)
+    P.num_classes = len(labels)
+    P.test_pre_proc = True
+    P.cuda_device = device
+    P.preload_net = weights
+    P.cnn_model = model
+    P.feature_size2d = feature_sizes[model, image_sizes[dataset_id]]
+    P.classif_model = ''
+    P.feature_dim = feature_dim
+    P.regions_k = regions_k
+
+    print('Testing network on dataset with ID {0}'.format(dataset_id))
+    net = get_siamese_net()
+    set_net_train(net, False)
+    test_embeddings = get_embeddings(net, test_set, device, net.feature_size)
+    ref_embeddings = get_embeddings(net, test_train_set, device, net.feature_size)
+    return C.evaluate_retrieval(test_embeddings, ref_embeddings, test_set, test_train_set, device, labels, dba)
+
+
+if __name__ == '__main__':
+    C.run_cli(sys.argv[1:], usage,
+              {'dataset': ('dataset', 'dataset'), 'model': ('model', 'model'), 'weights': ('file', 'initialization weights'),
+               'device': ('int', 'device'), 'feature-dim': ('int', 'feature-dim'), 'regions-k': ('int', 'regions-k'), 'dba': ('int', 'dba')},
+              ('dataset', 'model', 'device', 'feature_dim', 'regions_k'),
+              lambda dataset, model, weights, device, feature_dim, regions_k, dba: main(dataset, model, weights, device, feature_dim, regions_k, dba), P)

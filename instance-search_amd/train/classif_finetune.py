@@ -1,0 +1,77 @@
+"""Global-descriptor approach: the retrieval-path functions of the reference's
+train/classif_finetune.py -- get_embeddings (:82-110), get_class_net (:113-121),
+test_classif_net (:25-50).  The fine-tuning loop (:53-78, main) is out of scope."""
+import torch
+import torch.nn as nn
+
+from model.custom_modules import l2_normalize_rows
+from model.siamese import TuneClassif
+from utils import fold_batches, move_device, tensor
+from ._common import base_model, load_weights, stage_batch, test_transform
+from .classif_finetune_p import P
+
+labels = []   # filled by the entry point once the reference set is listed, then constant
+
+
+def test_classif_net(net, test_set):
+    """(correct, total) classification accuracy of an eval-mode net."""
+    trans = test_transform(P)
+
+    def run(acc, i, is_final, batch):
+        correct, total = acc
+        with torch.no_grad():
+            pred = net(stage_batch(batch, trans, P.cuda_device)).argmax(1).tolist()
+        correct += sum(1 for (_, lab, _), p in zip(batch, pred) if labels.index(lab) == p)
+        return correct, total + len(batch)
+
+    return fold_batches(run, (0, 0), test_set, P.test_batch_size)
+
+
+def _full_map_pool(net, fmap):
+    """True when feature_reduc is exactly one average pool spanning the whole feature map."""
+    reduc = list(net.feature_reduc)
+    if len(reduc) != 1 or not isinstance(reduc[0], nn.AvgPool2d):
+        return False
+    ks = reduc[0].kernel_size
+    ks = ks if isinstance(ks, tuple) else (ks, ks)
+    return tuple(fmap.shape[2:]) == tuple(ks)
+
+
+def get_embeddings(net, dataset, device, out_size):
+    """(len(dataset), out_size) slab of L2-normalised descriptors on `device`.
+    P.embeddings_classify False: pooled convolutional features (classifier stripped for the
+    pass, restored afterwards); True: the class scores.  On the GPU the pool + L2 of a batch is
+    one fused kernel (`isx_gap_l2`) writing straight into the slab rows."""
+    trans = test_transform(P)
+    stripped = not P.embeddings_classify
+    if stripped:
+        classifier, net.classifier = net.classifier, nn.Sequential()
+    slab = tensor(device, len(dataset), out_size)
+
+    def run(slab, i, is_final, batch):
+        x = stage_batch(batch, trans, P.cuda_device)
+        rows = slab[i:i + len(batch)]
+        with torch.no_grad():
+            if stripped and x.is_cuda and slab.is_cuda:
+                fmap = net.features(x)
+                if _full_map_pool(net, fmap):
+                    from isx import ops
+                    ops.gap_l2(fmap.float(), out=rows)
+                    return slab
+                out = net.feature_reduc(fmap)
+                out = out.view(out.size(0), -1)
+            else:
+                out = net(x)
+            rows.copy_(l2_normalize_rows(out))
+        return slab
+
+    try:
+        return fold_batches(run, slab, dataset, P.test_batch_size)
+    finally:
+        if stripped:
+            net.classifier = classifier
+
+
+def get_class_net():
+    net = TuneClassif(base_model(P), len(labels), untrained=P.untrained_blocks)
+    return move_device(load_weights(net, P.preload_net), P.cuda_device)

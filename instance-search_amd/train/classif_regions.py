@@ -1,0 +1,73 @@
+"""Sub-region classifier approach: get_embeddings (reference train/classif_regions.py:107-132),
+get_class_net (:135-149), test_classif_net (:25-51).  Descriptor = the class-score vector at the
+location whose best class score is highest, L2-normalised."""
+import torch
+
+from model.custom_modules import l2_normalize_rows
+from model.siamese import TuneClassif, TuneClassifSub
+from utils import fold_batches, move_device, tensor
+from ._common import base_model, load_weights, stage_batch, test_transform
+from .classif_regions_p import P
+
+labels = []
+
+
+def _best_location_descriptors(score_map):
+    """(B, n_cls, H', W') -> (B, n_cls): libisx `isx_best_location_desc` on the GPU."""
+    if score_map.is_cuda:
+        from isx import ops
+        return ops.best_location_desc(score_map.float())[0]
+    B, K, Hp, Wp = score_map.shape
+    mx = score_map.max(1)[0]                                   # class-max map
+    # first maximal index: smallest column, then smallest row in that column
+    colmax, row_of_col = mx.max(1)                             # over rows, per column
+    col = colmax.max(1)[1]
+    row = row_of_col.gather(1, col[:, None])[:, 0]
+    picked = score_map[torch.arange(B), :, row, col]
+    return l2_normalize_rows(picked)
+
+
+def test_classif_net(net, test_set):
+    trans = test_transform(P)
+
+    def run(acc, i, is_final, batch):
+        correct, total = acc
+        with torch.no_grad():
+            out = net(stage_batch(batch, trans, P.cuda_device))[0]
+            # prediction = class of the globally highest score over all locations
+            pred = out.max(1)[0].flatten(1).argmax(1)
+            flat = out.flatten(2)
+            cls = flat[torch.arange(out.size(0)), :, pred].argmax(1).tolist()
+        correct += sum(1 for (_, lab, _), p in zip(batch, cls) if labels.index(lab) == p)
+        return correct, total + len(batch)
+
+    return fold_batches(run, (0, 0), test_set, 1)
+
+
+def get_embeddings(net, dataset, device, out_size):
+    trans = test_transform(P)
+    slab = tensor(device, len(dataset), out_size)
+
+    def run(slab, i, is_final, batch):
+        with torch.no_grad():
+            out = net(stage_batch(batch, trans, P.cuda_device))[0]
+            slab[i:i + len(batch)].copy_(_best_location_descriptors(out))
+        return slab
+
+    # the reference walks one image at a time (images may differ in size); same-sized images
+    # can be batched, which P.test_batch_size > 1 enables
+    bs = P.test_batch_size if _same_size(dataset) else 1
+    return fold_batches(run, slab, dataset, max(bs, 1))
+
+
+def _same_size(dataset):
+    return len(set(tuple(im.shape) for im, _, _ in dataset)) <= 1
+
+
+def get_class_net():
+    if P.bn_model:
+        bn_model = load_weights(TuneClassif(base_model(P, pretrained=False), len(labels)), P.bn_model)
+    else:
+        bn_model = base_model(P)
+    net = TuneClassifSub(bn_model, len(labels), P.feature_size2d, untrained=P.untrained_blocks)
+    return move_device(load_weights(net, P.preload_net), P.cuda_device)

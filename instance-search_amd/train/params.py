@@ -1,0 +1,32 @@
+"""The global `P` parameter object the reference's entry points mutate
+(train/*_p.py: `P = Params()` built at import).  Only the fields of the retrieval path exist
+(test mains set: test_pre_proc, cuda_device, image_input_size, test_batch_size, preload_net,
+cnn_model, feature_size2d, embeddings_classify, feature_dim, num_classes, classif_model,
+bn_model, regions_k -- test/*_test.py:44-56); training hyper-parameters are out of scope.
+Unlike the reference nothing is read from disk at import."""
+
+
+class Params(object):
+    def __init__(self, **overrides):
+        self.cnn_model = 'AlexNet'
+        self.cuda_device = 0
+        self.image_input_size = (3, 224, 224)
+        self.num_classes = 464
+        self.feature_size2d = (6, 6)
+        self.untrained_blocks = -1
+        self.preload_net = ''
+        self.bn_model = ''
+        self.classif_model = ''
+        self.test_batch_size = 64
+        self.test_pre_proc = True
+        self.test_trans = None                 # identity when test_pre_proc (images arrive normalised)
+        self.embeddings_classify = False
+        self.feature_dim = 2048
+        self.regions_k = 6                     # train/siamese_regions_p.py:98
+        self.train_bn = False
+        # descriptor slabs / similarity matrices larger than this go to the CPU in the reference
+        # (2**30 there, utils/train_siamese.py:30-43); sized here for 288 GB of HBM3E
+        self.embeddings_cuda_size = 64 * 2 ** 30
+        self.log_file = None
+        for k, v in overrides.items():
+            setattr(self, k, v)

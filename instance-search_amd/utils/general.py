@@ -1,0 +1,101 @@
+"""Option checkers, dataset-id / mean-std parsing and device helpers -- the subset of the
+reference's utils/general.py that the retrieval entry points use (check_* :13-67,
+parse_dataset_id :70-73, read_mean_std :76-80, move_device / tensor_t / tensor :94-106,
+log / log_detail :137-146)."""
+from __future__ import print_function
+
+import os
+import sys
+
+import torch
+
+
+def _fail(message, usage):
+    print(message)
+    usage()
+    sys.exit(2)
+
+
+def check_file(arg, name, should_exist, usage):
+    present = os.path.isfile(arg)
+    if should_exist and not present:
+        _fail('Cannot find {0} file at path {1}\n'.format(name, arg), usage)
+    if not should_exist and present:
+        _fail('Cannot overwrite {0} file at path {1}\n'.format(name, arg), usage)
+    return arg
+
+
+def check_folder(arg, name, should_exist, usage):
+    present = os.path.isdir(arg)
+    if should_exist and not present:
+        _fail('Cannot find {0} folder at path {1}\n'.format(name, arg), usage)
+    if not should_exist and present:
+        _fail('Cannot overwrite {0} folder at path {1}\n'.format(name, arg), usage)
+    return arg
+
+
+VALID_MODELS = ('alexnet', 'resnet152', 'resnet50')   # the reference admits the first two; resnet50 is BASELINE's choice
+
+
+def check_model(arg, usage):
+    if arg.lower() in VALID_MODELS:
+        return arg.lower()
+    _fail('Model {0} is not a valid model'.format(arg), usage)
+
+
+def check_int(arg, name, usage):
+    try:
+        return int(arg)
+    except ValueError:
+        _fail('{0} was given as {1}. This is not an integer.\n'.format(name, arg), usage)
+
+
+def check_bool(arg, name, usage):
+    arg = arg.lower()
+    if arg == '':
+        _fail('{0} was not given. It should be a boolean (true/yes/y/1 for True and otherwise False).'.format(name), usage)
+    return arg in ('true', 'yes', 'y', '1')
+
+
+def parse_dataset_id(dataset_full):
+    trimmed = dataset_full[:-1] if dataset_full.endswith('/') else dataset_full   # ONE trailing slash
+    return trimmed.split('/')[-1]
+
+
+def read_mean_std(fname):
+    """Two lines of space-separated floats: per-channel mean, then std."""
+    with open(fname) as f:
+        mean = [float(v) for v in f.readline().split(' ')]
+        std = [float(v) for v in f.readline().split(' ')]
+    return mean, std
+
+
+def move_device(obj, device):
+    """device >= 0 -> the current GPU (the caller selects it with torch.cuda.device), else CPU."""
+    return obj.cuda() if device >= 0 else obj.cpu()
+
+
+def tensor_t(t, device, *sizes):
+    return move_device(t(*sizes), device)
+
+
+def tensor(device, *sizes):
+    """Uninitialised fp32 tensor, allocated directly where it will live."""
+    return torch.empty(*sizes, dtype=torch.float32, device='cuda' if device >= 0 else 'cpu')
+
+
+def log(P, message):
+    print(message)
+    log_file = getattr(P, 'log_file', None)
+    if log_file:
+        with open(log_file, 'a') as f:
+            f.write(str(message) + '\n')
+
+
+def log_detail(P, message, detail):
+    if message is not None:
+        log(P, message)
+    log_file = getattr(P, 'log_file', None)
+    if log_file and detail:
+        with open(log_file, 'a') as f:
+            f.write(str(detail) + '\n')

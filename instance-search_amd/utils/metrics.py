@@ -1,0 +1,75 @@
+"""Retrieval metrics with the reference's signatures (utils/metrics.py:8-55):
+precision1, avg_precision, mean_avg_precision over a (queries x gallery) similarity matrix
+and two datasets of (tensor, label, path) tuples.
+
+The reference sorts every row and walks every rank in a Python loop (16 ms per query at
+N = 10k).  Here a GPU matrix goes through libisx: `isx_topk_rows` for P@k,
+`isx_rank_full` + `isx_average_precision` for AP -- canonical order (score desc, index asc),
+float64 AP accumulated rank by rank in the same operation order as the Python loop, so on
+the same score matrix the values are bit-identical to the reference's.  A CPU matrix (the
+reference's `--device=-1` path) is handled with the same arithmetic in vectorised torch.
+"""
+import torch
+
+
+def _label_ids(test_set, ref_set):
+    table = {}
+    ids = lambda ds: [table.setdefault(lab, len(table)) for _, lab, _ in ds]
+    q, g = ids(test_set), ids(ref_set)
+    return torch.tensor(q, dtype=torch.int32), torch.tensor(g, dtype=torch.int32)
+
+
+def _topk(sim, k):
+    """Canonical top-k (values, indices) of every row."""
+    if sim.is_cuda:
+        from isx import ops
+        return ops.topk_rows(sim.float(), k)
+    order = sim.sort(dim=1, descending=True, stable=True)
+    return order.values[:, :k], order.indices[:, :k]
+
+
+def precision1(sim, test_set, ref_set, kth=1):
+    """Label of the kth-ranked gallery item vs the query label.
+    Returns (precision, correct, total, max_sim (M,1), max_label list)."""
+    total = sim.size(0)
+    kth = max(kth, 1)
+    vals, idx = _topk(sim, kth)
+    hit_idx = idx[:, kth - 1].tolist()
+    max_label = [ref_set[j][1] for j in hit_idx]
+    correct = sum(1 for (_, lab, _), got in zip(test_set, max_label) if lab == got)
+    return float(correct) / total, correct, total, vals[:, kth - 1:kth], max_label
+
+
+def _average_precisions(sim, qlab, glab, kth):
+    """float64 AP per query, NaN where the query has no (remaining) positive."""
+    if sim.is_cuda:
+        from isx import ops
+        ranked = ops.rank_full(sim.float())
+        return ops.average_precision(ranked, qlab.to(sim.device), glab.to(sim.device), kth).cpu()
+    M, N = sim.shape
+    ranked = sim.sort(dim=1, descending=True, stable=True).indices
+    n_pos = (glab[None, :] == qlab[:, None]).sum(1) - (kth - 1)
+    hit = (glab[ranked.long()] == qlab[:, None])[:, kth - 1:].double()          # the first kth-1 ranks are ignored
+    j = torch.arange(hit.size(1), dtype=torch.float64)[None, :]
+    incl = hit.cumsum(1)
+    before = incl - hit
+    dn = n_pos.clamp(min=1).double()[:, None]
+    recall, old_recall = incl / dn, before / dn
+    precision = incl / (j + 1.0)
+    old_precision = torch.where(j == 0, torch.ones_like(j), before / j.clamp(min=1.0))
+    terms = (recall - old_recall) * ((old_precision + precision) / 2.0)            # exactly 0 off the hits
+    ap = terms.cumsum(1)[:, -1] if hit.size(1) > 0 else torch.zeros(M, dtype=torch.float64)   # sequential, rank order
+    return torch.where(n_pos > 0, ap, torch.full_like(ap, float('nan')))
+
+
+def avg_precision(sim, i, test_set, ref_set, kth=1):
+    """Oxford-buildings AP of query i; None when it has no positive left after skipping kth-1."""
+    qlab, glab = _label_ids(test_set, ref_set)
+    ap = _average_precisions(sim[i:i + 1], qlab[i:i + 1], glab, kth)[0].item()
+    return None if ap != ap else ap
+
+
+def mean_avg_precision(sim, test_set, ref_set, kth=1):
+    qlab, glab = _label_ids(test_set, ref_set)
+    aps = [a for a in _average_precisions(sim, qlab, glab, kth).tolist() if a == a]
+    return sum(aps) / float(len(aps))

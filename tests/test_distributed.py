@@ -1,0 +1,75 @@
+"""world_size-2 gloo (CPU) run of the sharded-gallery driver: sharded == unsharded, bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle as O
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "instance-search_amd"))
+    from isx import retrieval as R
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(0)
+    N, D, k, Mloc = 203, 24, 10, 3
+    G = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+    G[150] = G[7]                                           # tie across the shard boundary
+    Qall = torch.nn.functional.normalize(torch.randn(world * Mloc, D, generator=g), dim=1)
+    gal = R.ShardedGallery.from_full(G)
+    lo, hi = R.shard_bounds(N, world, rank)
+    assert gal.shard.size(0) == hi - lo and gal.idx_base == lo
+    Q = R.gather_queries(Qall[rank * Mloc:(rank + 1) * Mloc])
+    assert torch.equal(Q, Qall)
+    s, i = gal.search(Q, k)
+    # k larger than a shard row count exercises the (-inf,-1) padding
+    tiny = R.ShardedGallery(G[lo:lo + 2], lo)
+    s2, i2 = tiny.search(Q, 5)
+    torch.save({"s": s, "i": i, "s2": s2, "i2": i2, "G": G, "Q": Qall, "lo": lo}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_matches_unsharded(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "r%d.pt" % k)) for k in range(world)]
+    assert torch.equal(r[0]["i"], r[1]["i"]) and torch.equal(r[0]["s"], r[1]["s"])      # every rank holds the merged result
+    G, Q = r[0]["G"], r[0]["Q"]
+    sim = Q @ G.t()
+    want = sim.sort(dim=1, descending=True, stable=True)
+    assert torch.equal(r[0]["i"], want.indices[:, :10])
+    assert torch.equal(r[0]["s"], want.values[:, :10])
+    # the canonical order also agrees with the oracle's ranking of the same score matrix
+    np.testing.assert_array_equal(r[0]["i"].numpy(), O.rank_full(sim.numpy())[:, :10])
+    # tiny shards: 2 rows each -> 4 real candidates + padding
+    rows = torch.cat([G[r[0]["lo"]:r[0]["lo"] + 2], G[r[1]["lo"]:r[1]["lo"] + 2]])
+    ids = torch.tensor([r[0]["lo"], r[0]["lo"] + 1, r[1]["lo"], r[1]["lo"] + 1])
+    sub = (Q @ rows.t())
+    o = sub.sort(dim=1, descending=True, stable=True)
+    assert torch.equal(r[0]["i2"][:, :4], ids[o.indices])
+    assert (r[0]["i2"][:, 4:] == -1).all() and torch.isinf(r[0]["s2"][:, 4:]).all()
+
+
+def test_shard_bounds_cover_rows():
+    from isx.retrieval import shard_bounds
+    for n in (0, 1, 7, 8, 1000003):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
