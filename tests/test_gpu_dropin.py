@@ -1,0 +1,131 @@
+"""The Python drop-in surface on the GPU: the HIP path is the one that runs, and it agrees with
+the CPU restatement at the kernel boundary (same feature map in -> same descriptors out)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def host(t):
+    return t.detach().float().cpu().numpy()
+
+
+def test_libisx_is_loaded_and_used():
+    from isx import _lib, ops
+    assert _lib.lib().isx_version() >= 100
+    x = torch.randn(4, 64, device="cuda")
+    y = ops.l2norm_rows(x)
+    maps = open("/proc/self/maps").read()
+    assert "libisx.so" in maps                                     # the native library really is in this process
+    np.testing.assert_allclose(host(y), O.l2norm_rows(host(x)), rtol=2e-6, atol=2e-7)
+
+
+def test_modules_gpu_vs_oracle():
+    from model.custom_modules import NormalizeL2, Shift
+    x = torch.randn(33, 2048, device="cuda")
+    np.testing.assert_allclose(host(NormalizeL2()(x)), O.l2norm_rows(host(x)), rtol=2e-6, atol=2e-7)
+    sh = Shift(2048).cuda()
+    sh.param.data.normal_()
+    np.testing.assert_array_equal(host(sh(x)), O.shift_rows(host(x), host(sh.param)))
+    # with autograd the same op still differentiates
+    xr = x.clone().requires_grad_(True)
+    NormalizeL2()(xr).sum().backward()
+    assert xr.grad is not None and torch.isfinite(xr.grad).all()
+
+
+def test_global_descriptor_path_kernel_boundary():
+    from isx import backbones
+    from model.nn_utils import set_net_train
+    from model.siamese import TuneClassif
+    from train import classif_finetune as cf
+    from utils.dataset import synthetic_image_set
+    net = TuneClassif(backbones.resnet18(pretrained=True), 10).cuda()
+    set_net_train(net, False)
+    ds = synthetic_image_set(10, 3)
+    cf.P.test_pre_proc, cf.P.cuda_device, cf.P.test_batch_size, cf.P.embeddings_classify = True, 0, 4, False
+    slab = cf.get_embeddings(net, ds, 0, 512)
+    assert slab.is_cuda and slab.shape == (10, 512)
+    with torch.no_grad():
+        fmap = net.features(torch.stack([d[0] for d in ds]).cuda())
+    np.testing.assert_allclose(host(slab), O.gap_l2(host(fmap)), rtol=2e-5, atol=2e-6)     # batch-4 vs batch-10 conv rounding
+    with torch.no_grad():
+        fm4 = net.features(torch.stack([d[0] for d in ds[:4]]).cuda())
+    np.testing.assert_allclose(host(slab[:4]), O.gap_l2(host(fm4)), rtol=2e-6, atol=2e-7)
+    cf.P.embeddings_classify = True
+    slab2 = cf.get_embeddings(net, ds, 0, 10)
+    with torch.no_grad():
+        logits = net(torch.stack([d[0] for d in ds[:4]]).cuda())
+    np.testing.assert_allclose(host(slab2[:4]), O.l2norm_rows(host(logits)), rtol=2e-6, atol=2e-7)
+
+
+def test_region_modules_gpu_vs_cpu_path():
+    import copy
+    from isx import backbones
+    from model.siamese import DescriptorNet, RegionDescriptorNet, TuneClassifSub
+    from train import classif_regions as cr
+    torch.manual_seed(1)
+    sub = TuneClassifSub(backbones.resnet18(pretrained=True), 12, (7, 7)).cuda().eval()
+    x = torch.randn(2, 3, 448, 448, device="cuda")
+    with torch.no_grad():
+        fmap = sub.features(x)                                      # (2,512,14,14)
+        pooled = sub.feature_reduc(fmap)
+        np.testing.assert_array_equal(host(pooled), O.boxpool_s1(host(fmap), 7, 7))
+        cmap = sub.classifier(pooled)                               # (2,12,8,8)
+        d = cr._best_location_descriptors(cmap)
+        for b in range(2):
+            od, ol = O.best_location_desc(host(cmap[b]))
+            np.testing.assert_allclose(host(d[b]), od, rtol=2e-6, atol=2e-7)
+    rd = RegionDescriptorNet(backbones.resnet18(pretrained=True), 6, 64, (7, 7)).cuda().eval()
+    rd.feature_reduc1[1].param.data.normal_(0, 0.01)
+    rd_cpu = copy.deepcopy(rd).cpu()
+    with torch.no_grad():
+        fm = rd.features(x[:1])
+        c = rd.classifier(rd.feature_reduc(fm))
+        d_gpu, cls_gpu = rd._single_image(fm, c)
+        d_cpu, cls_cpu = rd_cpu._single_image(fm.cpu(), c.cpu())
+        np.testing.assert_allclose(host(d_gpu), host(d_cpu), rtol=1e-4, atol=1e-5)
+        np.testing.assert_array_equal(host(cls_gpu), host(cls_cpu))
+        full = rd(x)
+        assert full.shape == (2, 64)
+        np.testing.assert_allclose(host(full[:1]), host(d_gpu), rtol=1e-4, atol=1e-5)
+    dn = DescriptorNet(backbones.alexnet(pretrained=True), 128, (6, 6)).cuda().eval()
+    dn.feature_reduc1[1].param.data.normal_(0, 0.01)
+    dn_cpu = copy.deepcopy(dn).cpu()
+    xi = torch.randn(3, 3, 224, 224, device="cuda")
+    with torch.no_grad():
+        f = dn.features(xi)
+        got = dn.feature_reduc2(__import__("model.siamese", fromlist=["_apply_head"])._apply_head(dn.feature_reduc1, f.reshape(3, -1)))
+        want = dn_cpu.feature_reduc2(dn_cpu.feature_reduc1(f.cpu().reshape(3, -1)))
+        np.testing.assert_allclose(host(got), host(want), rtol=1e-4, atol=1e-5)
+
+
+def test_entry_point_on_gpu_matches_oracle(capsys):
+    from test import classif_finetune_test
+    from test._common import load_sets
+    from train import classif_finetune as cf
+    spec = "synthetic:CLICIDE_video_224sq:n=40:q=10:labels=5"
+    p1, mAP = classif_finetune_test.main(spec, "resnet50", "", 0, False, 16, 0)
+    out = capsys.readouterr().out
+    assert "Descriptor (TEST): " in out
+    labs = []
+    qs, rs = load_sets(spec, labs)
+    net = cf.get_class_net().eval()
+    cf.P.embeddings_classify = False
+    Eq, Er = cf.get_embeddings(net, qs, 0, 2048), cf.get_embeddings(net, rs, 0, 2048)
+    assert Eq.is_cuda
+    ids = {l: i for i, l in enumerate(labs)}
+    ql = np.array([ids[l] for _, l, _ in qs], np.int32); gl = np.array([ids[l] for _, l, _ in rs], np.int32)
+    sim = O.cosine_sim(host(Eq), host(Er))
+    ap = O.average_precision(O.rank_full(sim), ql, gl)
+    assert O.mean_avg_precision(ap) == mAP                          # ranks + AP bit-exact given the same descriptors
+    ts, ti = O.topk_rows(sim, 1)
+    assert O.precision1(ti, ql, gl)[0] == p1
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
