@@ -103,22 +103,25 @@ def test_region_modules_gpu_vs_cpu_path():
         np.testing.assert_allclose(host(got), host(want), rtol=1e-4, atol=1e-5)
 
 
-def test_entry_point_on_gpu_matches_oracle(capsys):
+def test_entry_point_on_gpu_matches_oracle(capsys, monkeypatch):
+    from test import _common as C
     from test import classif_finetune_test
-    from test._common import load_sets
-    from train import classif_finetune as cf
+    seen = {}
+    real = C.evaluate_retrieval
+
+    def spy(test_embeddings, ref_embeddings, test_set, ref_set, device, labels, dba):
+        seen.update(Eq=test_embeddings, Er=ref_embeddings, qs=test_set, rs=ref_set, labels=list(labels))
+        return real(test_embeddings, ref_embeddings, test_set, ref_set, device, labels, dba)
+
+    monkeypatch.setattr(C, "evaluate_retrieval", spy)
     spec = "synthetic:CLICIDE_video_224sq:n=40:q=10:labels=5"
     p1, mAP = classif_finetune_test.main(spec, "resnet50", "", 0, False, 16, 0)
     out = capsys.readouterr().out
     assert "Descriptor (TEST): " in out
-    labs = []
-    qs, rs = load_sets(spec, labs)
-    net = cf.get_class_net().eval()
-    cf.P.embeddings_classify = False
-    Eq, Er = cf.get_embeddings(net, qs, 0, 2048), cf.get_embeddings(net, rs, 0, 2048)
-    assert Eq.is_cuda
-    ids = {l: i for i, l in enumerate(labs)}
-    ql = np.array([ids[l] for _, l, _ in qs], np.int32); gl = np.array([ids[l] for _, l, _ in rs], np.int32)
+    Eq, Er = seen["Eq"], seen["Er"]
+    assert Eq.is_cuda and Eq.shape == (10, 2048) and Er.shape == (40, 2048)
+    ids = {l: i for i, l in enumerate(seen["labels"])}
+    ql = np.array([ids[l] for _, l, _ in seen["qs"]], np.int32); gl = np.array([ids[l] for _, l, _ in seen["rs"]], np.int32)
     sim = O.cosine_sim(host(Eq), host(Er))
     ap = O.average_precision(O.rank_full(sim), ql, gl)
     assert O.mean_avg_precision(ap) == mAP                          # ranks + AP bit-exact given the same descriptors
