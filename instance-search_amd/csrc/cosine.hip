@@ -24,8 +24,7 @@ namespace isx {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDT = BM + 1;            // K-major LDS row stride (floats), odd
+constexpr int BK = 32;
 constexpr int GROUP_N = 16;            // n-tiles per scheduling group
 
 struct TileMap {
@@ -48,12 +47,12 @@ __device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int
     tile_n = first_n + within % gsz;
 }
 
-template <bool ALIGNED>
+// ROWS x 32 k = ROWS*8 float4; thread t takes idx = j*256 + t: row = idx/8, chunk = idx%8
+template <bool ALIGNED, int ROWS>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t rows, int D, int64_t row0, int k0,
-                                          float4 (&reg)[4]) {
-    // 128 rows x 32 k = 1024 float4; thread t takes idx = j*256 + t: row = idx/8, chunk = idx%8
+                                          float4 (&reg)[ROWS / 32]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < ROWS / 32; ++j) {
         const int idx = j * 256 + threadIdx.x;
         int64_t r = row0 + (idx >> 3);
         r = r < rows ? r : rows - 1;                       // clamp: rows past the edge are never stored
@@ -70,25 +69,29 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t r
     }
 }
 
-__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&reg)[4]) {
+template <int ROWS>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&reg)[ROWS / 32]) {
+    constexpr int LD = ROWS + 1;                            // odd K-major stride: conflict-free transposed writes
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < ROWS / 32; ++j) {
         const int idx = j * 256 + threadIdx.x;
         const int r = idx >> 3, k = (idx & 7) << 2;
-        T[(k + 0) * LDT + r] = reg[j].x;
-        T[(k + 1) * LDT + r] = reg[j].y;
-        T[(k + 2) * LDT + r] = reg[j].z;
-        T[(k + 3) * LDT + r] = reg[j].w;
+        T[(k + 0) * LD + r] = reg[j].x;
+        T[(k + 1) * LD + r] = reg[j].y;
+        T[(k + 2) * LD + r] = reg[j].z;
+        T[(k + 3) * LD + r] = reg[j].w;
     }
 }
 
-template <bool ALIGNED>
+// Block tile (64*TM) x (64*TN): 4 waves as 2x2, each wave TM x TN MFMA tiles of 32x32.
+template <bool ALIGNED, int TM, int TN>
 __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
                                                           const float* __restrict__ G, int64_t N, int D,
                                                           float* __restrict__ C, int64_t ldc, TileMap tm) {
-    __shared__ float lds[2 * BK * LDT];
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 1, LDB = BN + 1;
+    __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
-    float* Bs = lds + BK * LDT;
+    float* Bs = lds + BK * LDA;
 
     int tile_m, tile_n;
     tile_of_block(tm, tile_m, tile_n);
@@ -98,77 +101,114 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    float4 ra[4], rb[4];
+    float4 ra[BM / 32], rb[BN / 32];
     const int nk = (D + BK - 1) / BK;
-    load_tile<ALIGNED>(Q, M, D, m0, 0, ra);
-    load_tile<ALIGNED>(G, N, D, n0, 0, rb);
-    store_tile(As, ra);
-    store_tile(Bs, rb);
+    load_tile<ALIGNED, BM>(Q, M, D, m0, 0, ra);
+    load_tile<ALIGNED, BN>(G, N, D, n0, 0, rb);
+    store_tile<BM>(As, ra);
+    store_tile<BN>(Bs, rb);
     __syncthreads();
 
-    const float* a_base = As + half * LDT + wm * 64 + l31;
-    const float* b_base = Bs + half * LDT + wn * 64 + l31;
+    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
+    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
 
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
         if (more) {
-            load_tile<ALIGNED>(Q, M, D, m0, (kt + 1) * BK, ra);
-            load_tile<ALIGNED>(G, N, D, n0, (kt + 1) * BK, rb);
+            load_tile<ALIGNED, BM>(Q, M, D, m0, (kt + 1) * BK, ra);
+            load_tile<ALIGNED, BN>(G, N, D, n0, (kt + 1) * BK, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const float a0 = a_base[(2 * kk) * LDT];
-            const float a1 = a_base[(2 * kk) * LDT + 32];
-            const float b0 = b_base[(2 * kk) * LDT];
-            const float b1 = b_base[(2 * kk) * LDT + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = a_base[(2 * kk) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = b_base[(2 * kk) * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
         if (more) {
-            store_tile(As, ra);
-            store_tile(Bs, rb);
+            store_tile<BM>(As, ra);
+            store_tile<BN>(Bs, rb);
             __syncthreads();
         }
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t n = n0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < TN; ++j) {
+            const int64_t n = n0 + wn * (32 * TN) + j * 32 + l31;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                const int64_t m = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                 if (m < M && n < N) C[m * ldc + n] = acc[i][j][e];
             }
         }
     }
 }
 
+// ---- tile-shape selection ------------------------------------------------------------------
+// Candidate block tiles with their measured steady-state efficiency (fraction of the fp32-MFMA
+// peak on a large problem) and resident workgroups per CU.  The launcher picks the shape with the
+// smallest estimated time  rounds(T tiles over S slots) * tile_work / efficiency  -- large
+// problems get 128x128, mid-size ones (bench: 512 x 10k) avoid a half-empty last round.
+struct TileCfg { int tm, tn, wg_per_cu; float eff; };
+static const TileCfg kCfgs[] = { {2, 2, 2, 0.83f}, {1, 2, 4, 0.79f}, {2, 1, 4, 0.805f}, {1, 1, 6, 0.72f} };
+static int g_force_cfg = -1;            // debug / A-B hook
+void set_gemm_cfg(int c) { g_force_cfg = c; }
+
+template <int TM, int TN>
+static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
+                       hipStream_t st) {
+    TileMap tm;
+    tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
+    tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
+    const dim3 grid((unsigned)(tm.tiles_m * tm.tiles_n)), block(256);
+    if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm);
+    else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm);
+}
+
 int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
                        hipStream_t st) {
     if (M == 0 || N == 0) return ISX_OK;
-    TileMap tm;
-    const int64_t tmm = (M + BM - 1) / BM, tnn = (N + BN - 1) / BN;
-    if (tmm * tnn >= (1ll << 31)) { isx_set_error("cosine gemm: %lld x %lld tiles exceed the grid limit", (long long)tmm, (long long)tnn); return ISX_ERR_ARG; }
-    tm.tiles_m = (int)tmm;
-    tm.tiles_n = (int)tnn;
+    if (((M + 63) / 64) * ((N + 63) / 64) >= (1ll << 31)) { isx_set_error("cosine gemm: too many tiles for one grid"); return ISX_ERR_ARG; }
     const bool aligned = (D % 4 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);
-    const dim3 grid((unsigned)(tmm * tnn)), block(256);
-    if (aligned) hipLaunchKernelGGL(cosine_gemm_kernel<true>, grid, block, 0, st, Q, M, G, N, D, C, ldc, tm);
-    else hipLaunchKernelGGL(cosine_gemm_kernel<false>, grid, block, 0, st, Q, M, G, N, D, C, ldc, tm);
+    int best = 0;
+    double best_t = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        const TileCfg& k = kCfgs[c];
+        const double tiles = (double)((M + 64 * k.tm - 1) / (64 * k.tm)) * (double)((N + 64 * k.tn - 1) / (64 * k.tn));
+        const double slots = 256.0 * k.wg_per_cu;
+        // time in units of "one full round" = wg_per_cu tiles per CU.  128x128 tiles run in lock-step
+        // rounds (the last, partial one costs a whole round); the smaller shapes keep 4-6 workgroups
+        // per CU, finish unevenly and only pay a fraction of a round as tail (fitted on MI355X)
+        double rounds = tiles / slots;
+        if (c == 0) rounds = (double)(long long)(rounds + 0.999999);
+        else rounds += (c == 3 ? 0.15 : 0.25);
+        const double t = rounds * k.wg_per_cu * (k.tm * k.tn) / k.eff;
+        if (t < best_t) { best_t = t; best = c; }
+    }
+    if (g_force_cfg >= 0 && g_force_cfg < 4) best = g_force_cfg;
+    switch (best) {
+        case 0: launch_cfg<2, 2>(aligned, Q, M, G, N, D, C, ldc, st); break;
+        case 1: launch_cfg<1, 2>(aligned, Q, M, G, N, D, C, ldc, st); break;
+        case 2: launch_cfg<2, 1>(aligned, Q, M, G, N, D, C, ldc, st); break;
+        default: launch_cfg<1, 1>(aligned, Q, M, G, N, D, C, ldc, st); break;
+    }
     ISX_CHECK_LAUNCH("cosine_gemm");
     return ISX_OK;
 }
@@ -176,6 +216,9 @@ int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int
 }  // namespace isx
 
 using namespace isx;
+
+// Debug / A-B hook (not declared in include/isx.h): force a tile shape (0..3), -1 = automatic.
+ISX_API void isx_debug_set_gemm_cfg(int c) { set_gemm_cfg(c); }
 
 ISX_API int isx_cosine_sim(const float* Q, int64_t M, const float* G, int64_t N, int D, float* sim, isx_stream_t stream) {
     ISX_REQUIRE(M >= 0 && N >= 0 && D > 0, "isx_cosine_sim: bad shape M=%lld N=%lld D=%d", (long long)M, (long long)N, D);
