@@ -57,6 +57,11 @@ int isx_l2norm_shift_rows(const float* x, const float* shift, int64_t B, int64_t
  * the whole HxW map, flatten, L2.  fmap: (B,C,H,W) NCHW; y: (B,C). */
 int isx_gap_l2(const float* fmap, int64_t B, int C, int H, int W, float eps, float* y, isx_stream_t stream);
 
+/* Same operation on a channels-last feature map: fmap is (B,H,W,C) in memory (torch
+ * memory_format=channels_last of a logical (B,C,H,W) tensor), which is what the NHWC convolution
+ * kernels of the backbone produce.  Same summation order, same result.  y: (B,C). */
+int isx_gap_l2_nhwc(const float* fmap, int64_t B, int C, int H, int W, float eps, float* y, isx_stream_t stream);
+
 /* model/siamese.py:67-71 nn.AvgPool2d(feature_size2d, stride=1) of TuneClassifSub /
  * RegionDescriptorNet.  fmap: (B,C,H,W); out: (B,C,H-kh+1,W-kw+1). */
 int isx_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out,

@@ -98,7 +98,6 @@ __global__ __launch_bounds__(RK_THREADS) void average_precision_kernel(const int
                                                                        double* __restrict__ ap_out) {
     __shared__ double terms[AP_CHUNK];
     __shared__ int wsum[RK_THREADS / 64];
-    __shared__ int chunk_hits_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t row = blockIdx.x;
     const int32_t q = qlab[row];

@@ -50,11 +50,21 @@ def l2norm_shift_rows(x, shift=None, eps=EPS):
 
 
 def gap_l2(fmap, eps=EPS, out=None):
-    fmap = _f32(fmap, "fmap")
+    """Global average pool + L2 of a logical (B,C,H,W) feature map.  A channels-last tensor (the
+    layout NHWC convolutions produce) is consumed in place by the NHWC kernel -- no transpose."""
+    if not (isinstance(fmap, torch.Tensor) and fmap.is_cuda):
+        raise _lib.IsxError("fmap must be a CUDA tensor (libisx has no CPU path)")
+    if fmap.dtype != torch.float32:
+        raise _lib.IsxError("fmap must be float32, got %s" % (fmap.dtype,))
     B, Cc, H, W = fmap.shape
     y = torch.empty((B, Cc), device=fmap.device, dtype=torch.float32) if out is None else out
     assert y.is_contiguous() and y.shape == (B, Cc)
-    check(lib().isx_gap_l2(fmap.data_ptr(), B, Cc, H, W, eps, y.data_ptr(), _stream()), "isx_gap_l2")
+    nhwc = (H * W > 1 and Cc > 1) and not fmap.is_contiguous() and fmap.is_contiguous(memory_format=torch.channels_last)
+    if nhwc:
+        check(lib().isx_gap_l2_nhwc(fmap.data_ptr(), B, Cc, H, W, eps, y.data_ptr(), _stream()), "isx_gap_l2_nhwc")
+    else:
+        fmap = fmap.contiguous()
+        check(lib().isx_gap_l2(fmap.data_ptr(), B, Cc, H, W, eps, y.data_ptr(), _stream()), "isx_gap_l2")
     return y
 
 

@@ -56,7 +56,7 @@ def get_embeddings(net, dataset, device, out_size):
                 fmap = net.features(x)
                 if _full_map_pool(net, fmap):
                     from isx import ops
-                    ops.gap_l2(fmap.float(), out=rows)
+                    ops.gap_l2(fmap.float(), out=rows)        # NCHW or channels-last, consumed in place
                     return slab
                 out = net.feature_reduc(fmap)
                 out = out.view(out.size(0), -1)

@@ -55,6 +55,17 @@ def test_gap_l2(ops, B, C, H, W):
     np.testing.assert_allclose(y, O.gap_l2(f), **TOL)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(3, 16, 4, 4), (4, 2048, 7, 7), (2, 256, 6, 6), (2, 4096, 3, 3), (3, 30, 5, 3), (2, 8200, 2, 2), (1, 2048, 14, 14)])
+def test_gap_l2_channels_last(ops, B, C, H, W):
+    rng = np.random.default_rng(C * 7 + H)
+    f = np.maximum(rng.standard_normal((B, C, H, W), dtype=np.float32), 0)
+    x = dev(f).to(memory_format=torch.channels_last)
+    assert not x.is_contiguous()
+    y = host(ops.gap_l2(x))
+    np.testing.assert_allclose(y, O.gap_l2(f), **TOL)
+    np.testing.assert_allclose(y, host(ops.gap_l2(dev(f))), **TOL)      # NHWC and NCHW kernels agree (same pooled values)
+
+
 def test_gap_l2_golden(ops, golden):
     g = golden("gap_l2.npz")
     np.testing.assert_allclose(host(ops.gap_l2(dev(g["fmap"]))), g["desc"], **TOL)
