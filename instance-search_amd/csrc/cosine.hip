@@ -84,10 +84,12 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 }
 
 // Block tile (64*TM) x (64*TN): 4 waves as 2x2, each wave TM x TN MFMA tiles of 32x32.
-template <bool ALIGNED, int TM, int TN>
+template <bool ALIGNED, int TM, int TN, bool FILTER>
 __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
                                                           const float* __restrict__ G, int64_t N, int D,
-                                                          float* __restrict__ C, int64_t ldc, TileMap tm) {
+                                                          float* __restrict__ C, int64_t ldc, TileMap tm,
+                                                          const float* __restrict__ thr, float* __restrict__ gmax,
+                                                          int ngrp) {
     constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 1, LDB = BN + 1;
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
@@ -151,11 +153,25 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int64_t n = n0 + wn * (32 * TN) + j * 32 + l31;
+            const int64_t ng = n0 + wn * (32 * TN) + j * 32;        // first column of this 32-column group
+            const int64_t n = ng + l31;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t m = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                if (m < M && n < N) C[m * ldc + n] = acc[i][j][e];
+                const float v = acc[i][j][e];
+                if (FILTER) {
+                    // fused top-k filter: a 32-column group of row m is stored only if its best score can
+                    // still enter the row's top-k; the group maximum always goes to gmax
+                    float rmax = (n < N) ? v : -INFINITY;
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o, 64));   // stays inside the 32-lane half
+                    if (m < M && ng < N) {
+                        if (l31 == 0) gmax[m * ngrp + (ng >> 5)] = rmax;
+                        if (rmax >= thr[m] && n < N) C[m * ldc + n] = v;
+                    }
+                } else {
+                    if (m < M && n < N) C[m * ldc + n] = v;
+                }
             }
         }
     }
@@ -173,17 +189,23 @@ void set_gemm_cfg(int c) { g_force_cfg = c; }
 
 template <int TM, int TN>
 static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                       hipStream_t st) {
+                       const float* thr, float* gmax, hipStream_t st) {
     TileMap tm;
     tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
     tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
+    const int ngrp = (int)((N + 31) / 32);
     const dim3 grid((unsigned)(tm.tiles_m * tm.tiles_n)), block(256);
-    if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm);
-    else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm);
+    if (gmax) {
+        if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
+        else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
+    } else {
+        if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
+        else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
+    }
 }
 
-int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                       hipStream_t st) {
+static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
+                           const float* thr, float* gmax, hipStream_t st) {
     if (M == 0 || N == 0) return ISX_OK;
     if (((M + 63) / 64) * ((N + 63) / 64) >= (1ll << 31)) { isx_set_error("cosine gemm: too many tiles for one grid"); return ISX_ERR_ARG; }
     const bool aligned = (D % 4 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);
@@ -204,13 +226,22 @@ int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int
     }
     if (g_force_cfg >= 0 && g_force_cfg < 4) best = g_force_cfg;
     switch (best) {
-        case 0: launch_cfg<2, 2>(aligned, Q, M, G, N, D, C, ldc, st); break;
-        case 1: launch_cfg<1, 2>(aligned, Q, M, G, N, D, C, ldc, st); break;
-        case 2: launch_cfg<2, 1>(aligned, Q, M, G, N, D, C, ldc, st); break;
-        default: launch_cfg<1, 1>(aligned, Q, M, G, N, D, C, ldc, st); break;
+        case 0: launch_cfg<2, 2>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
+        case 1: launch_cfg<1, 2>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
+        case 2: launch_cfg<2, 1>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
+        default: launch_cfg<1, 1>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
     }
     ISX_CHECK_LAUNCH("cosine_gemm");
     return ISX_OK;
+}
+
+int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc, hipStream_t st) {
+    return launch_gemm_any(Q, M, G, N, D, C, ldc, nullptr, nullptr, st);
+}
+
+int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
+                              const float* thr, float* gmax, hipStream_t st) {
+    return launch_gemm_any(Q, M, G, N, D, C, ldc, thr, gmax, st);
 }
 
 }  // namespace isx
@@ -226,14 +257,22 @@ ISX_API int isx_cosine_sim(const float* Q, int64_t M, const float* G, int64_t N,
     return launch_cosine_gemm(Q, M, G, N, D, sim, N, (hipStream_t)stream);
 }
 
-// Workspace layout of isx_cosine_topk: [ carry keys: M*k u64 | score chunk: M*Nc f32 ].
-static size_t topk_carry_bytes(int64_t M, int k) { return (((size_t)M * k * 8) + 255) & ~(size_t)255; }
+// Workspace layout of isx_cosine_topk:
+//   [ carry keys: M*k u64 | thr: M f32 | gmax: M*ceil(Nc/32) f32 | score chunk: M*Nc f32 ]
+// The first column chunk (<= kFirstChunk columns) is materialised and selected in full; it leaves a
+// per-row lower bound thr of the final k-th score.  Every later chunk runs the FILTERING GEMM: only
+// 32-column groups whose best score reaches thr are stored and read back, so for typical data the
+// M x N matrix is never written -- just one float per 32 scores.  Exact for any data: in the worst
+// case (every group qualifies) the chunk is simply materialised in full, as in round 0.
+constexpr int64_t kFirstChunk = 8192;
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t topk_fixed_bytes(int64_t M, int k) { return align256((size_t)M * k * 8) + align256((size_t)M * 4); }
+static size_t topk_chunk_bytes(int64_t M, int64_t nc) { return align256((size_t)M * ((nc + 31) / 32) * 4) + (size_t)M * nc * 4; }
 
 ISX_API size_t isx_cosine_topk_workspace(int64_t M, int64_t N, int D, int k) {
     (void)D;
     if (M <= 0 || N <= 0 || k <= 0) return 256;
-    // recommended: whole matrix if it is <= 1 GiB, else column chunks of ~1 GiB
-    // (multiple of 2048 columns so that every chunk launch fills the chip evenly).
+    // recommended: whole matrix if it is <= 1 GiB, else column chunks of ~1 GiB (multiple of 2048 columns)
     const size_t budget = (size_t)1 << 30;
     int64_t nc = N;
     if ((size_t)M * N * 4 > budget) {
@@ -242,8 +281,8 @@ ISX_API size_t isx_cosine_topk_workspace(int64_t M, int64_t N, int D, int k) {
         if (nc < 2048) nc = 2048;
         if (nc > N) nc = N;
     }
-    return topk_carry_bytes(M, k) + (size_t)M * nc * 4;
-    // minimum accepted by isx_cosine_topk: carry + M * min(N, 128) * 4 bytes
+    return topk_fixed_bytes(M, k) + topk_chunk_bytes(M, nc);
+    // minimum accepted by isx_cosine_topk: the same formula with nc = min(N, 128)
 }
 
 ISX_API int isx_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N, int D, int k, int64_t idx_base,
@@ -255,25 +294,41 @@ ISX_API int isx_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N
     ISX_REQUIRE(Q && top_score && top_idx && (G || N == 0), "isx_cosine_topk: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) return launch_select(nullptr, M, 0, 0, 0, k, nullptr, true, true, idx_base, top_score, top_idx, st);
-    const size_t carry_b = topk_carry_bytes(M, k);
+    const size_t fixed_b = topk_fixed_bytes(M, k);
     const int64_t min_nc = N < 128 ? N : 128;
-    if (!ws || ((uintptr_t)ws % 256) != 0 || ws_bytes < carry_b + (size_t)M * min_nc * 4) {
+    if (!ws || ((uintptr_t)ws % 256) != 0 || ws_bytes < fixed_b + topk_chunk_bytes(M, min_nc)) {
         isx_set_error("isx_cosine_topk: workspace of %zu bytes too small or misaligned (need >= %zu, 256-B aligned)", ws_bytes,
-                      carry_b + (size_t)M * min_nc * 4);
+                      fixed_b + topk_chunk_bytes(M, min_nc));
         return ISX_ERR_WORKSPACE;
     }
+    // largest chunk width (multiple of 128 unless it covers N) whose gmax + scores fit
+    int64_t nc = (int64_t)((ws_bytes - fixed_b) / ((size_t)M * 4));
+    if (nc > N) nc = N;
+    while (nc > min_nc && topk_chunk_bytes(M, nc) > ws_bytes - fixed_b) nc -= (nc > 4096 ? 1024 : 128);
+    if (nc < N) nc = nc >= 128 ? nc / 128 * 128 : nc;
     uint64_t* carry = (uint64_t*)ws;
-    float* chunk = (float*)((char*)ws + carry_b);
-    int64_t nc = (int64_t)((ws_bytes - carry_b) / ((size_t)M * 4));
-    if (nc >= N) nc = N;
-    else nc = nc >= 128 ? nc / 128 * 128 : nc;            // whole tiles per chunk
-    for (int64_t c0 = 0; c0 < N; c0 += nc) {
-        const int64_t w = (N - c0 < nc) ? N - c0 : nc;
-        int rc = launch_cosine_gemm(Q, M, G + c0 * D, w, D, chunk, w, st);
+    float* thr = (float*)((char*)ws + align256((size_t)M * k * 8));
+    float* gmax = (float*)((char*)ws + fixed_b);
+    float* chunk = (float*)((char*)gmax + align256((size_t)M * ((nc + 31) / 32) * 4));
+    const bool filter = (k <= kGroupSelectMaxK);
+    int64_t c0 = 0;
+    while (c0 < N) {
+        const bool first = (c0 == 0);
+        int64_t w = N - c0 < nc ? N - c0 : nc;
+        if (first && filter && w > kFirstChunk && N > kFirstChunk) w = kFirstChunk;   // short bootstrap chunk
+        const bool last = (c0 + w >= N);
+        int rc;
+        if (first || !filter) {
+            rc = launch_cosine_gemm(Q, M, G + c0 * D, w, D, chunk, w, st);
+            if (rc) return rc;
+            rc = launch_select(chunk, M, w, w, c0, k, carry, first, last, idx_base, top_score, top_idx, st, thr);
+        } else {
+            rc = launch_cosine_gemm_filter(Q, M, G + c0 * D, w, D, chunk, w, thr, gmax, st);
+            if (rc) return rc;
+            rc = launch_select_groups(chunk, gmax, M, w, w, c0, k, carry, thr, last, idx_base, top_score, top_idx, st);
+        }
         if (rc) return rc;
-        const bool first = (c0 == 0), last = (c0 + w >= N);
-        rc = launch_select(chunk, M, w, w, c0, k, carry, first, last, idx_base, top_score, top_idx, st);
-        if (rc) return rc;
+        c0 += w;
     }
     return ISX_OK;
 }

@@ -8,12 +8,28 @@ namespace isx {
 int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
                        hipStream_t st);
 
+// Same GEMM with the filtering epilogue: for every row and every group of 32 columns the maximum
+// score is written to gmax (M, ngrp = ceil(N/32)); the scores of a group are stored to C only when
+// that maximum reaches thr[row] (a lower bound of the row's final k-th best score).
+int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
+                              const float* thr, float* gmax, hipStream_t st);
+
 // Per-row running top-k over a score chunk.  sim: (M, Nc) with row stride ld; column j
 // of the chunk is gallery row col_base + j.  carry: (M, k) u64 keys (canonical order,
 // 0 = empty); read unless `first`, written unless `emit`.  With `emit` the final
 // (score, idx_base + index) lists are written instead.
 int launch_select(const float* sim, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k, uint64_t* carry,
-                  bool first, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx, hipStream_t st);
+                  bool first, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx, hipStream_t st,
+                  float* thr_out = nullptr);
+
+// Running top-k update from a FILTERED chunk: only the 32-column groups whose maximum (gmax) reaches
+// the row's current k-th score are read from sim.  k <= kGroupSelectMaxK.  Updates carry and thr
+// (thr[row] = score of the k-th key, -inf while fewer than k).
+int launch_select_groups(const float* sim, const float* gmax, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
+                         uint64_t* carry, float* thr, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx,
+                         hipStream_t st);
+
+constexpr int kGroupSelectMaxK = 256;
 
 constexpr int kSelectMaxK = 1024;
 

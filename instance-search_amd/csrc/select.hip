@@ -32,7 +32,8 @@ template <bool VEC>
 __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __restrict__ sim, int64_t Nc, int64_t ld,
                                                              uint32_t col_base, int k, uint64_t* __restrict__ carry,
                                                              int first, int emit, int64_t idx_base,
-                                                             float* __restrict__ top_score, int64_t* __restrict__ top_idx) {
+                                                             float* __restrict__ top_score, int64_t* __restrict__ top_idx,
+                                                             float* __restrict__ thr_out) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[SEL_CAP];
     __shared__ int cnt_s, dirty_s;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -100,17 +101,105 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
     } else {
         for (int i = tid; i < k; i += SEL_THREADS) carry[row * k + i] = buf[i];
     }
+    if (thr_out && tid == 0) thr_out[row] = buf[k - 1] ? key_score(buf[k - 1]) : -INFINITY;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Running top-k update from a chunk produced by the FILTERING GEMM epilogue (cosine.hip): one wave
+// (64-thread workgroup) per query row.  gmax holds, per 32-column group, the best score of the
+// group; only groups with gmax >= (current k-th score) can change the list, and those are exactly
+// the groups whose scores the GEMM stored.  The wave scans the gmax row 64 groups at a time, then
+// reads two qualifying 128-B segments per step (one per half-wave).  Candidates beating the k-th
+// key go to a 512-key LDS buffer that is bitonic-sorted and cut to k when it fills.
+constexpr int GS_CAP = 512;
+
+__global__ __launch_bounds__(64) void select_groups_kernel(const float* __restrict__ sim, const float* __restrict__ gmax,
+                                                           int64_t Nc, int64_t ld, int ngrp, uint32_t col_base, int k,
+                                                           uint64_t* __restrict__ carry, float* __restrict__ thr, int emit,
+                                                           int64_t idx_base, float* __restrict__ top_score,
+                                                           int64_t* __restrict__ top_idx) {
+    __shared__ __attribute__((aligned(16))) uint64_t buf[GS_CAP];
+    const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+    const int64_t row = blockIdx.x;
+    const float* r = sim + row * ld;
+    const float* gm = gmax + row * ngrp;
+    for (int i = lane; i < GS_CAP; i += 64) buf[i] = (i < k) ? carry[row * k + i] : 0ull;
+    __syncthreads();
+    uint64_t thr_key = buf[k - 1];
+    float thr_f = thr_key ? key_score(thr_key) : -INFINITY;
+    int cnt = k;                                   // uniform
+    bool dirty = false;
+
+    for (int g0 = 0; g0 < ngrp; g0 += 64) {
+        const int g = g0 + lane;
+        const bool q = (g < ngrp) && (gm[g] >= thr_f);
+        unsigned long long mask = __ballot(q);
+        while (mask) {
+            // two qualifying groups per step: lower half-wave takes the first, upper half the second
+            const int ga = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            int gb = -1;
+            if (mask) { gb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+            const int gsel = half ? gb : ga;
+            const int64_t col = (int64_t)(g0 + gsel) * 32 + l31;
+            const bool in = (gsel >= 0) && (col < Nc);
+            uint64_t key = 0;
+            if (in) key = rank_key(r[col], col_base + (uint32_t)col);
+            const bool take = in && key > thr_key;
+            const unsigned long long tm = __ballot(take);
+            if (tm) {
+                const int pos = cnt + __popcll(tm & ((1ull << lane) - 1ull));
+                if (take) buf[pos] = key;
+                cnt += __popcll(tm);
+                dirty = true;
+                if (cnt > GS_CAP - 64) {           // the next step could add up to 64 more
+                    __syncthreads();
+                    bitonic_sort_desc<64>(buf, GS_CAP);
+                    for (int i = k + lane; i < GS_CAP; i += 64) buf[i] = 0ull;
+                    __syncthreads();
+                    cnt = k;
+                    thr_key = buf[k - 1];
+                    thr_f = thr_key ? key_score(thr_key) : -INFINITY;
+                    dirty = false;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (dirty) bitonic_sort_desc<64>(buf, GS_CAP);
+    if (emit) {
+        for (int i = lane; i < k; i += 64) {
+            const uint64_t kk = buf[i];
+            top_score[row * k + i] = kk ? key_score(kk) : -INFINITY;
+            top_idx[row * k + i] = kk ? (idx_base + (int64_t)key_idx(kk)) : -1;
+        }
+    } else {
+        for (int i = lane; i < k; i += 64) carry[row * k + i] = buf[i];
+        if (lane == 0) thr[row] = buf[k - 1] ? key_score(buf[k - 1]) : -INFINITY;
+    }
+}
+
+int launch_select_groups(const float* sim, const float* gmax, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
+                         uint64_t* carry, float* thr, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx,
+                         hipStream_t st) {
+    if (M == 0) return ISX_OK;
+    if (M >= (1ll << 31) || k > kGroupSelectMaxK) { isx_set_error("select_groups: unsupported M=%lld k=%d", (long long)M, k); return ISX_ERR_ARG; }
+    const int ngrp = (int)((Nc + 31) / 32);
+    hipLaunchKernelGGL(select_groups_kernel, dim3((unsigned)M), dim3(64), 0, st, sim, gmax, Nc, ld, ngrp, (uint32_t)col_base, k, carry, thr,
+                       emit ? 1 : 0, idx_base, top_score, top_idx);
+    ISX_CHECK_LAUNCH("select_groups");
+    return ISX_OK;
 }
 
 int launch_select(const float* sim, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k, uint64_t* carry,
-                  bool first, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx, hipStream_t st) {
+                  bool first, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx, hipStream_t st, float* thr_out) {
     if (M == 0) return ISX_OK;
     if (M >= (1ll << 31)) { isx_set_error("select: too many rows"); return ISX_ERR_ARG; }
     const bool vec = sim && ((uintptr_t)sim % 16 == 0) && (ld % 4 == 0);
     if (vec) hipLaunchKernelGGL(select_kernel<true>, dim3((unsigned)M), dim3(SEL_THREADS), 0, st, sim, Nc, ld, (uint32_t)col_base, k,
-                                carry, first ? 1 : 0, emit ? 1 : 0, idx_base, top_score, top_idx);
+                                carry, first ? 1 : 0, emit ? 1 : 0, idx_base, top_score, top_idx, thr_out);
     else hipLaunchKernelGGL(select_kernel<false>, dim3((unsigned)M), dim3(SEL_THREADS), 0, st, sim, Nc, ld, (uint32_t)col_base, k,
-                            carry, first ? 1 : 0, emit ? 1 : 0, idx_base, top_score, top_idx);
+                            carry, first ? 1 : 0, emit ? 1 : 0, idx_base, top_score, top_idx, thr_out);
     ISX_CHECK_LAUNCH("select");
     return ISX_OK;
 }

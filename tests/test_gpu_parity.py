@@ -194,10 +194,36 @@ def test_cosine_topk(ops, M, N, D, k):
     np.testing.assert_array_equal(host(ti), oi)
     np.testing.assert_array_equal(host(ts), os_)
     # a tiny workspace forces many column chunks + carry merging: same answer
-    small = torch.empty((((M * k * 8 + 255) // 256) * 256 + M * 256 * 4,), dtype=torch.uint8, device="cuda")
+    a256 = lambda v: (v + 255) // 256 * 256
+    small = torch.empty((a256(M * k * 8) + a256(M * 4) + a256(M * 8 * 4) + M * 256 * 4,), dtype=torch.uint8, device="cuda")
     ts2, ti2 = ops.cosine_topk(dev(Q), dev(G), k, idx_base=11, ws=small)
     np.testing.assert_array_equal(host(ti2), oi)
     np.testing.assert_array_equal(host(ts2), os_)
+
+
+@pytest.mark.parametrize("k", [1, 100, 256, 300])
+@pytest.mark.parametrize("order", ["random", "ascending", "descending"])
+def test_cosine_topk_filtered_chunks(ops, k, order):
+    """N > 8192 columns: bootstrap chunk + FILTERING GEMM chunks (k <= 256) or the materialised path
+    (k = 300).  'ascending' is the adversarial order: every later column beats the running threshold
+    of query 0, so every 32-column group qualifies and the filter degenerates to full materialisation."""
+    rng = np.random.default_rng(k)
+    M, N, D = 37, 21000, 48
+    Q, G = unit(rng, M, D), unit(rng, N, D)
+    if order != "random":
+        s0 = G @ Q[0]
+        G = G[np.argsort(s0 if order == "ascending" else -s0)]
+    G[9000] = G[17]; G[20999] = G[17]; G[8191] = G[8192]          # ties across chunk boundaries
+    want_s, want_i = O.cosine_topk(Q, G, k, idx_base=3)
+    ts, ti = ops.cosine_topk(dev(Q), dev(G), k, idx_base=3)
+    np.testing.assert_array_equal(host(ti), want_i)
+    np.testing.assert_array_equal(host(ts), want_s)
+    a256 = lambda v: (v + 255) // 256 * 256
+    for nc in (4096, 1000):                                           # several filtered chunks / odd chunk width
+        ws = torch.empty((a256(M * k * 8) + a256(M * 4) + a256(M * ((nc + 31) // 32) * 4) + M * nc * 4,), dtype=torch.uint8, device="cuda")
+        ts, ti = ops.cosine_topk(dev(Q), dev(G), k, idx_base=3, ws=ws)
+        np.testing.assert_array_equal(host(ti), want_i)
+        np.testing.assert_array_equal(host(ts), want_s)
 
 
 def test_topk_rows_adversarial(ops):
