@@ -88,7 +88,7 @@ template <bool ALIGNED, int TM, int TN, bool FILTER>
 __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
                                                           const float* __restrict__ G, int64_t N, int D,
                                                           float* __restrict__ C, int64_t ldc, TileMap tm,
-                                                          const float* __restrict__ thr, float* __restrict__ gmax,
+                                                          const float* __restrict__ thr, uint8_t* __restrict__ gflag,
                                                           int ngrp) {
     constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 1, LDB = BN + 1;
     __shared__ float lds[BK * (LDA + LDB)];
@@ -160,14 +160,17 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
                 const int64_t m = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                 const float v = acc[i][j][e];
                 if (FILTER) {
-                    // fused top-k filter: a 32-column group of row m is stored only if its best score can
-                    // still enter the row's top-k; the group maximum always goes to gmax
-                    float rmax = (n < N) ? v : -INFINITY;
-#pragma unroll
-                    for (int o = 16; o > 0; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o, 64));   // stays inside the 32-lane half
-                    if (m < M && ng < N) {
-                        if (l31 == 0) gmax[m * ngrp + (ng >> 5)] = rmax;
-                        if (rmax >= thr[m] && n < N) C[m * ldc + n] = v;
+                    // fused top-k filter: a 32-column group of row m is stored only if one of its scores
+                    // can still enter the row's top-k (score >= thr[m], a lower bound of the final k-th
+                    // score); one flag byte per (row, group) tells the select kernel which groups exist.
+                    // The test is a compare + wave ballot (no cross-lane data movement).
+                    const bool row_ok = (m < M);
+                    const float t = row_ok ? thr[m] : INFINITY;
+                    const unsigned long long qm = __ballot(n < N && v >= t);
+                    const bool q = ((half ? (qm >> 32) : qm) & 0xFFFFFFFFull) != 0ull;
+                    if (row_ok && ng < N) {
+                        if (l31 == 0) gflag[m * ngrp + (ng >> 5)] = q ? 1 : 0;
+                        if (q && n < N) C[m * ldc + n] = v;
                     }
                 } else {
                     if (m < M && n < N) C[m * ldc + n] = v;
@@ -189,7 +192,7 @@ void set_gemm_cfg(int c) { g_force_cfg = c; }
 
 template <int TM, int TN>
 static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                       const float* thr, float* gmax, hipStream_t st) {
+                       const float* thr, uint8_t* gmax, hipStream_t st) {
     TileMap tm;
     tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
     tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
@@ -205,7 +208,7 @@ static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, 
 }
 
 static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                           const float* thr, float* gmax, hipStream_t st) {
+                           const float* thr, uint8_t* gmax, hipStream_t st) {
     if (M == 0 || N == 0) return ISX_OK;
     if (((M + 63) / 64) * ((N + 63) / 64) >= (1ll << 31)) { isx_set_error("cosine gemm: too many tiles for one grid"); return ISX_ERR_ARG; }
     const bool aligned = (D % 4 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);
@@ -240,7 +243,7 @@ int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int
 }
 
 int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                              const float* thr, float* gmax, hipStream_t st) {
+                              const float* thr, uint8_t* gmax, hipStream_t st) {
     return launch_gemm_any(Q, M, G, N, D, C, ldc, thr, gmax, st);
 }
 
@@ -258,7 +261,7 @@ ISX_API int isx_cosine_sim(const float* Q, int64_t M, const float* G, int64_t N,
 }
 
 // Workspace layout of isx_cosine_topk:
-//   [ carry keys: M*k u64 | thr: M f32 | gmax: M*ceil(Nc/32) f32 | score chunk: M*Nc f32 ]
+//   [ carry keys: M*k u64 | thr: M f32 | group flags: M*ceil(Nc/32) u8 | score chunk: M*Nc f32 ]
 // The first column chunk (<= kFirstChunk columns) is materialised and selected in full; it leaves a
 // per-row lower bound thr of the final k-th score.  Every later chunk runs the FILTERING GEMM: only
 // 32-column groups whose best score reaches thr are stored and read back, so for typical data the
@@ -267,7 +270,7 @@ ISX_API int isx_cosine_sim(const float* Q, int64_t M, const float* G, int64_t N,
 constexpr int64_t kFirstChunk = 8192;
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static size_t topk_fixed_bytes(int64_t M, int k) { return align256((size_t)M * k * 8) + align256((size_t)M * 4); }
-static size_t topk_chunk_bytes(int64_t M, int64_t nc) { return align256((size_t)M * ((nc + 31) / 32) * 4) + (size_t)M * nc * 4; }
+static size_t topk_chunk_bytes(int64_t M, int64_t nc) { return align256((size_t)M * ((nc + 31) / 32)) + (size_t)M * nc * 4; }
 
 ISX_API size_t isx_cosine_topk_workspace(int64_t M, int64_t N, int D, int k) {
     (void)D;
@@ -306,10 +309,19 @@ ISX_API int isx_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N
     if (nc > N) nc = N;
     while (nc > min_nc && topk_chunk_bytes(M, nc) > ws_bytes - fixed_b) nc -= (nc > 4096 ? 1024 : 128);
     if (nc < N) nc = nc >= 128 ? nc / 128 * 128 : nc;
+    if (nc < N && nc >= 4096) {
+        // a chunk launch runs ceil(tiles / 512) lock-step rounds of 128x128 tiles: trim the width (by at
+        // most 16 tiles) so that the last round is >= 90 % full
+        const int64_t tm_ = (M + 127) / 128;
+        for (int64_t tn = nc / 128, tries = 0; tries < 16 && tn > 16; --tn, ++tries) {
+            const int64_t rem = (tm_ * tn) % 512;
+            if (rem == 0 || rem >= 460) { nc = tn * 128; break; }
+        }
+    }
     uint64_t* carry = (uint64_t*)ws;
     float* thr = (float*)((char*)ws + align256((size_t)M * k * 8));
-    float* gmax = (float*)((char*)ws + fixed_b);
-    float* chunk = (float*)((char*)gmax + align256((size_t)M * ((nc + 31) / 32) * 4));
+    uint8_t* gmax = (uint8_t*)((char*)ws + fixed_b);
+    float* chunk = (float*)((char*)gmax + align256((size_t)M * ((nc + 31) / 32)));
     const bool filter = (k <= kGroupSelectMaxK);
     int64_t c0 = 0;
     while (c0 < N) {

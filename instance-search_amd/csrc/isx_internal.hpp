@@ -8,11 +8,11 @@ namespace isx {
 int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
                        hipStream_t st);
 
-// Same GEMM with the filtering epilogue: for every row and every group of 32 columns the maximum
-// score is written to gmax (M, ngrp = ceil(N/32)); the scores of a group are stored to C only when
-// that maximum reaches thr[row] (a lower bound of the row's final k-th best score).
+// Same GEMM with the filtering epilogue: the scores of a (row, 32-column group) are stored to C only
+// when one of them reaches thr[row] (a lower bound of the row's final k-th best score); gflag
+// (M, ngrp = ceil(N/32)) bytes say which groups were stored.
 int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                              const float* thr, float* gmax, hipStream_t st);
+                              const float* thr, uint8_t* gflag, hipStream_t st);
 
 // Per-row running top-k over a score chunk.  sim: (M, Nc) with row stride ld; column j
 // of the chunk is gallery row col_base + j.  carry: (M, k) u64 keys (canonical order,
@@ -22,10 +22,9 @@ int launch_select(const float* sim, int64_t M, int64_t Nc, int64_t ld, int64_t c
                   bool first, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx, hipStream_t st,
                   float* thr_out = nullptr);
 
-// Running top-k update from a FILTERED chunk: only the 32-column groups whose maximum (gmax) reaches
-// the row's current k-th score are read from sim.  k <= kGroupSelectMaxK.  Updates carry and thr
+// Running top-k update from a FILTERED chunk: only the flagged 32-column groups are read from sim.  k <= kGroupSelectMaxK.  Updates carry and thr
 // (thr[row] = score of the k-th key, -inf while fewer than k).
-int launch_select_groups(const float* sim, const float* gmax, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
+int launch_select_groups(const float* sim, const uint8_t* gflag, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
                          uint64_t* carry, float* thr, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx,
                          hipStream_t st);
 

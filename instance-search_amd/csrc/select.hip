@@ -106,14 +106,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
 
 // ---------------------------------------------------------------------------------------------
 // Running top-k update from a chunk produced by the FILTERING GEMM epilogue (cosine.hip): one wave
-// (64-thread workgroup) per query row.  gmax holds, per 32-column group, the best score of the
-// group; only groups with gmax >= (current k-th score) can change the list, and those are exactly
-// the groups whose scores the GEMM stored.  The wave scans the gmax row 64 groups at a time, then
+// (64-thread workgroup) per query row.  gflag marks the 32-column groups the GEMM stored (those with
+// a score reaching the row's threshold); nothing else can change the list.  The wave scans the flag
+// row 64 groups at a time, then
 // reads two qualifying 128-B segments per step (one per half-wave).  Candidates beating the k-th
 // key go to a 512-key LDS buffer that is bitonic-sorted and cut to k when it fills.
 constexpr int GS_CAP = 512;
 
-__global__ __launch_bounds__(64) void select_groups_kernel(const float* __restrict__ sim, const float* __restrict__ gmax,
+__global__ __launch_bounds__(64) void select_groups_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gflag,
                                                            int64_t Nc, int64_t ld, int ngrp, uint32_t col_base, int k,
                                                            uint64_t* __restrict__ carry, float* __restrict__ thr, int emit,
                                                            int64_t idx_base, float* __restrict__ top_score,
@@ -122,17 +122,16 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int64_t row = blockIdx.x;
     const float* r = sim + row * ld;
-    const float* gm = gmax + row * ngrp;
+    const uint8_t* gf = gflag + row * (int64_t)ngrp;
     for (int i = lane; i < GS_CAP; i += 64) buf[i] = (i < k) ? carry[row * k + i] : 0ull;
     __syncthreads();
     uint64_t thr_key = buf[k - 1];
-    float thr_f = thr_key ? key_score(thr_key) : -INFINITY;
     int cnt = k;                                   // uniform
     bool dirty = false;
 
     for (int g0 = 0; g0 < ngrp; g0 += 64) {
         const int g = g0 + lane;
-        const bool q = (g < ngrp) && (gm[g] >= thr_f);
+        const bool q = (g < ngrp) && (gf[g] != 0);
         unsigned long long mask = __ballot(q);
         while (mask) {
             // two qualifying groups per step: lower half-wave takes the first, upper half the second
@@ -159,7 +158,6 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
                     __syncthreads();
                     cnt = k;
                     thr_key = buf[k - 1];
-                    thr_f = thr_key ? key_score(thr_key) : -INFINITY;
                     dirty = false;
                 }
             }
@@ -179,13 +177,13 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
     }
 }
 
-int launch_select_groups(const float* sim, const float* gmax, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
+int launch_select_groups(const float* sim, const uint8_t* gflag, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
                          uint64_t* carry, float* thr, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx,
                          hipStream_t st) {
     if (M == 0) return ISX_OK;
     if (M >= (1ll << 31) || k > kGroupSelectMaxK) { isx_set_error("select_groups: unsupported M=%lld k=%d", (long long)M, k); return ISX_ERR_ARG; }
     const int ngrp = (int)((Nc + 31) / 32);
-    hipLaunchKernelGGL(select_groups_kernel, dim3((unsigned)M), dim3(64), 0, st, sim, gmax, Nc, ld, ngrp, (uint32_t)col_base, k, carry, thr,
+    hipLaunchKernelGGL(select_groups_kernel, dim3((unsigned)M), dim3(64), 0, st, sim, gflag, Nc, ld, ngrp, (uint32_t)col_base, k, carry, thr,
                        emit ? 1 : 0, idx_base, top_score, top_idx);
     ISX_CHECK_LAUNCH("select_groups");
     return ISX_OK;

@@ -220,7 +220,7 @@ def test_cosine_topk_filtered_chunks(ops, k, order):
     np.testing.assert_array_equal(host(ts), want_s)
     a256 = lambda v: (v + 255) // 256 * 256
     for nc in (4096, 1000):                                           # several filtered chunks / odd chunk width
-        ws = torch.empty((a256(M * k * 8) + a256(M * 4) + a256(M * ((nc + 31) // 32) * 4) + M * nc * 4,), dtype=torch.uint8, device="cuda")
+        ws = torch.empty((a256(M * k * 8) + a256(M * 4) + a256(M * ((nc + 31) // 32)) + M * nc * 4,), dtype=torch.uint8, device="cuda")
         ts, ti = ops.cosine_topk(dev(Q), dev(G), k, idx_base=3, ws=ws)
         np.testing.assert_array_equal(host(ti), want_i)
         np.testing.assert_array_equal(host(ts), want_s)
