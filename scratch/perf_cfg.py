@@ -16,13 +16,13 @@ def timeit(f, n=5, w=2):
 D = 2048
 Qs = ops.l2norm_rows(torch.randn(130, 464, device="cuda")); Gs = ops.l2norm_rows(torch.randn(257, 464, device="cuda"))
 want = O.cosine_sim(Qs.cpu().numpy(), Gs.cpu().numpy())
-for c in range(6):
+for c in range(4):
     lib.isx_debug_set_gemm_cfg(c)
     print("cfg", c, "bit-exact:", np.array_equal(ops.cosine_sim(Qs, Gs).cpu().numpy(), want))
-for (M, N) in [(1000, 100000), (10000, 32768)]:
+for (M, N) in [(512, 10000), (2048, 10000), (10000, 32768)]:
     Q = torch.randn(M, D, device="cuda"); G = torch.randn(N, D, device="cuda"); out = torch.empty(M, N, device="cuda")
     res = []
-    for c in (0, 4, 5, -1):
+    for c in (0, 1, 2, 3, -1):
         lib.isx_debug_set_gemm_cfg(c)
         ms = timeit(lambda: ops.cosine_sim(Q, G, out=out))
         res.append("%s %.3fms %.1fTF" % ("auto" if c < 0 else "c%d" % c, ms, 2*M*N*D/ms/1e9))
