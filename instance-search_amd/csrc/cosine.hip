@@ -327,7 +327,7 @@ ISX_API int isx_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N
     while (c0 < N) {
         const bool first = (c0 == 0);
         int64_t w = N - c0 < nc ? N - c0 : nc;
-        if (first && filter && w > kFirstChunk && N > kFirstChunk) w = kFirstChunk;   // short bootstrap chunk
+        if (first && filter && w > kFirstChunk && N >= 4 * kFirstChunk) w = kFirstChunk;   // short bootstrap chunk
         const bool last = (c0 + w >= N);
         int rc;
         if (!filter) {

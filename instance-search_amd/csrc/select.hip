@@ -122,8 +122,8 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int64_t row = blockIdx.x;
     const float* r = sim + row * ld;
-    const uint8_t* gf = gflag + row * (int64_t)ngrp;
-    for (int i = lane; i < GS_CAP; i += 64) buf[i] = (i < k) ? carry[row * k + i] : 0ull;
+    const uint8_t* gf = gflag ? gflag + row * (int64_t)ngrp : nullptr;     // null = every group present
+    for (int i = lane; i < GS_CAP; i += 64) buf[i] = (carry && i < k) ? carry[row * k + i] : 0ull;   // null carry = empty list
     __syncthreads();
     uint64_t thr_key = buf[k - 1];
     int cnt = k;                                   // uniform
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
 
     for (int g0 = 0; g0 < ngrp; g0 += 64) {
         const int g = g0 + lane;
-        const bool q = (g < ngrp) && (gf[g] != 0);
+        const bool q = (g < ngrp) && (!gf || gf[g] != 0);
         unsigned long long mask = __ballot(q);
         while (mask) {
             // two qualifying groups per step: lower half-wave takes the first, upper half the second
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
         }
     } else {
         for (int i = lane; i < k; i += 64) carry[row * k + i] = buf[i];
-        if (lane == 0) thr[row] = buf[k - 1] ? key_score(buf[k - 1]) : -INFINITY;
+        if (lane == 0 && thr) thr[row] = buf[k - 1] ? key_score(buf[k - 1]) : -INFINITY;
     }
 }
 
@@ -238,6 +238,8 @@ ISX_API int isx_topk_rows(const float* sim, int64_t M, int64_t N, int k, int64_t
     ISX_REQUIRE(k >= 1 && k <= kSelectMaxK, "isx_topk_rows: k=%d outside [1,%d]", k, kSelectMaxK);
     ISX_REQUIRE(idx_base >= 0 && idx_base + N <= 0xFFFFFFFFll, "isx_topk_rows: gallery indices must stay below 2^32");
     ISX_REQUIRE((top_score && top_idx && (sim || N == 0)) || M == 0, "isx_topk_rows: null pointer");
+    if (k <= kGroupSelectMaxK && M > 0)     // wave-per-row kernel: all groups present, empty carry
+        return launch_select_groups(sim, nullptr, M, N, N, 0, k, nullptr, nullptr, true, idx_base, top_score, top_idx, (hipStream_t)stream);
     return launch_select(sim, M, N, N, 0, k, nullptr, true, true, idx_base, top_score, top_idx, (hipStream_t)stream);
 }
 

@@ -208,12 +208,12 @@ def test_cosine_topk_filtered_chunks(ops, k, order):
     (k = 300).  'ascending' is the adversarial order: every later column beats the running threshold
     of query 0, so every 32-column group qualifies and the filter degenerates to full materialisation."""
     rng = np.random.default_rng(k)
-    M, N, D = 37, 21000, 48
+    M, N, D = 37, 40000, 48
     Q, G = unit(rng, M, D), unit(rng, N, D)
     if order != "random":
         s0 = G @ Q[0]
         G = G[np.argsort(s0 if order == "ascending" else -s0)]
-    G[9000] = G[17]; G[20999] = G[17]; G[8191] = G[8192]          # ties across chunk boundaries
+    G[9000] = G[17]; G[39999] = G[17]; G[8191] = G[8192]          # ties across chunk boundaries
     want_s, want_i = O.cosine_topk(Q, G, k, idx_base=3)
     ts, ti = ops.cosine_topk(dev(Q), dev(G), k, idx_base=3)
     np.testing.assert_array_equal(host(ti), want_i)
