@@ -121,6 +121,14 @@ int isx_rank_full(const float* sim, int64_t M, int64_t N, int64_t* ranked, void*
 int isx_average_precision(const int64_t* ranked, int64_t M, int64_t N, const int32_t* qlab, const int32_t* glab,
                           int kth, double* ap, isx_stream_t stream);
 
+/* The same AP values straight from the score matrix, WITHOUT the full sort: AP only depends on the
+ * ranks of the query's positives (every other rank adds exactly 0 in utils/metrics.py:34-44), and
+ * rank(p) = #{gallery keys above key(p)} is one streaming pass.  Bit-identical to
+ * isx_rank_full + isx_average_precision.  Queries with more than 32 positives get ap = -1.0
+ * (use the sorted path for those); NaN where the reference returns None.  sim: (M,N). */
+int isx_average_precision_sim(const float* sim, int64_t M, int64_t N, const int32_t* qlab, const int32_t* glab,
+                              int kth, double* ap, isx_stream_t stream);
+
 /* utils/train_siamese.py:74-76 sum_pos / (sum_neg + sum_pos) of test_descriptor_net, per
  * query row (the host adds the M row values in order, which keeps the result
  * deterministic): out[2*i] = sum_j sim[i][j] over label-equal pairs, out[2*i+1] = sum_j

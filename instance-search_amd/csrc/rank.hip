@@ -162,6 +162,80 @@ __global__ __launch_bounds__(RK_THREADS) void average_precision_kernel(const int
     if (tid == 0) ap_out[row] = ap;
 }
 
+// ----------------------------------------------- average precision without the sort --
+// AP only depends on the RANKS OF THE POSITIVES: the reference's loop (utils/metrics.py:34-44) adds
+// (recall - old_recall) * (...) at every rank, which is exactly 0 unless the rank holds a positive.
+// rank(p) = #{gallery keys > key(p)}, so one streaming pass over the score row with the (few)
+// positive keys held in registers replaces the full sort.  Per query: <= AP_MAXP positives (more ->
+// ap = -1, the caller uses rank_full + average_precision).  Same float64 terms, summed in rank
+// order by one thread -> bit-identical to the sorted path and to the reference.
+constexpr int AP_MAXP = 32;
+
+__global__ __launch_bounds__(RK_THREADS) void average_precision_sim_kernel(const float* __restrict__ sim, int64_t N,
+                                                                           const int32_t* __restrict__ qlab,
+                                                                           const int32_t* __restrict__ glab, int kth,
+                                                                           double* __restrict__ ap_out) {
+    __shared__ uint64_t pkey[AP_MAXP];
+    __shared__ int pcnt[AP_MAXP];
+    __shared__ int rk[AP_MAXP];              // thread 0's sort buffer (LDS: runtime-indexed, keeps it out of scratch)
+    __shared__ int npos_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t row = blockIdx.x;
+    const int32_t q = qlab[row];
+    const float* r = sim + row * N;
+    if (tid == 0) npos_s = 0;
+    if (tid < AP_MAXP) { pcnt[tid] = 0; pkey[tid] = ~0ull; }
+    __syncthreads();
+    for (int64_t j = tid; j < N; j += RK_THREADS) {
+        if (glab[j] == q) {
+            const int slot = atomicAdd(&npos_s, 1);
+            if (slot < AP_MAXP) pkey[slot] = rank_key(r[j], (uint32_t)j);
+        }
+    }
+    __syncthreads();
+    const int n_lab = npos_s;
+    const int64_t n_pos = (int64_t)n_lab - (kth - 1);
+    if (n_pos <= 0) { if (tid == 0) ap_out[row] = __longlong_as_double(0x7FF8000000000000ll); return; }
+    if (n_lab > AP_MAXP) { if (tid == 0) ap_out[row] = -1.0; return; }
+    // ranks: count, for every positive, the gallery keys above it (unused slots hold ~0: never exceeded)
+    uint64_t pk[AP_MAXP];
+    int cnt[AP_MAXP];
+#pragma unroll
+    for (int p = 0; p < AP_MAXP; ++p) { pk[p] = pkey[p]; cnt[p] = 0; }
+    for (int64_t j = tid; j < N; j += RK_THREADS) {
+        const uint64_t x = rank_key(r[j], (uint32_t)j);
+#pragma unroll
+        for (int p = 0; p < AP_MAXP; ++p) cnt[p] += (x > pk[p]) ? 1 : 0;
+    }
+#pragma unroll
+    for (int p = 0; p < AP_MAXP; ++p) {
+        const int c = wave_sum(cnt[p]);
+        if (lane == 0 && c) atomicAdd(&pcnt[p], c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // positives in rank order (insertion sort of <= 32 distinct ranks)
+        for (int p = 0; p < n_lab; ++p) {
+            int v = pcnt[p], i = p;
+            while (i > 0 && rk[i - 1] > v) { rk[i] = rk[i - 1]; --i; }
+            rk[i] = v;
+        }
+        const double dn = (double)n_pos;
+        double ap = 0.0;
+        int64_t h = 0;
+        for (int p = 0; p < n_lab; ++p) {
+            if (rk[p] < kth - 1) continue;                       // the first kth-1 ranks are skipped entirely
+            const int64_t j = rk[p] - (kth - 1);
+            const double recall = (double)(h + 1) / dn, old_recall = (double)h / dn;
+            const double precision = (double)(h + 1) / ((double)j + 1.0);
+            const double old_precision = (j == 0) ? 1.0 : (double)h / (double)j;
+            ap += (recall - old_recall) * ((old_precision + precision) / 2.0);
+            ++h;
+        }
+        ap_out[row] = ap;
+    }
+}
+
 // Per-row label-masked sums: out[row*2] = sum_j sim[row][j] * [glab[j]==qlab[row]], out[row*2+1] = sum_j sim[row][j]
 __global__ __launch_bounds__(RK_THREADS) void masked_row_sums_kernel(const float* __restrict__ sim, int64_t N,
                                                                      const int32_t* __restrict__ qlab,
@@ -241,6 +315,16 @@ ISX_API int isx_average_precision(const int64_t* ranked, int64_t M, int64_t N, c
     ISX_REQUIRE(qlab && ap && ((ranked && glab) || N == 0), "isx_average_precision: null pointer");
     hipLaunchKernelGGL(average_precision_kernel, dim3((unsigned)M), dim3(RK_THREADS), 0, (hipStream_t)stream, ranked, N, qlab, glab, kth, ap);
     ISX_CHECK_LAUNCH("isx_average_precision");
+    return ISX_OK;
+}
+
+ISX_API int isx_average_precision_sim(const float* sim, int64_t M, int64_t N, const int32_t* qlab, const int32_t* glab, int kth,
+                                      double* ap, isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && N >= 0 && kth >= 1 && M < (1ll << 31) && N <= 0xFFFFFFFFll, "isx_average_precision_sim: bad shape M=%lld N=%lld kth=%d", (long long)M, (long long)N, kth);
+    if (M == 0) return ISX_OK;
+    ISX_REQUIRE(qlab && ap && ((sim && glab) || N == 0), "isx_average_precision_sim: null pointer");
+    hipLaunchKernelGGL(average_precision_sim_kernel, dim3((unsigned)M), dim3(RK_THREADS), 0, (hipStream_t)stream, sim, N, qlab, glab, kth, ap);
+    ISX_CHECK_LAUNCH("isx_average_precision_sim");
     return ISX_OK;
 }
 

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "isx_rank_full_workspace": (SZ, [I64, I64]),
     "isx_rank_full": (C.c_int, [VP, I64, I64, VP, VP, SZ, VP]),
     "isx_average_precision": (C.c_int, [VP, I64, I64, VP, VP, I32, VP, VP]),
+    "isx_average_precision_sim": (C.c_int, [VP, I64, I64, VP, VP, I32, VP, VP]),
     "isx_masked_sums": (C.c_int, [VP, I64, I64, VP, VP, VP, VP]),
     "isx_topk_merge": (C.c_int, [VP, VP, I32, I64, I32, VP, VP, VP]),
 }

@@ -173,6 +173,22 @@ def average_precision(ranked, qlab, glab, kth=1):
     return ap
 
 
+def average_precision_sim(sim, qlab, glab, kth=1):
+    """AP per query straight from the score matrix (no sort).  Rows with more than 32 positives are
+    recomputed through rank_full + average_precision, so the result always equals the sorted path."""
+    sim = _f32(sim, "sim")
+    M, N = sim.shape
+    qlab = _typed(qlab, torch.int32, "qlab")
+    glab = _typed(glab, torch.int32, "glab")
+    ap = torch.empty((M,), device=sim.device, dtype=torch.float64)
+    check(lib().isx_average_precision_sim(sim.data_ptr(), M, N, qlab.data_ptr(), glab.data_ptr(), kth, ap.data_ptr(),
+                                          _stream()), "isx_average_precision_sim")
+    heavy = (ap == -1.0).nonzero().flatten()
+    if heavy.numel():
+        ap[heavy] = average_precision(rank_full(sim[heavy]), qlab[heavy], glab, kth)
+    return ap
+
+
 def masked_sums(sim, qlab, glab):
     sim = _f32(sim, "sim")
     M, N = sim.shape

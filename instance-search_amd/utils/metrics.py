@@ -44,8 +44,9 @@ def _average_precisions(sim, qlab, glab, kth):
     """float64 AP per query, NaN where the query has no (remaining) positive."""
     if sim.is_cuda:
         from isx import ops
-        ranked = ops.rank_full(sim.float())
-        return ops.average_precision(ranked, qlab.to(sim.device), glab.to(sim.device), kth).cpu()
+        # no full sort: AP needs only the ranks of the positives (isx_average_precision_sim); queries
+        # with many positives fall back to isx_rank_full + isx_average_precision inside the wrapper
+        return ops.average_precision_sim(sim.float(), qlab.to(sim.device), glab.to(sim.device), kth).cpu()
     M, N = sim.shape
     ranked = sim.sort(dim=1, descending=True, stable=True).indices
     n_pos = (glab[None, :] == qlab[:, None]).sum(1) - (kth - 1)

@@ -28,6 +28,18 @@ def main():
             r = dict(r)
             r["Name"] = r["Name"][:160]
             w.writerow(r)
+    # per-launch-shape averages of the hand-written kernels from the kernel trace next to the stats file
+    trace = stats.replace("_kernel_stats.csv", "_kernel_trace.csv")
+    if os.path.exists(trace):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(trace)):
+            if "isx::" in r["Kernel_Name"]:
+                per[(r["Kernel_Name"].split("(")[0][:90], r["Grid_Size_X"], r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        with open(os.path.join(HERE, tag + "_isx_kernels_by_shape.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "grid_threads", "workgroup", "launches", "avg_us", "min_us", "max_us"])
+            for (k, g, wg), v in sorted(per.items()):
+                w.writerow([k, g, wg, len(v), "%.1f" % (sum(v) / len(v) / 1e3), "%.1f" % (min(v) / 1e3), "%.1f" % (max(v) / 1e3)])
     if len(sys.argv) >= 5:
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for cname, path in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
@@ -48,7 +60,7 @@ def main():
         traffic = {"cosine_gemm_kernel": {}}
         for grid, tot in out.get("cosine_gemm_kernel", {}).items():
             tiles = int(grid) // 256
-            for shape, t in (("512x10000x2048", 4 * 79), ("10000x32768x2048", 79 * 256)):
+            for shape, t in (("512x10000x2048", 4 * 79), ("512x10000x2048", 8 * 157), ("10000x32768x2048", 79 * 256)):
                 if tiles == t:
                     traffic["cosine_gemm_kernel"][shape] = tot
         json.dump(traffic, open(os.path.join(HERE, "roofline_traffic.json"), "w"), indent=1)

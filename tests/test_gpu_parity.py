@@ -257,6 +257,22 @@ def test_rank_full_and_ap(ops, M, N):
         np.testing.assert_array_equal(ap[~np.isnan(ap)], want[~np.isnan(want)])     # float64, bit-exact
 
 
+@pytest.mark.parametrize("M,N,L", [(12, 40, 6), (9, 1000, 100), (5, 5000, 50), (4, 3000, 3), (20, 10000, 1000)])
+def test_average_precision_sim_equals_sorted_path(ops, M, N, L):
+    """Sort-free AP == rank_full + average_precision == oracle, bit for bit (incl. kth > 1, skipped
+    queries, tied scores, and rows with > 32 positives that take the fallback)."""
+    rng = np.random.default_rng(N + L)
+    sim = (np.round(rng.random((M, N)) * 200) / 200).astype(np.float32)        # many exact ties
+    gl = (np.arange(N) % L).astype(np.int32)
+    ql = (np.arange(M) % (L + 1)).astype(np.int32)
+    ranked = O.rank_full(sim)
+    for kth in (1, 2, 4):
+        want = O.average_precision(ranked, ql, gl, kth)
+        got = host(ops.average_precision_sim(dev(sim), dev(ql), dev(gl), kth))
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+        np.testing.assert_array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+
+
 def test_metrics_golden(ops, golden):
     g = golden("metrics.npz")
     sim, ql, gl = g["sim"], g["qlab"], g["glab"]
