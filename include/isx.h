@@ -145,6 +145,19 @@ int isx_masked_sums(const float* sim, int64_t M, int64_t N, const int32_t* qlab,
 int isx_topk_merge(const float* scores, const int64_t* idx, int P, int64_t M, int k, float* out_s, int64_t* out_i,
                    isx_stream_t stream);
 
+/* RCCL (xGMI) exchange of the per-shard lists: every rank contributes (M,k) scores + (M,k) global
+ * indices, every rank receives (P,M,k) of each, rank-major -- the input of isx_topk_merge.  One
+ * grouped ncclAllGather pair on `stream`.  RCCL is bound lazily (dlopen), so single-GPU users never
+ * load it.  comm: an ncclComm_t, the caller's own or one made by isx_comm_init_rank from a unique
+ * id (isx_comm_unique_id on rank 0, isx_comm_unique_id_bytes() bytes, shipped to the other ranks by
+ * any means).  isx_comm_* are host-side set-up calls, not stream operations. */
+int isx_comm_unique_id_bytes(void);
+int isx_comm_unique_id(void* out_bytes);
+int isx_comm_init_rank(void** comm, int nranks, int rank, const void* unique_id_bytes);
+int isx_comm_destroy(void* comm);
+int isx_shard_topk_allgather(void* comm, const float* s_local, const int64_t* i_local, int64_t M, int k, float* s_all,
+                             int64_t* i_all, isx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,11 @@ _SIGNATURES = {
     "isx_average_precision_sim": (C.c_int, [VP, I64, I64, VP, VP, I32, VP, VP]),
     "isx_masked_sums": (C.c_int, [VP, I64, I64, VP, VP, VP, VP]),
     "isx_topk_merge": (C.c_int, [VP, VP, I32, I64, I32, VP, VP, VP]),
+    "isx_comm_unique_id_bytes": (C.c_int, []),
+    "isx_comm_unique_id": (C.c_int, [VP]),
+    "isx_comm_init_rank": (C.c_int, [C.POINTER(VP), I32, I32, VP]),
+    "isx_comm_destroy": (C.c_int, [VP]),
+    "isx_shard_topk_allgather": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, VP]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))

@@ -209,3 +209,38 @@ def topk_merge(scores, idx):
     check(lib().isx_topk_merge(scores.data_ptr(), idx.data_ptr(), P, M, k, os_.data_ptr(), oi.data_ptr(), _stream()),
           "isx_topk_merge")
     return os_, oi
+
+
+# ---- native RCCL exchange of per-shard top-k lists (lazy-bound librccl; see csrc/comm.cpp) -------------
+def comm_unique_id():
+    """bytes of an ncclUniqueId (create on rank 0, ship to the other ranks by any means)."""
+    import ctypes
+    n = lib().isx_comm_unique_id_bytes()
+    buf = ctypes.create_string_buffer(n)
+    check(lib().isx_comm_unique_id(ctypes.cast(buf, ctypes.c_void_p)), "isx_comm_unique_id")
+    return bytes(buf.raw)
+
+
+def comm_init_rank(nranks, rank, unique_id):
+    """ncclComm_t handle (an int) of this rank; the current CUDA device must already be set."""
+    import ctypes
+    handle = ctypes.c_void_p()
+    buf = ctypes.create_string_buffer(unique_id, len(unique_id))
+    check(lib().isx_comm_init_rank(ctypes.byref(handle), nranks, rank, ctypes.cast(buf, ctypes.c_void_p)), "isx_comm_init_rank")
+    return handle.value
+
+
+def comm_destroy(comm):
+    check(lib().isx_comm_destroy(comm), "isx_comm_destroy")
+
+
+def shard_topk_allgather(comm, nranks, s_local, i_local):
+    """(P,M,k) scores and indices gathered from every rank (rank-major), on the current stream."""
+    s_local = _f32(s_local, "s_local")
+    i_local = _typed(i_local, torch.int64, "i_local")
+    M, k = s_local.shape
+    all_s = torch.empty((nranks, M, k), device=s_local.device, dtype=torch.float32)
+    all_i = torch.empty((nranks, M, k), device=s_local.device, dtype=torch.int64)
+    check(lib().isx_shard_topk_allgather(comm, s_local.data_ptr(), i_local.data_ptr(), M, k, all_s.data_ptr(), all_i.data_ptr(),
+                                         _stream()), "isx_shard_topk_allgather")
+    return all_s, all_i

@@ -60,13 +60,39 @@ def merge_topk(scores, idx):
     return _canonical_topk_cpu(scores.permute(1, 0, 2).reshape(M, P * k), idx.permute(1, 0, 2).reshape(M, P * k), k)
 
 
+class NativeComm(object):
+    """An RCCL communicator owned by libisx (csrc/comm.cpp): the unique id is created on rank 0 and
+    shipped through the existing torch.distributed group (control plane only); the data-path
+    all-gather then runs as ONE grouped ncclAllGather pair issued by the library itself."""
+
+    def __init__(self, group=None):
+        from . import ops
+        self.nranks = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        box = [ops.comm_unique_id() if self.rank == 0 else None]
+        if self.nranks > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self.handle = ops.comm_init_rank(self.nranks, self.rank, box[0])
+
+    def allgather_topk(self, s, i):
+        from . import ops
+        return ops.shard_topk_allgather(self.handle, self.nranks, s, i)
+
+    def close(self):
+        if self.handle:
+            from . import ops
+            ops.comm_destroy(self.handle)
+            self.handle = None
+
+
 class ShardedGallery(object):
     """This rank's slice of a row-sharded descriptor gallery."""
 
-    def __init__(self, shard, idx_base, group=None):
+    def __init__(self, shard, idx_base, group=None, native_comm=None):
         self.shard = shard.contiguous()
         self.idx_base = int(idx_base)
         self.group = group
+        self.native_comm = native_comm        # NativeComm: all-gather issued by libisx instead of torch.distributed
         self._ws = None
 
     @classmethod
@@ -89,6 +115,10 @@ class ShardedGallery(object):
     def search(self, Q, k):
         """Global canonical top-k for the (replicated) query block Q: (scores (M,k), idx (M,k))."""
         s, i = local_topk(Q, self.shard, k, self.idx_base, self._workspace(Q.size(0), k))
+        if self.native_comm is not None and s.is_cuda:
+            if self.native_comm.nranks == 1:
+                return s, i
+            return merge_topk(*self.native_comm.allgather_topk(s, i))
         if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
             return s, i
         P = dist.get_world_size(self.group)

@@ -316,6 +316,28 @@ def test_topk_merge(ops, P, k):
     np.testing.assert_array_equal(host(ms), fs)
 
 
+def test_native_rccl_allgather_single_rank(ops):
+    """libisx's own RCCL communicator (dlopen'd librccl): with one rank the all-gather is the identity;
+    exercises unique-id creation, ncclCommInitRank and the grouped ncclAllGather pair."""
+    uid = ops.comm_unique_id()
+    assert len(uid) == 128
+    comm = ops.comm_init_rank(1, 0, uid)
+    s = torch.randn(50, 10, device="cuda")
+    i = torch.randint(0, 1000, (50, 10), device="cuda")
+    all_s, all_i = ops.shard_topk_allgather(comm, 1, s, i)
+    torch.cuda.synchronize()
+    assert all_s.shape == (1, 50, 10) and torch.equal(all_s[0], s) and torch.equal(all_i[0], i)
+    from isx.retrieval import NativeComm, ShardedGallery
+    nc = NativeComm()
+    g = ShardedGallery(ops.l2norm_rows(torch.randn(300, 64, device="cuda")), 0, native_comm=nc)
+    q = ops.l2norm_rows(torch.randn(5, 64, device="cuda"))
+    ts, ti = g.search(q, 7)
+    want = O.cosine_topk(host(q), host(g.shard), 7)
+    np.testing.assert_array_equal(host(ti), want[1])
+    nc.close()
+    ops.comm_destroy(comm)
+
+
 # ------------------------------------------------------------------ full-size properties (BASELINE sizes)
 def test_full_size_properties(ops):
     """1k x 100k x 2048 (config 3 scale) and a 10k-query slab: size-independent checks --
