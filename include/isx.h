@@ -158,6 +158,27 @@ int isx_comm_destroy(void* comm);
 int isx_shard_topk_allgather(void* comm, const float* s_local, const int64_t* i_local, int64_t M, int k, float* s_all,
                              int64_t* i_all, isx_stream_t stream);
 
+/* ---- siamese triplet training step (next scope row) ------------------------------- */
+
+/* train/siamese_descriptor.py:94-128 (and siamese_regions.py:94-135): for every positive couple
+ * (i1[c], i2[c]) the negative = arg-max over j of sim[i1][j] after excluding same-label items and, in
+ * the semi-hard phase (epoch < train_epoch_switch), items with sim >= sim[i1][i2]; ties -> smallest
+ * index; neg[c] = -1 when everything is excluded (caller picks a random negative).
+ * sim: (N,N); labels: (N) int32; i1, i2, neg: (n_couples) int64. */
+int isx_mine_negatives(const float* sim, int64_t N, const int32_t* labels, const int64_t* i1, const int64_t* i2,
+                       int64_t n_couples, int semi_hard, int64_t* neg, isx_stream_t stream);
+
+/* model/custom_modules.py:153-171 TripletLossFun.forward, per-row part: loss_rows[b] = max(0, l_b) with
+ * l_b = a.n - a.p + margin (normalized) or (|a-p|^2 - |a-n|^2 + 2 margin)/2.  The caller sums the rows
+ * (and divides by B for size_average).  anchor, pos, neg: (B,D). */
+int isx_triplet_loss_fwd(const float* anchor, const float* pos, const float* neg, int64_t B, int D, float margin,
+                         int normalized, float* loss_rows, isx_stream_t stream);
+
+/* model/custom_modules.py:173-203 TripletLossFun.backward: g_a = n - p, g_p = -a (p - a), g_n = a (a - n)
+ * on rows with loss_rows > 0, zero elsewhere, times `scale`. */
+int isx_triplet_loss_bwd(const float* anchor, const float* pos, const float* neg, const float* loss_rows, int64_t B, int D,
+                         float scale, int normalized, float* g_anchor, float* g_pos, float* g_neg, isx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,113 @@
+// train.hip -- kernels of the siamese triplet training step:
+//   * hard / semi-hard negative mining over the epoch's similarity matrix
+//     (reference train/siamese_descriptor.py:94-128, siamese_regions.py:94-135)
+//   * TripletLoss forward + analytic backward (reference model/custom_modules.py:140-203)
+#include "isx_common.hpp"
+
+namespace isx {
+
+// One 256-thread workgroup per positive couple (i1, i2): the negative is the most similar gallery
+// item of anchor i1 that does not share its label and (semi-hard phase, FaceNet) is strictly less
+// similar than the positive.  Excluded entries are treated as -2 exactly like the reference
+// (`sims[ind_exl] = -2; sims.max(0)`), ties go to the smallest index; -1 = every item excluded
+// (the caller falls back to a random negative, reference :100-107,129-131).
+__global__ __launch_bounds__(256) void mine_negatives_kernel(const float* __restrict__ sim, int64_t N,
+                                                             const int32_t* __restrict__ lab, const int64_t* __restrict__ i1,
+                                                             const int64_t* __restrict__ i2, int semi_hard,
+                                                             int64_t* __restrict__ neg) {
+    __shared__ uint64_t red[4];
+    const int64_t a = i1[blockIdx.x], p = i2[blockIdx.x];
+    const float* row = sim + a * N;
+    const float sim_pos = row[p];
+    const int32_t la = lab[a];
+    uint64_t best = 0;
+    for (int64_t j = threadIdx.x; j < N; j += 256) {
+        const float s = row[j];
+        const bool excl = (lab[j] == la) || (semi_hard && s >= sim_pos);
+        if (!excl) {
+            const uint64_t key = rank_key(s, (uint32_t)j);
+            best = key > best ? key : best;
+        }
+    }
+    best = wave_max(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) best = red[i] > best ? red[i] : best;
+        neg[blockIdx.x] = best ? (int64_t)key_idx(best) : -1;
+    }
+}
+
+// One wave per triplet row.  normalized: l = a.n - a.p + margin ; else l = (|a-p|^2 - |a-n|^2 + 2 margin) / 2;
+// loss_rows[b] = max(l, 0)  (the reference zeroes l <= 0, custom_modules.py:166-167).
+__global__ __launch_bounds__(256) void triplet_fwd_kernel(const float* __restrict__ A, const float* __restrict__ P,
+                                                          const float* __restrict__ Ng, int64_t B, int D, float margin,
+                                                          int normalized, float* __restrict__ loss_rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float *a = A + b * D, *p = P + b * D, *n = Ng + b * D;
+    float s = 0.0f;
+    for (int j = lane; j < D; j += 64) {
+        if (normalized) s += a[j] * n[j] - a[j] * p[j];
+        else { const float dp = a[j] - p[j], dn = a[j] - n[j]; s += dp * dp - dn * dn; }
+    }
+    s = wave_sum(s);
+    float l = normalized ? s + margin : (s + 2.0f * margin) * 0.5f;
+    if (lane == 0) loss_rows[b] = l > 0.0f ? l : 0.0f;
+}
+
+// Gradients (custom_modules.py:173-203), rows with zero loss get zero gradient, everything scaled by
+// `scale` (= grad_output [/ B when size_average]).
+__global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ A, const float* __restrict__ P,
+                                                          const float* __restrict__ Ng, const float* __restrict__ loss_rows,
+                                                          int64_t B, int D, float scale, int normalized,
+                                                          float* __restrict__ gA, float* __restrict__ gP, float* __restrict__ gN) {
+    const int64_t total = B * D;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / D;
+        const bool on = loss_rows[b] > 0.0f;
+        const float a = A[i], p = P[i], n = Ng[i];
+        float ga = n - p, gp, gn;
+        if (normalized) { gp = -a; gn = a; } else { gp = p - a; gn = a - n; }
+        gA[i] = on ? ga * scale : 0.0f;
+        gP[i] = on ? gp * scale : 0.0f;
+        gN[i] = on ? gn * scale : 0.0f;
+    }
+}
+
+}  // namespace isx
+
+using namespace isx;
+
+ISX_API int isx_mine_negatives(const float* sim, int64_t N, const int32_t* labels, const int64_t* i1, const int64_t* i2,
+                               int64_t n_couples, int semi_hard, int64_t* neg, isx_stream_t stream) {
+    ISX_REQUIRE(N > 0 && N <= 0xFFFFFFFFll && n_couples >= 0 && n_couples < (1ll << 31), "isx_mine_negatives: bad shape N=%lld couples=%lld", (long long)N, (long long)n_couples);
+    if (n_couples == 0) return ISX_OK;
+    ISX_REQUIRE(sim && labels && i1 && i2 && neg, "isx_mine_negatives: null pointer");
+    hipLaunchKernelGGL(mine_negatives_kernel, dim3((unsigned)n_couples), dim3(256), 0, (hipStream_t)stream, sim, N, labels, i1, i2, semi_hard, neg);
+    ISX_CHECK_LAUNCH("isx_mine_negatives");
+    return ISX_OK;
+}
+
+ISX_API int isx_triplet_loss_fwd(const float* anchor, const float* pos, const float* neg, int64_t B, int D, float margin,
+                                 int normalized, float* loss_rows, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && D > 0 && B < (1ll << 31), "isx_triplet_loss_fwd: bad shape B=%lld D=%d", (long long)B, D);
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(anchor && pos && neg && loss_rows, "isx_triplet_loss_fwd: null pointer");
+    hipLaunchKernelGGL(triplet_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, anchor, pos, neg, B, D, margin, normalized, loss_rows);
+    ISX_CHECK_LAUNCH("isx_triplet_loss_fwd");
+    return ISX_OK;
+}
+
+ISX_API int isx_triplet_loss_bwd(const float* anchor, const float* pos, const float* neg, const float* loss_rows, int64_t B, int D,
+                                 float scale, int normalized, float* g_anchor, float* g_pos, float* g_neg, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && D > 0 && B < (1ll << 31), "isx_triplet_loss_bwd: bad shape B=%lld D=%d", (long long)B, D);
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(anchor && pos && neg && loss_rows && g_anchor && g_pos && g_neg, "isx_triplet_loss_bwd: null pointer");
+    const int64_t total = B * D;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(triplet_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, anchor, pos, neg, loss_rows, B, D, scale, normalized, g_anchor, g_pos, g_neg);
+    ISX_CHECK_LAUNCH("isx_triplet_loss_bwd");
+    return ISX_OK;
+}

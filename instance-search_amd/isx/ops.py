@@ -244,3 +244,37 @@ def shard_topk_allgather(comm, nranks, s_local, i_local):
     check(lib().isx_shard_topk_allgather(comm, s_local.data_ptr(), i_local.data_ptr(), M, k, all_s.data_ptr(), all_i.data_ptr(),
                                          _stream()), "isx_shard_topk_allgather")
     return all_s, all_i
+
+
+# ---- training step -----------------------------------------------------------------------
+def mine_negatives(sim, labels, i1, i2, semi_hard):
+    """neg index per positive couple (int64, -1 = none available)."""
+    sim = _f32(sim, "sim")
+    N = sim.size(0)
+    assert sim.shape == (N, N)
+    labels = _typed(labels, torch.int32, "labels")
+    i1 = _typed(i1, torch.int64, "i1")
+    i2 = _typed(i2, torch.int64, "i2")
+    neg = torch.empty_like(i1)
+    check(lib().isx_mine_negatives(sim.data_ptr(), N, labels.data_ptr(), i1.data_ptr(), i2.data_ptr(), i1.numel(),
+                                   1 if semi_hard else 0, neg.data_ptr(), _stream()), "isx_mine_negatives")
+    return neg
+
+
+def triplet_loss_rows(anchor, pos, neg, margin, normalized=True):
+    anchor, pos, neg = _f32(anchor, "anchor"), _f32(pos, "pos"), _f32(neg, "neg")
+    B, D = anchor.shape
+    rows = torch.empty((B,), device=anchor.device, dtype=torch.float32)
+    check(lib().isx_triplet_loss_fwd(anchor.data_ptr(), pos.data_ptr(), neg.data_ptr(), B, D, margin, 1 if normalized else 0,
+                                     rows.data_ptr(), _stream()), "isx_triplet_loss_fwd")
+    return rows
+
+
+def triplet_loss_grads(anchor, pos, neg, loss_rows, scale, normalized=True):
+    anchor, pos, neg = _f32(anchor, "anchor"), _f32(pos, "pos"), _f32(neg, "neg")
+    B, D = anchor.shape
+    ga, gp, gn = torch.empty_like(anchor), torch.empty_like(anchor), torch.empty_like(anchor)
+    check(lib().isx_triplet_loss_bwd(anchor.data_ptr(), pos.data_ptr(), neg.data_ptr(), _f32(loss_rows, "loss_rows").data_ptr(), B, D,
+                                     float(scale), 1 if normalized else 0, ga.data_ptr(), gp.data_ptr(), gn.data_ptr(), _stream()),
+          "isx_triplet_loss_bwd")
+    return ga, gp, gn

@@ -5,8 +5,9 @@ Forward on a GPU tensor runs the hand-written HIP kernel (libisx `isx_l2norm_row
 raises if the library is missing -- there is no silent torch fallback on the GPU.  On a CPU
 tensor (the reference's `--device=-1`, BASELINE config 1 "plumbing, no GPU") the same
 arithmetic runs in plain torch.  Backward follows the reference's formula (:59-67) so the
-modules stay usable in training graphs.  The losses (MetricLoss, TripletLoss :81-215) are
-training-only and out of scope for this round."""
+modules stay usable in training graphs.  TripletLoss (:140-215) runs its per-row forward and its
+analytic backward as HIP kernels on the GPU (`isx_triplet_loss_fwd/bwd`); MetricLoss (:81-137, not
+used by any of the four approaches) is kept in plain torch."""
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -92,3 +93,89 @@ class Shift(nn.Module):
 
     def forward(self, x):
         return x + self.param.view(1, -1)
+
+
+# ---------------------------------------------------------------------------------------- losses
+def _triplet_rows(anchor, pos, neg, margin, normalized):
+    """Per-row clamped loss (reference custom_modules.py:153-167)."""
+    if anchor.is_cuda:
+        from isx import ops
+        return ops.triplet_loss_rows(anchor, pos, neg, margin, normalized)
+    if normalized:
+        l = (anchor * neg).sum(1) - (anchor * pos).sum(1) + margin
+    else:
+        l = ((anchor - pos).pow(2).sum(1) - (anchor - neg).pow(2).sum(1) + 2 * margin) / 2
+    return l.clamp(min=0)
+
+
+class _Triplet(Function):
+    @staticmethod
+    def forward(ctx, anchor, pos, neg, margin, size_average, normalized):
+        a, p, n = anchor.detach().float(), pos.detach().float(), neg.detach().float()
+        rows = _triplet_rows(a, p, n, margin, normalized)
+        ctx.save_for_backward(a, p, n, rows)
+        ctx.cfg = (size_average, normalized)
+        loss = rows.sum().view(1)
+        return loss / a.size(0) if size_average else loss
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        a, p, n, rows = ctx.saved_tensors
+        size_average, normalized = ctx.cfg
+        scale = float(grad_output.reshape(-1)[0]) / (a.size(0) if size_average else 1)
+        if a.is_cuda:
+            from isx import ops
+            ga, gp, gn = ops.triplet_loss_grads(a, p, n, rows, scale, normalized)
+        else:
+            on = (rows > 0).float().view(-1, 1) * scale
+            ga = (n - p) * on
+            gp = (-a if normalized else p - a) * on
+            gn = (a if normalized else a - n) * on
+        return ga, gp, gn, None, None, None
+
+
+class TripletLossFun(object):
+    """sum_i max(0, a_i.n_i - a_i.p_i + margin) for unit vectors (normalized=True), else the squared
+    distance form; `size_average` divides by the batch size."""
+
+    def __init__(self, margin, size_average=True, normalized=True):
+        self.margin, self.size_average, self.normalized = margin, size_average, normalized
+
+    def __call__(self, anchor, pos, neg):
+        return _Triplet.apply(anchor, pos, neg, self.margin, self.size_average, self.normalized)
+
+    forward = __call__
+
+
+class TripletLoss(nn.Module):
+    def __init__(self, margin, size_average=True, normalized=True):
+        super().__init__()
+        self.margin, self.size_average, self.normalized = margin, size_average, normalized
+
+    def forward(self, anchor, pos, neg):
+        return _Triplet.apply(anchor, pos, neg, self.margin, self.size_average, self.normalized)
+
+
+class MetricLossFun(object):
+    """Chopra et al. contrastive loss with Q = 2 on the L1 energy E = |x1 - x2|_1:
+    (1+y)/2 * E^2 + (1-y) * 2 * exp(-2.77 E / 2), y = +1 (same) / -1 (different).  Plain torch autograd."""
+
+    def __init__(self, size_average=True):
+        self.size_average = size_average
+
+    def __call__(self, input1, input2, y):
+        energy = (input1 - input2).abs().sum(1)
+        loss = energy * energy * (1 + y) / 2 + torch.exp(-2.77 * energy / 2) * (1 - y) * 2
+        loss = loss.sum().view(1)
+        return loss / y.size(0) if self.size_average else loss
+
+    forward = __call__
+
+
+class MetricLoss(nn.Module):
+    def __init__(self, size_average=True):
+        super().__init__()
+        self.size_average = size_average
+
+    def forward(self, input1, input2, target):
+        return MetricLossFun(self.size_average)(input1, input2, target)

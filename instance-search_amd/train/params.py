@@ -28,5 +28,24 @@ class Params(object):
         # (2**30 there, utils/train_siamese.py:30-43); sized here for 288 GB of HBM3E
         self.embeddings_cuda_size = 64 * 2 ** 30
         self.log_file = None
+        # --- siamese training (train/siamese_descriptor_p.py:62-101 of the reference) ---
+        self.train_epochs = 20
+        self.train_batch_size = 64
+        self.train_micro_batch = 8
+        self.train_lr = 1e-3
+        self.train_momentum = 0.9
+        self.train_weight_decay = 5e-4
+        self.train_annealing = {}
+        self.train_loss_avg = False
+        self.train_loss2_avg = False
+        self.train_loss2_alpha = 1.0
+        self.train_loss_int = 10
+        self.train_test_int = 0
+        self.train_pre_proc = True
+        self.train_trans = None
+        self.triplet_margin = 0.1
+        self.train_epoch_switch = 2          # semi-hard negatives before this epoch, hard ones after
+        self.save_dir = None
+        self.train_seed = 0
         for k, v in overrides.items():
             setattr(self, k, v)

@@ -1,10 +1,18 @@
 """Global siamese descriptor approach: get_embeddings (reference
-train/siamese_descriptor.py:25-41) and get_siamese_net (:151-162).  Triplet training with
-hard-negative mining (:45-148) is the next scope item."""
+train/siamese_descriptor.py:25-41), get_siamese_net (:151-162) and the triplet training with
+semi-hard / hard negative mining (train_siam_triplets_pos_couples :45-148).  Per epoch the whole
+reference set is embedded, the N x N similarity matrix comes from `isx_cosine_sim`, and the negative
+of EVERY positive couple of the epoch is mined in one `isx_mine_negatives` launch (the reference
+walks the couples in Python, one masked row arg-max each)."""
+import random
+
+import numpy as np
 import torch
 
 from model.siamese import DescriptorNet, TuneClassif
-from utils import fold_batches, move_device, tensor
+from model.custom_modules import TripletLoss
+from utils import (choose_rand_neg, embeddings_device_dim, fold_batches, get_pos_couples, get_similarities, log, move_device,
+                   tensor, test_print_descriptor, train_gen)
 from ._common import base_model, load_weights, stage_batch, test_transform
 from .siamese_descriptor_p import P
 
@@ -28,3 +36,88 @@ def get_siamese_net():
     load_weights(class_net, P.classif_model)
     net = DescriptorNet(class_net, P.feature_dim, P.feature_size2d, untrained=P.untrained_blocks)
     return move_device(load_weights(net, P.preload_net), P.cuda_device)
+
+
+def shuffle_couples(couples):
+    """Interleave the couples so that every mini-batch sees many instances (reference :62-85): labels
+    are shuffled, couples are dealt round-robin up to the 80th-percentile list length, the tail of the
+    longer lists is inserted at random positions."""
+    for lab in couples:
+        random.shuffle(couples[lab])
+    x = int(np.percentile(np.array([len(c) for c in couples.values()]), 80))
+    keys = list(couples.keys())
+    random.shuffle(keys)
+    out = [couples[lab][i] for i in range(x) for lab in keys if i < len(couples[lab])]
+    for lab in keys:
+        for c in couples[lab][x:]:
+            out.insert(random.randrange(len(out)), c)
+    return out
+
+
+def mine_epoch_negatives(similarities, dataset, couples_list, semi_hard):
+    """Index of the negative for every couple (-1: none, use a random one)."""
+    table = {}
+    lab = torch.tensor([table.setdefault(l, len(table)) for _, l, _ in dataset], dtype=torch.int32)
+    i1 = torch.tensor([c[1][0] for c in couples_list], dtype=torch.int64)
+    i2 = torch.tensor([c[1][1] for c in couples_list], dtype=torch.int64)
+    if similarities.is_cuda:
+        from isx import ops
+        return ops.mine_negatives(similarities, lab.cuda(), i1.cuda(), i2.cuda(), semi_hard).cpu()
+    rows = similarities[i1]
+    excl = lab[None, :] == lab[i1][:, None]
+    if semi_hard:
+        excl = excl | (rows >= similarities[i1, i2][:, None])
+    masked = rows.masked_fill(excl, -2.0)
+    neg = masked.argmax(1)
+    return torch.where(excl.all(1), torch.full_like(neg, -1), neg)
+
+
+def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, optimizer, best_score=0):
+    trans = None if P.train_pre_proc else P.train_trans
+    couples = get_pos_couples(train_set)
+    log(P, '#pos (without order, with duplicates):{0}'.format(sum(len(c) for c in couples.values())))
+
+    def create_epoch(epoch, couples, testset_tuple):
+        similarities, _ = get_similarities(P, get_embeddings, net, testset_tuple[1])
+        shuffled = shuffle_couples(couples)
+        negs = mine_epoch_negatives(similarities, testset_tuple[1], shuffled, epoch < P.train_epoch_switch).tolist()
+        missing = sum(1 for k in negs if k < 0)
+        if missing:
+            log(P, 'cant find semi-hard neg for {0} couples, falling back to random neg'.format(missing))
+        tagged = [c + (k,) for c, k in zip(shuffled, negs)]
+        return tagged, {'epoch': epoch}
+
+    def create_batch(batch, n, epoch):
+        prep = (lambda im: im) if trans is None else trans
+        a = torch.stack([prep(im1) for _, _, (im1, _), _ in batch])
+        p = torch.stack([prep(im2) for _, _, (_, im2), _ in batch])
+        ng = torch.stack([prep(train_set[k][0] if k >= 0 else choose_rand_neg(train_set, lab)) for lab, _, _, k in batch])
+        lab_ids = torch.tensor([labels.index(lab) for lab, _, _, _ in batch], dtype=torch.int64)
+        mv = lambda t: move_device(t, P.cuda_device)
+        return [mv(a), mv(p), mv(ng)], [mv(lab_ids)]
+
+    def create_loss(out, labels_list):
+        return criterion(*out), None
+
+    return train_gen(train_type, P, test_print_descriptor, get_embeddings, net, couples, testset_tuple, optimizer, create_epoch,
+                     create_batch, create_loss, best_score=best_score)
+
+
+train_type = 'Siamese descriptor'
+
+
+def main(train_set, test_train_set, test_set):
+    """Training entry (reference :165-207) on already loaded (tensor, label, path) datasets."""
+    import torch.optim as optim
+    del labels[:]
+    labels.extend(sorted(set(l for _, l, _ in train_set)))
+    P.num_classes = len(labels)
+    net = get_siamese_net()
+    optimizer = optim.SGD((p for p in net.parameters() if p.requires_grad), lr=P.train_lr, momentum=P.train_momentum,
+                          weight_decay=P.train_weight_decay)
+    criterion = TripletLoss(P.triplet_margin, P.train_loss_avg)
+    testset_tuple = (test_set, test_train_set)
+    score = test_print_descriptor(train_type, P, net, testset_tuple, get_embeddings)
+    score = train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, optimizer, best_score=score)
+    test_print_descriptor(train_type, P, net, testset_tuple, get_embeddings, best_score=len(test_set) + 1)
+    return net, score

@@ -26,6 +26,35 @@ def get_lab_indicators(dataset, device):
     return out
 
 
+def get_pos_couples(dataset, duplicate=True):
+    """label -> [(label, (i1, i2), (x1, x2))] over all same-label index pairs i1 <= i2 (i1 < i2 without
+    `duplicate`), in index order (reference utils/dataset.py:42-55)."""
+    by_label = {}
+    for i, (_, lab, _) in enumerate(dataset):
+        by_label.setdefault(lab, []).append(i)
+    couples = {}
+    order = sorted((idx[0], lab) for lab, idx in by_label.items())
+    for _, lab in order:
+        idx = by_label[lab]
+        out = []
+        for a in range(len(idx)):
+            for b in range(a if duplicate else a + 1, len(idx)):
+                i1, i2 = idx[a], idx[b]
+                out.append((lab, (i1, i2), (dataset[i1][0], dataset[i2][0])))
+        if out:
+            couples[lab] = out
+    return couples
+
+
+def choose_rand_neg(train_set, lab):
+    """A random image whose label differs from `lab` (reference utils/dataset.py:59-63)."""
+    import random
+    while True:
+        im, l2, _ = random.choice(train_set)
+        if l2 != lab:
+            return im
+
+
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 

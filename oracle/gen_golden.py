@@ -116,6 +116,7 @@ def npz(name, **kw):
 def main():
     os.makedirs(OUT, exist_ok=True)
     met, nn_utils, cm, siam, md, general, gp = install_shims()
+    torch.manual_seed(20260301)                       # toy-backbone weights come from the global RNG
     g = torch.Generator().manual_seed(20260301)
     rn = lambda *s: torch.randn(*s, generator=g)
 
@@ -279,6 +280,50 @@ def main():
                     "map" + t: np.float64(met.mean_avg_precision(s.as_subclass(KD), ts_, rs_)),
                     "p1" + t: np.array([p1[0], p1[1], p1[2]], dtype=np.float64)})
     npz("synthetic_retrieval.npz", **syn)
+
+    # ---- training step: TripletLossFun.forward (model/custom_modules.py:153-171, the reference's own code) and the
+    #      negative mining of train/siamese_descriptor.py:94-128 replayed line by line
+    tg_ = torch.Generator().manual_seed(11)
+    nrm = lambda t: cm.NormalizeL2Fun().forward(t.as_subclass(KD)).as_subclass(torch.Tensor)
+    A, Pp, Nn = nrm(torch.randn(9, 24, generator=tg_)), nrm(torch.randn(9, 24, generator=tg_)), nrm(torch.randn(9, 24, generator=tg_))
+    Pp[:4] = nrm(A[:4] + 0.05 * torch.randn(4, 24, generator=tg_))            # easy positives -> some rows clamp to 0
+    trip = {"a": A, "p": Pp, "n": Nn}
+    for normalized in (True, False):
+        for avg in (True, False):
+            f = cm.TripletLossFun(0.1, avg, normalized)
+            f.save_for_backward = lambda *a_: None
+            loss = f.forward(A.clone().as_subclass(KD), Pp.clone().as_subclass(KD), Nn.clone().as_subclass(KD))
+            trip["loss_n%d_a%d" % (normalized, avg)] = loss.as_subclass(torch.Tensor)
+    mlf = cm.MetricLossFun(True)
+    mlf.save_for_backward = lambda *a_: None
+    yv = torch.tensor([1., -1., 1., -1., 1., -1., 1., -1., 1.])
+    trip["metric_loss"] = mlf.forward(A.clone().as_subclass(KD), Pp.clone().as_subclass(KD), yv).as_subclass(torch.Tensor)
+    trip["metric_y"] = yv
+    Ns_ = 60
+    E_ = nrm(torch.randn(Ns_, 12, generator=tg_))
+    E_[7] = E_[3]                                                                  # duplicate item: tied similarities
+    labs_ = torch.arange(Ns_) % 9
+    S_ = torch.mm(E_, E_.t())
+    couples_ = [(int(i), int(j)) for i in range(Ns_) for j in range(i, Ns_) if labs_[i] == labs_[j]][:80]
+    mined = {}
+    for semi in (1, 0):
+        out = []
+        for (c1, c2) in couples_:
+            ind_exl = labs_ == labs_[c1]
+            sim_pos = S_[c1, c2]
+            if semi:
+                ind_exl = ind_exl | S_[c1].ge(sim_pos)
+            if int(ind_exl.sum()) >= S_.size(0):
+                out.append(-1)
+            else:
+                sims = S_[c1].clone()
+                sims[ind_exl] = -2
+                _, kk = sims.max(0)
+                out.append(int(kk))
+        mined["neg_semi%d" % semi] = np.array(out, np.int64)
+    trip.update({"mine_sim": S_, "mine_labels": labs_.int(), "mine_i1": np.array([c[0] for c in couples_], np.int64),
+                 "mine_i2": np.array([c[1] for c in couples_], np.int64), **mined})
+    npz("training.npz", **trip)
 
     # ---- host-side helpers: Maxnet structure, copyParameters, convolutionalize, parse/check, tables
     host = {}

@@ -323,3 +323,50 @@ ISXO_API void isxo_masked_sums(const float* sim, int64_t M, int64_t N, const int
         }
     *sum_pos = sp; *sum_all = sa;
 }
+
+/* ------------------------------------------------------- training step ----- */
+
+/* train/siamese_descriptor.py:94-128: negative for the positive couple (i1,i2):
+ *   ind_exl = same label as the anchor  [| similarities[i1] >= sim_pos  while epoch < train_epoch_switch]
+ *   all excluded -> None (-1 here; the caller draws a random negative)
+ *   else sims[ind_exl] = -2; k = argmax(sims)       (first maximal index) */
+ISXO_API void isxo_mine_negatives(const float* sim, int64_t N, const int32_t* lab, const int64_t* i1, const int64_t* i2,
+                                  int64_t n_couples, int semi_hard, int64_t* neg) {
+    for (int64_t c = 0; c < n_couples; ++c) {
+        const float* row = sim + i1[c] * N;
+        const float sim_pos = row[i2[c]];
+        int64_t best = -1; float bs = 0.0f;
+        for (int64_t j = 0; j < N; ++j) {
+            int excl = (lab[j] == lab[i1[c]]) || (semi_hard && row[j] >= sim_pos);
+            if (excl) continue;
+            if (best < 0 || row[j] > bs) { best = j; bs = row[j]; }
+        }
+        neg[c] = best;
+    }
+}
+
+/* model/custom_modules.py:153-203 TripletLossFun forward (per-row clamped losses + their sum, divided by B
+ * when size_average) and backward (grad_output = 1). */
+ISXO_API float isxo_triplet_loss(const float* a, const float* p, const float* n, int64_t B, int D, float margin,
+                                 int normalized, int size_average, float* rows, float* ga, float* gp, float* gn) {
+    double total = 0.0;
+    for (int64_t b = 0; b < B; ++b) {
+        double s = 0.0;
+        for (int j = 0; j < D; ++j) {
+            const double av = a[b * D + j], pv = p[b * D + j], nv = n[b * D + j];
+            s += normalized ? (av * nv - av * pv) : ((av - pv) * (av - pv) - (av - nv) * (av - nv));
+        }
+        float l = normalized ? (float)s + margin : ((float)s + 2.0f * margin) * 0.5f;
+        if (l <= 0.0f) l = 0.0f;
+        rows[b] = l; total += l;
+        const float sc = size_average ? 1.0f / (float)B : 1.0f;
+        for (int j = 0; j < D; ++j) {
+            const float av = a[b * D + j], pv = p[b * D + j], nv = n[b * D + j];
+            const int on = l > 0.0f;
+            ga[b * D + j] = on ? (nv - pv) * sc : 0.0f;
+            gp[b * D + j] = on ? (normalized ? -av : pv - av) * sc : 0.0f;
+            gn[b * D + j] = on ? (normalized ? av : av - nv) * sc : 0.0f;
+        }
+    }
+    return (float)(size_average ? total / (double)B : total);
+}

@@ -162,3 +162,22 @@ def precision1(top_idx, qlab, glab, kth=1):
     hit = np.asarray(glab)[np.asarray(top_idx)[:, max(kth, 1) - 1]]
     correct = int((hit == np.asarray(qlab)).sum())
     return correct / float(len(qlab)), correct, len(qlab), hit
+
+
+def mine_negatives(sim, labels, i1, i2, semi_hard):
+    sim = _f32(sim); N = sim.shape[0]
+    labels = np.ascontiguousarray(labels, np.int32)
+    i1 = np.ascontiguousarray(i1, np.int64); i2 = np.ascontiguousarray(i2, np.int64)
+    neg = np.empty_like(i1)
+    lib().isxo_mine_negatives(_p(sim, F32P), C.c_int64(N), _p(labels, I32P), _p(i1, I64P), _p(i2, I64P), C.c_int64(len(i1)),
+                              1 if semi_hard else 0, _p(neg, I64P))
+    return neg
+
+
+def triplet_loss(a, p, n, margin, normalized=True, size_average=True):
+    a, p, n = _f32(a), _f32(p), _f32(n); B, D = a.shape
+    rows = np.empty((B,), np.float32); ga, gp, gn = np.empty_like(a), np.empty_like(a), np.empty_like(a)
+    lib().isxo_triplet_loss.restype = C.c_float
+    loss = lib().isxo_triplet_loss(_p(a, F32P), _p(p, F32P), _p(n, F32P), C.c_int64(B), D, C.c_float(margin),
+                                   1 if normalized else 0, 1 if size_average else 0, _p(rows, F32P), _p(ga, F32P), _p(gp, F32P), _p(gn, F32P))
+    return float(loss), rows, ga, gp, gn

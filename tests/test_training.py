@@ -1,0 +1,232 @@
+"""Siamese triplet training step: losses, negative mining, couple generation, the
+gradient-accumulating training loop and its data-parallel (gloo, world_size 2) execution."""
+import os
+import random
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def test_losses_match_reference_forward(golden):
+    from model.custom_modules import MetricLoss, TripletLoss, TripletLossFun
+    g = golden("training.npz")
+    a, p, n = t(g["a"]), t(g["p"]), t(g["n"])
+    for normalized in (True, False):
+        for avg in (True, False):
+            want = float(g["loss_n%d_a%d" % (normalized, avg)][0])
+            got = TripletLoss(0.1, avg, normalized)(a, p, n)
+            assert got.shape == (1,) and abs(float(got) - want) <= 1e-6
+            assert abs(float(TripletLossFun(0.1, avg, normalized)(a, p, n)) - want) <= 1e-6
+            lo, rows, ga, gp, gn = O.triplet_loss(g["a"], g["p"], g["n"], 0.1, normalized, avg)
+            assert abs(lo - want) <= 1e-6 and (rows == 0).any() and (rows > 0).any()
+            # analytic backward == oracle gradients
+            ar, pr, nr = (x.clone().requires_grad_(True) for x in (a, p, n))
+            TripletLoss(0.1, avg, normalized)(ar, pr, nr).backward()
+            np.testing.assert_allclose(ar.grad.numpy(), ga, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(pr.grad.numpy(), gp, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(nr.grad.numpy(), gn, rtol=1e-6, atol=1e-7)
+    assert abs(float(MetricLoss(True)(a, p, t(g["metric_y"]))) - float(g["metric_loss"][0])) <= 1e-5
+    # backward == derivative of the forward formula (double precision autograd as the judge)
+    ad, pd_, nd = (x.double().clone().requires_grad_(True) for x in (a, p, n))
+    l = ((ad * nd).sum(1) - (ad * pd_).sum(1) + 0.1).clamp(min=0).sum()
+    l.backward()
+    ar, pr, nr = (x.clone().requires_grad_(True) for x in (a, p, n))
+    TripletLoss(0.1, False, True)(ar, pr, nr).backward()
+    np.testing.assert_allclose(ar.grad.numpy(), ad.grad.float().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_mining_cpu_path_matches_reference(golden):
+    from train.siamese_descriptor import mine_epoch_negatives
+    g = golden("training.npz")
+    ds = [(None, int(l), None) for l in g["mine_labels"]]
+    couples = [(int(g["mine_labels"][a]), (int(a), int(b)), (None, None)) for a, b in zip(g["mine_i1"], g["mine_i2"])]
+    for semi in (1, 0):
+        got = mine_epoch_negatives(t(g["mine_sim"]), ds, couples, bool(semi))
+        np.testing.assert_array_equal(got.numpy(), g["neg_semi%d" % semi])
+        np.testing.assert_array_equal(O.mine_negatives(g["mine_sim"], g["mine_labels"], g["mine_i1"], g["mine_i2"], semi), g["neg_semi%d" % semi])
+
+
+def test_pos_couples_and_shuffle():
+    from utils import choose_rand_neg, get_pos_couples
+    from train.siamese_descriptor import shuffle_couples
+    ds = [("x%d" % i, "abcab"[i], None) for i in range(5)]
+    c = get_pos_couples(ds)
+    assert list(c) == ["a", "b", "c"]
+    assert [x[1] for x in c["a"]] == [(0, 0), (0, 3), (3, 3)] and [x[1] for x in c["c"]] == [(2, 2)]
+    assert c["a"][1][2] == ("x0", "x3")
+    assert [x[1] for x in get_pos_couples(ds, duplicate=False)["b"]] == [(1, 4)]
+    random.seed(3)
+    big = get_pos_couples([(i, i % 7, None) for i in range(70)])
+    out = shuffle_couples(big)
+    assert sorted(x[1] for x in out) == sorted(x[1] for v in big.values() for x in v)       # a permutation
+    assert len(set(x[0] for x in out[:7])) == 7                                              # first round covers all labels
+    random.seed(0)
+    assert choose_rand_neg([(0, "a", None), (1, "b", None)], "a") == 1
+
+
+class _TinyNet(nn.Module):
+    """Stands in for DescriptorNet in the loop tests: features + a descriptor head, 3 inputs in training."""
+
+    def __init__(self):
+        super().__init__()
+        self.features = nn.Sequential(nn.Conv2d(3, 4, 3, stride=2), nn.BatchNorm2d(4), nn.ReLU())
+        self.head = nn.Linear(4 * 3 * 3, 8)
+        self.feature_size = 8
+
+    def one(self, x):
+        y = self.head(self.features(x).flatten(1))
+        return y / (y.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()
+
+    def forward(self, a, p=None, n=None):
+        return (self.one(a), self.one(p), self.one(n)) if self.training and n is not None else self.one(a)
+
+
+def _run_training(rank, world, port, out):
+    sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    from model.custom_modules import TripletLoss
+    from train import siamese_descriptor as sd
+    from utils import train_gen
+    import torch.optim as optim
+    torch.manual_seed(0)
+    random.seed(0)
+    net = _TinyNet()
+    P = sd.P
+    P.cuda_device, P.train_epochs, P.train_batch_size, P.train_micro_batch = -1, 2, 8, 2
+    P.train_loss_int, P.train_test_int, P.test_batch_size, P.feature_dim, P.train_seed = 1000, 1000, 8, 8, 5
+    P.train_epoch_switch, P.train_pre_proc, P.train_loss_avg = 1, True, False
+    g = torch.Generator().manual_seed(1)
+    ds = [(torch.randn(3, 8, 8, generator=g), "l%d" % (i % 4), "p%d" % i) for i in range(16)]
+    del sd.labels[:]
+    sd.labels.extend(sorted(set(l for _, l, _ in ds)))
+    opt = optim.SGD(net.parameters(), lr=0.05, momentum=0.9, weight_decay=5e-4)
+    sd.test_print_descriptor = lambda *a, **k: 0            # no evaluation inside this test
+    if world == 1:
+        # train_gen re-seeds `random` per epoch only under DP (identical couple order on all ranks);
+        # the single-process run mimics that seeding so both runs see the same triplets
+        import utils.train_general as tg
+        real_train_gen = tg.train_gen
+
+        def seeded_train_gen(*a, **k):
+            create_epoch = a[8]
+
+            def ce(epoch, train_set, testset_tuple):
+                random.seed(P.train_seed + epoch)
+                return create_epoch(epoch, train_set, testset_tuple)
+            a2 = list(a)
+            a2[8] = ce
+            return real_train_gen(*a2, **k)
+        sd.train_gen = seeded_train_gen
+    sd.train_siam_triplets_pos_couples(net, ds, (ds[:4], ds), TripletLoss(P.triplet_margin, False), opt)
+    if rank == 0:
+        torch.save({k: v.clone() for k, v in net.state_dict().items()}, out)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_data_parallel_training_matches_single_process(tmp_path):
+    """2 ranks x half of every mini-batch + gradient all-reduce == 1 process with the whole mini-batch
+    (gradient accumulation over micro-batches, BatchNorm frozen), after 2 epochs of SGD."""
+    single = str(tmp_path / "single.pt")
+    dp = str(tmp_path / "dp.pt")
+    mp.spawn(_run_training, args=(1, 0, single), nprocs=1, join=True)
+    mp.spawn(_run_training, args=(2, _free_port(), dp), nprocs=2, join=True)
+    a, b = torch.load(single), torch.load(dp)
+    assert set(a) == set(b)
+    moved = 0.0
+    torch.manual_seed(0)
+    init = _TinyNet().state_dict()
+    for k in a:
+        np.testing.assert_allclose(a[k].numpy(), b[k].numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+        moved += float((a[k].float() - init[k].float()).abs().sum())
+    assert moved > 1e-3                                          # training really changed the weights
+    assert torch.equal(a["features.1.running_mean"], init["features.1.running_mean"])     # BN frozen (train_bn False)
+
+
+def test_grad_all_reducer_single_process_is_noop():
+    from isx.dp import GradAllReducer
+    net = _TinyNet()
+    r = GradAllReducer(list(net.parameters()), bucket_mb=0.0001)
+    assert len(r.buckets) > 1 and r.flat.numel() == sum(p.numel() for p in net.parameters())
+    r.zero_grad()
+    x = torch.randn(2, 3, 8, 8)
+    net.train()
+    r.arm()
+    net(x, x, x)[0].sum().backward()
+    r.finish()
+    assert all(p.grad.data_ptr() >= r.flat.data_ptr() for p in net.parameters())          # grads live in the flat buffer
+    assert float(r.flat.abs().sum()) > 0
+
+
+# ------------------------------------------------------------------ GPU kernels
+@pytest.mark.gpu
+def test_mining_and_triplet_kernels(golden):
+    from isx import ops
+    from model.custom_modules import TripletLoss
+    g = golden("training.npz")
+    dev = lambda a: t(a).cuda()
+    for semi in (1, 0):
+        neg = ops.mine_negatives(dev(g["mine_sim"]), dev(g["mine_labels"]), dev(g["mine_i1"]), dev(g["mine_i2"]), semi)
+        np.testing.assert_array_equal(neg.cpu().numpy(), g["neg_semi%d" % semi])
+    rng = np.random.default_rng(0)
+    N = 3000
+    E = O.l2norm_rows(rng.standard_normal((N, 64), dtype=np.float32))
+    E[100] = E[7]
+    sim = O.cosine_sim(E, E)
+    lab = (np.arange(N) % 300).astype(np.int32)
+    i1 = rng.integers(0, N, 500); i2 = (i1 + 300 * rng.integers(0, 9, 500)) % N
+    for semi in (1, 0):
+        neg = ops.mine_negatives(dev(sim), dev(lab), dev(i1), dev(i2), semi)
+        np.testing.assert_array_equal(neg.cpu().numpy(), O.mine_negatives(sim, lab, i1, i2, semi))
+    B, D = 37, 2048
+    a, p, n = (O.l2norm_rows(rng.standard_normal((B, D), dtype=np.float32)) for _ in range(3))
+    p[:10] = O.l2norm_rows(a[:10] + 0.01 * rng.standard_normal((10, D), dtype=np.float32))
+    for normalized in (True, False):
+        lo, rows, ga, gp, gn = O.triplet_loss(a, p, n, 0.1, normalized, True)
+        got = ops.triplet_loss_rows(dev(a), dev(p), dev(n), 0.1, normalized)
+        np.testing.assert_allclose(got.cpu().numpy(), rows, rtol=1e-5, atol=1e-6)
+        ar, pr, nr = (dev(x).requires_grad_(True) for x in (a, p, n))
+        loss = TripletLoss(0.1, True, normalized)(ar, pr, nr)
+        assert abs(float(loss) - lo) <= 1e-5
+        loss.backward()
+        on = got.cpu().numpy() > 0
+        np.testing.assert_allclose(ar.grad.cpu().numpy()[on], ga[on], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(pr.grad.cpu().numpy()[on], gp[on], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(nr.grad.cpu().numpy()[on], gn[on], rtol=1e-6, atol=1e-7)
+        assert float(ar.grad[torch.from_numpy(~on).cuda()].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+def test_training_epoch_on_gpu_reduces_loss():
+    from train import siamese_descriptor as sd
+    from utils.dataset import synthetic_image_set
+    torch.manual_seed(0); random.seed(0)
+    P = sd.P
+    P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "alexnet", (6, 6), 32
+    P.train_epochs, P.train_batch_size, P.train_micro_batch, P.test_batch_size = 2, 8, 4, 16
+    P.train_loss_int, P.untrained_blocks, P.train_epoch_switch, P.train_lr = 1000, 4, 1, 1e-3
+    tr = synthetic_image_set(24, 4, seed=1)
+    te = synthetic_image_set(8, 4, seed=2)
+    net, score = sd.main(tr, tr, te)
+    assert next(net.parameters()).is_cuda and score >= 0
