@@ -10,7 +10,9 @@
 // definition.  K is never split across waves or blocks, so the order is preserved.
 //
 // Tiling (gfx950): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, each
-// wave 64x64 = 2x2 MFMA tiles of 32x32, 64 accumulator VGPRs), BK = 32.  Q and G tiles
+// wave 64x64 = 2x2 MFMA tiles of 32x32, 64 accumulator VGPRs), BK = 16 (124 VGPRs, 16.5 KB LDS:
+// 4 workgroups per CU; measured 133 TFLOP/s vs 130 at BK = 32 and 122 at BK = 8); smaller tiles
+// (64x128, 128x64, 64x64, BK = 32) are picked for mid-size problems.  Q and G tiles
 // are staged K-major in LDS ([k][row], row stride 129 floats): the staging loads are
 // 16 B/lane with 8 lanes covering one 128-B row segment (coalesced), the transposed
 // ds_write_b32 are bank-conflict-free by the odd stride, and the MFMA operand reads are
@@ -24,7 +26,6 @@ namespace isx {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int BK = 32;
 constexpr int GROUP_N = 16;            // n-tiles per scheduling group
 
 struct TileMap {
@@ -47,16 +48,17 @@ __device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int
     tile_n = first_n + within % gsz;
 }
 
-// ROWS x 32 k = ROWS*8 float4; thread t takes idx = j*256 + t: row = idx/8, chunk = idx%8
-template <bool ALIGNED, int ROWS>
+// ROWS x BK k = ROWS*CH float4; thread t takes idx = j*256 + t: row = idx/CH, chunk = idx%CH
+template <bool ALIGNED, int ROWS, int BK>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t rows, int D, int64_t row0, int k0,
-                                          float4 (&reg)[ROWS / 32]) {
+                                          float4 (&reg)[ROWS * BK / 1024]) {
+    constexpr int CH = BK / 4;               // 16-B chunks per staged row
 #pragma unroll
-    for (int j = 0; j < ROWS / 32; ++j) {
+    for (int j = 0; j < ROWS * CH / 256; ++j) {
         const int idx = j * 256 + threadIdx.x;
-        int64_t r = row0 + (idx >> 3);
+        int64_t r = row0 + (idx / CH);
         r = r < rows ? r : rows - 1;                       // clamp: rows past the edge are never stored
-        const int k = k0 + ((idx & 7) << 2);
+        const int k = k0 + ((idx % CH) << 2);
         const float* src = P + r * D + k;
         if (ALIGNED) {
             reg[j] = (k < D) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -69,13 +71,14 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t r
     }
 }
 
-template <int ROWS>
-__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&reg)[ROWS / 32]) {
+template <int ROWS, int BK>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&reg)[ROWS * BK / 1024]) {
+    constexpr int CH = BK / 4;
     constexpr int LD = ROWS + 1;                            // odd K-major stride: conflict-free transposed writes
 #pragma unroll
-    for (int j = 0; j < ROWS / 32; ++j) {
+    for (int j = 0; j < ROWS * CH / 256; ++j) {
         const int idx = j * 256 + threadIdx.x;
-        const int r = idx >> 3, k = (idx & 7) << 2;
+        const int r = idx / CH, k = (idx % CH) << 2;
         T[(k + 0) * LD + r] = reg[j].x;
         T[(k + 1) * LD + r] = reg[j].y;
         T[(k + 2) * LD + r] = reg[j].z;
@@ -84,7 +87,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 }
 
 // Block tile (64*TM) x (64*TN): 4 waves as 2x2, each wave TM x TN MFMA tiles of 32x32.
-template <bool ALIGNED, int TM, int TN, bool FILTER>
+template <bool ALIGNED, int TM, int TN, bool FILTER, int BK>
 __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
                                                           const float* __restrict__ G, int64_t N, int D,
                                                           float* __restrict__ C, int64_t ldc, TileMap tm,
@@ -111,12 +114,12 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-    float4 ra[BM / 32], rb[BN / 32];
+    float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
     const int nk = (D + BK - 1) / BK;
-    load_tile<ALIGNED, BM>(Q, M, D, m0, 0, ra);
-    load_tile<ALIGNED, BN>(G, N, D, n0, 0, rb);
-    store_tile<BM>(As, ra);
-    store_tile<BN>(Bs, rb);
+    load_tile<ALIGNED, BM, BK>(Q, M, D, m0, 0, ra);
+    load_tile<ALIGNED, BN, BK>(G, N, D, n0, 0, rb);
+    store_tile<BM, BK>(As, ra);
+    store_tile<BN, BK>(Bs, rb);
     __syncthreads();
 
     const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
@@ -125,8 +128,8 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
         if (more) {
-            load_tile<ALIGNED, BM>(Q, M, D, m0, (kt + 1) * BK, ra);
-            load_tile<ALIGNED, BN>(G, N, D, n0, (kt + 1) * BK, rb);
+            load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
+            load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
         }
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
@@ -142,8 +145,8 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
         }
         __syncthreads();
         if (more) {
-            store_tile<BM>(As, ra);
-            store_tile<BN>(Bs, rb);
+            store_tile<BM, BK>(As, ra);
+            store_tile<BN, BK>(Bs, rb);
             __syncthreads();
         }
     }
@@ -186,11 +189,11 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
 // smallest estimated time  rounds(T tiles over S slots) * tile_work / efficiency  -- large
 // problems get 128x128, mid-size ones (bench: 512 x 10k) avoid a half-empty last round.
 struct TileCfg { int tm, tn, wg_per_cu; float eff; };
-static const TileCfg kCfgs[] = { {2, 2, 2, 0.83f}, {1, 2, 4, 0.79f}, {2, 1, 4, 0.805f}, {1, 1, 6, 0.72f} };
+static const TileCfg kCfgs[] = { {2, 2, 4, 0.845f}, {1, 2, 4, 0.79f}, {2, 1, 4, 0.805f}, {1, 1, 6, 0.72f} };
 static int g_force_cfg = -1;            // debug / A-B hook
 void set_gemm_cfg(int c) { g_force_cfg = c; }
 
-template <int TM, int TN>
+template <int TM, int TN, int BK>
 static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
                        const float* thr, uint8_t* gmax, hipStream_t st) {
     TileMap tm;
@@ -199,11 +202,11 @@ static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, 
     const int ngrp = (int)((N + 31) / 32);
     const dim3 grid((unsigned)(tm.tiles_m * tm.tiles_n)), block(256);
     if (gmax) {
-        if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
-        else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
+        if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, true, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
+        else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, true, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
     } else {
-        if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
-        else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
+        if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, false, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
+        else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, false, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
     }
 }
 
@@ -218,21 +221,21 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
         const TileCfg& k = kCfgs[c];
         const double tiles = (double)((M + 64 * k.tm - 1) / (64 * k.tm)) * (double)((N + 64 * k.tn - 1) / (64 * k.tn));
         const double slots = 256.0 * k.wg_per_cu;
-        // time in units of "one full round" = wg_per_cu tiles per CU.  128x128 tiles run in lock-step
-        // rounds (the last, partial one costs a whole round); the smaller shapes keep 4-6 workgroups
-        // per CU, finish unevenly and only pay a fraction of a round as tail (fitted on MI355X)
-        double rounds = tiles / slots;
-        if (c == 0) rounds = (double)(long long)(rounds + 0.999999);
-        else rounds += (c == 3 ? 0.15 : 0.25);
+        // time in units of "one full round" (= wg_per_cu tiles on every CU).  Workgroups finish unevenly,
+        // so a launch costs its tile count plus a tail that is ~0.2 round for launches below one round and
+        // fades quadratically for longer ones (fitted on MI355X, 256 ... 10k query rows x 10k ... 100k)
+        const double x = tiles / slots;
+        const double t0 = (c == 0 ? 0.22 : c == 3 ? 0.15 : 0.25);
+        const double rounds = x + (x <= 0.7 ? t0 : t0 * (0.7 / x) * (0.7 / x));
         const double t = rounds * k.wg_per_cu * (k.tm * k.tn) / k.eff;
         if (t < best_t) { best_t = t; best = c; }
     }
     if (g_force_cfg >= 0 && g_force_cfg < 4) best = g_force_cfg;
     switch (best) {
-        case 0: launch_cfg<2, 2>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
-        case 1: launch_cfg<1, 2>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
-        case 2: launch_cfg<2, 1>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
-        default: launch_cfg<1, 1>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
+        case 0: launch_cfg<2, 2, 16>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
+        case 1: launch_cfg<1, 2, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
+        case 2: launch_cfg<2, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
+        default: launch_cfg<1, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
     }
     ISX_CHECK_LAUNCH("cosine_gemm");
     return ISX_OK;

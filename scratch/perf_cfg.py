@@ -19,7 +19,7 @@ want = O.cosine_sim(Qs.cpu().numpy(), Gs.cpu().numpy())
 for c in range(4):
     lib.isx_debug_set_gemm_cfg(c)
     print("cfg", c, "bit-exact:", np.array_equal(ops.cosine_sim(Qs, Gs).cpu().numpy(), want))
-for (M, N) in [(512, 10000), (2048, 10000), (10000, 32768)]:
+for (M, N) in [(256, 10000), (512, 10000), (1024, 10000), (2048, 10000), (4096, 10000), (1000, 100000), (10000, 32768)]:
     Q = torch.randn(M, D, device="cuda"); G = torch.randn(N, D, device="cuda"); out = torch.empty(M, N, device="cuda")
     res = []
     for c in (0, 1, 2, 3, -1):
