@@ -14,15 +14,15 @@ def timeit(f, n=5, w=2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 D = 2048
-Qs = ops.l2norm_rows(torch.randn(130, 464, device="cuda")); Gs = ops.l2norm_rows(torch.randn(257, 464, device="cuda"))
+Qs = ops.l2norm_rows(torch.randn(130, 2048, device="cuda")); Gs = ops.l2norm_rows(torch.randn(257, 2048, device="cuda"))
 want = O.cosine_sim(Qs.cpu().numpy(), Gs.cpu().numpy())
-for c in range(4):
+for c in (0, 4):
     lib.isx_debug_set_gemm_cfg(c)
     print("cfg", c, "bit-exact:", np.array_equal(ops.cosine_sim(Qs, Gs).cpu().numpy(), want))
-for (M, N) in [(256, 10000), (512, 10000), (1024, 10000), (2048, 10000), (4096, 10000), (1000, 100000), (10000, 32768)]:
+for (M, N) in [(2048, 10000), (1000, 100000), (10000, 32768)]:
     Q = torch.randn(M, D, device="cuda"); G = torch.randn(N, D, device="cuda"); out = torch.empty(M, N, device="cuda")
     res = []
-    for c in (0, 1, 2, 3, -1):
+    for c in (0, 4):
         lib.isx_debug_set_gemm_cfg(c)
         ms = timeit(lambda: ops.cosine_sim(Q, G, out=out))
         res.append("%s %.3fms %.1fTF" % ("auto" if c < 0 else "c%d" % c, ms, 2*M*N*D/ms/1e9))
