@@ -76,16 +76,17 @@ int isx_best_location_desc(const float* cls, int64_t B, int K, int Hp, int Wp, f
                            int64_t* loc, isx_stream_t stream);
 
 /* model/siamese.py:191-194: c_maxv = c.max(1).view(-1); topk(min(len,k)) in canonical
- * order.  cls: (K,Hp,Wp) of ONE image; flat_idx, score: (k); entries past Hp*Wp are
- * (-1, -inf).  Hp*Wp <= 4096. */
-int isx_region_topk(const float* cls, int K, int Hp, int Wp, int k, int64_t* flat_idx, float* score,
+ * order, for every image of a batch (the reference walks one image per call, :184).
+ * cls: (B,K,Hp,Wp); flat_idx, score: (B,k); entries past Hp*Wp are (-1, -inf).  Hp*Wp <= 4096. */
+int isx_region_topk(const float* cls, int64_t B, int K, int Hp, int Wp, int k, int64_t* flat_idx, float* score,
                     isx_stream_t stream);
 
-/* model/siamese.py:199-219: for each of the k windows (row,col) = (idx / Wp, idx % Wp):
- * x[:, :, row:row+kh, col:col+kw] flattened (C,h,w) -> NormalizeL2 -> Shift.
- * fmap: (C,Hf,Wf) of ONE image; rows: (k, C*kh*kw); shift (C*kh*kw) or NULL.
- * Windows with flat_idx < 0 produce zero rows. */
-int isx_region_gather_l2(const float* fmap, int C, int Hf, int Wf, int kh, int kw, const int64_t* flat_idx, int k,
+/* model/siamese.py:199-219: for each of the k windows of each image, (row,col) = (idx / Wp, idx % Wp):
+ * x[b, :, row:row+kh, col:col+kw] flattened (C,h,w) -> NormalizeL2 -> Shift.
+ * fmap: (B,C,Hf,Wf); flat_idx: (B,k); rows: (B, k, C*kh*kw); shift (C*kh*kw) or NULL.
+ * Windows with flat_idx < 0 produce zero rows.  The caller applies the Linear ONCE to all B*k rows
+ * (the 100352 x D weight is then streamed once per batch, not once per window as in the reference). */
+int isx_region_gather_l2(const float* fmap, int64_t B, int C, int Hf, int Wf, int kh, int kw, const int64_t* flat_idx, int k,
                          int Wp, const float* shift, float eps, float* rows, isx_stream_t stream);
 
 /* ---- retrieval ------------------------------------------------------------- */

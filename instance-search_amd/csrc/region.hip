@@ -47,10 +47,13 @@ __global__ __launch_bounds__(256) void best_location_desc_kernel(const float* __
     if (threadIdx.x == 0) { loc[blockIdx.x * 2] = row; loc[blockIdx.x * 2 + 1] = col; }
 }
 
-// Single block: class-max per location -> keys in LDS -> bitonic sort -> first k.
-__global__ __launch_bounds__(256) void region_topk_kernel(const float* __restrict__ cls, int K, int P, int PP2, int k,
-                                                          int64_t* __restrict__ flat_idx, float* __restrict__ score) {
+// One block per image: class-max per location -> keys in LDS -> bitonic sort -> first k.
+__global__ __launch_bounds__(256) void region_topk_kernel(const float* __restrict__ cls_all, int K, int P, int PP2, int k,
+                                                          int64_t* __restrict__ flat_idx_all, float* __restrict__ score_all) {
     extern __shared__ __attribute__((aligned(16))) uint64_t keys[];
+    const float* cls = cls_all + (int64_t)blockIdx.x * K * P;
+    int64_t* flat_idx = flat_idx_all + (int64_t)blockIdx.x * k;
+    float* score = score_all + (int64_t)blockIdx.x * k;
     for (int p = threadIdx.x; p < PP2; p += 256) {
         uint64_t key = 0;
         if (p < P) {
@@ -67,17 +70,19 @@ __global__ __launch_bounds__(256) void region_topk_kernel(const float* __restric
     }
 }
 
-// One 1024-thread block per window: pass 1 sum of squares over the gathered C*kh*kw
+// One 1024-thread block per (window, image): pass 1 sum of squares over the gathered C*kh*kw
 // values, pass 2 normalise (+shift) and write the row.
-__global__ __launch_bounds__(1024) void region_gather_l2_kernel(const float* __restrict__ fmap, int C, int Hf, int Wf, int kh,
+__global__ __launch_bounds__(1024) void region_gather_l2_kernel(const float* __restrict__ fmap_all, int C, int Hf, int Wf, int kh,
                                                                 int kw, const int64_t* __restrict__ flat_idx, int Wp,
                                                                 const float* __restrict__ shift, float eps,
                                                                 float* __restrict__ rows) {
     __shared__ float red[16];
     const int khw = kh * kw;
     const int F = C * khw;
-    float* out = rows + (int64_t)blockIdx.x * F;
-    const int64_t fi = flat_idx[blockIdx.x];
+    const int64_t w = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;       // window id: image-major
+    const float* fmap = fmap_all + (int64_t)blockIdx.y * C * Hf * Wf;
+    float* out = rows + w * F;
+    const int64_t fi = flat_idx[w];
     const int row = (int)(fi / Wp), col = (int)(fi % Wp);
     if (fi < 0 || row + kh > Hf || col + kw > Wf) {   // padding entry or out-of-range index: zero row, no gather
         for (int j = threadIdx.x; j < F; j += 1024) out[j] = 0.0f;
@@ -114,26 +119,27 @@ ISX_API int isx_best_location_desc(const float* cls, int64_t B, int K, int Hp, i
     return ISX_OK;
 }
 
-ISX_API int isx_region_topk(const float* cls, int K, int Hp, int Wp, int k, int64_t* flat_idx, float* score,
+ISX_API int isx_region_topk(const float* cls, int64_t B, int K, int Hp, int Wp, int k, int64_t* flat_idx, float* score,
                             isx_stream_t stream) {
-    ISX_REQUIRE(K > 0 && Hp > 0 && Wp > 0 && k > 0, "isx_region_topk: bad shape K=%d Hp=%d Wp=%d k=%d", K, Hp, Wp, k);
+    ISX_REQUIRE(B >= 0 && B < 65536 && K > 0 && Hp > 0 && Wp > 0 && k > 0, "isx_region_topk: bad shape B=%lld K=%d Hp=%d Wp=%d k=%d", (long long)B, K, Hp, Wp, k);
+    if (B == 0) return ISX_OK;
     const int64_t P = (int64_t)Hp * Wp;
     ISX_REQUIRE(P <= 4096, "isx_region_topk: Hp*Wp=%lld exceeds 4096 locations", (long long)P);
     ISX_REQUIRE(cls && flat_idx && score, "isx_region_topk: null pointer");
     const int PP2 = next_pow2((int)P < 2 ? 2 : (int)P);
-    hipLaunchKernelGGL(region_topk_kernel, dim3(1), dim3(256), (size_t)PP2 * 8, (hipStream_t)stream, cls, K, (int)P, PP2, k, flat_idx, score);
+    hipLaunchKernelGGL(region_topk_kernel, dim3((unsigned)B), dim3(256), (size_t)PP2 * 8, (hipStream_t)stream, cls, K, (int)P, PP2, k, flat_idx, score);
     ISX_CHECK_LAUNCH("isx_region_topk");
     return ISX_OK;
 }
 
-ISX_API int isx_region_gather_l2(const float* fmap, int C, int Hf, int Wf, int kh, int kw, const int64_t* flat_idx, int k,
+ISX_API int isx_region_gather_l2(const float* fmap, int64_t B, int C, int Hf, int Wf, int kh, int kw, const int64_t* flat_idx, int k,
                                  int Wp, const float* shift, float eps, float* rows, isx_stream_t stream) {
-    ISX_REQUIRE(C > 0 && Hf > 0 && Wf > 0 && kh > 0 && kw > 0 && kh <= Hf && kw <= Wf && k >= 0 && Wp == Wf - kw + 1,
+    ISX_REQUIRE(B >= 0 && B < 65536 && C > 0 && Hf > 0 && Wf > 0 && kh > 0 && kw > 0 && kh <= Hf && kw <= Wf && k >= 0 && Wp == Wf - kw + 1,
                 "isx_region_gather_l2: bad shape C=%d Hf=%d Wf=%d k=%dx%d n=%d Wp=%d", C, Hf, Wf, kh, kw, k, Wp);
     ISX_REQUIRE((int64_t)C * kh * kw < (1ll << 31), "isx_region_gather_l2: window too large");
     ISX_REQUIRE(fmap && flat_idx && rows, "isx_region_gather_l2: null pointer");
-    if (k == 0) return ISX_OK;
-    hipLaunchKernelGGL(region_gather_l2_kernel, dim3((unsigned)k), dim3(1024), 0, (hipStream_t)stream, fmap, C, Hf, Wf, kh, kw,
+    if (k == 0 || B == 0) return ISX_OK;
+    hipLaunchKernelGGL(region_gather_l2_kernel, dim3((unsigned)k, (unsigned)B), dim3(1024), 0, (hipStream_t)stream, fmap, C, Hf, Wf, kh, kw,
                        flat_idx, Wp, shift, eps, rows);
     ISX_CHECK_LAUNCH("isx_region_gather_l2");
     return ISX_OK;

@@ -24,8 +24,8 @@ _SIGNATURES = {
     "isx_gap_l2_nhwc": (C.c_int, [VP, I64, I32, I32, I32, F32, VP, VP]),
     "isx_boxpool_s1": (C.c_int, [VP, I64, I32, I32, I32, I32, I32, VP, VP]),
     "isx_best_location_desc": (C.c_int, [VP, I64, I32, I32, I32, F32, VP, VP, VP]),
-    "isx_region_topk": (C.c_int, [VP, I32, I32, I32, I32, VP, VP, VP]),
-    "isx_region_gather_l2": (C.c_int, [VP, I32, I32, I32, I32, I32, VP, I32, I32, VP, F32, VP, VP]),
+    "isx_region_topk": (C.c_int, [VP, I64, I32, I32, I32, I32, VP, VP, VP]),
+    "isx_region_gather_l2": (C.c_int, [VP, I64, I32, I32, I32, I32, I32, VP, I32, I32, VP, F32, VP, VP]),
     "isx_cosine_sim": (C.c_int, [VP, I64, VP, I64, I32, VP, VP]),
     "isx_cosine_topk_workspace": (SZ, [I64, I64, I32, I32]),
     "isx_cosine_topk": (C.c_int, [VP, I64, VP, I64, I32, I32, I64, VP, VP, VP, SZ, VP]),

@@ -87,27 +87,38 @@ def best_location_desc(cls, eps=EPS):
 
 
 def region_topk(cls, k):
+    """Canonical top-k locations of the class-max map.  cls (K,Hp,Wp) -> (idx (k), score (k));
+    cls (B,K,Hp,Wp) -> (idx (B,k), score (B,k))."""
     cls = _f32(cls, "cls")
-    K, Hp, Wp = cls.shape[-3:]
-    idx = torch.empty((k,), device=cls.device, dtype=torch.int64)
-    sc = torch.empty((k,), device=cls.device, dtype=torch.float32)
-    check(lib().isx_region_topk(cls.data_ptr(), K, Hp, Wp, k, idx.data_ptr(), sc.data_ptr(), _stream()), "isx_region_topk")
-    return idx, sc
+    single = cls.dim() == 3
+    if single:
+        cls = cls.unsqueeze(0)
+    B, K, Hp, Wp = cls.shape
+    idx = torch.empty((B, k), device=cls.device, dtype=torch.int64)
+    sc = torch.empty((B, k), device=cls.device, dtype=torch.float32)
+    check(lib().isx_region_topk(cls.data_ptr(), B, K, Hp, Wp, k, idx.data_ptr(), sc.data_ptr(), _stream()), "isx_region_topk")
+    return (idx[0], sc[0]) if single else (idx, sc)
 
 
 def region_gather_l2(fmap, kh, kw, flat_idx, Wp, shift=None, eps=EPS):
+    """Window gather + L2 + Shift.  fmap (C,Hf,Wf), flat_idx (k) -> rows (k,F); batched: fmap (B,C,Hf,Wf),
+    flat_idx (B,k) -> rows (B,k,F)."""
     fmap = _f32(fmap, "fmap")
-    Cc, Hf, Wf = fmap.shape[-3:]
     flat_idx = _typed(flat_idx, torch.int64, "flat_idx")
-    k = flat_idx.numel()
-    rows = torch.empty((k, Cc * kh * kw), device=fmap.device, dtype=torch.float32)
+    single = fmap.dim() == 3
+    if single:
+        fmap, flat_idx = fmap.unsqueeze(0), flat_idx.reshape(1, -1)
+    B, Cc, Hf, Wf = fmap.shape
+    k = flat_idx.size(1)
+    assert flat_idx.shape == (B, k)
+    rows = torch.empty((B, k, Cc * kh * kw), device=fmap.device, dtype=torch.float32)
     sp = 0
     if shift is not None:
         shift = _f32(shift, "shift")
         sp = shift.data_ptr()
-    check(lib().isx_region_gather_l2(fmap.data_ptr(), Cc, Hf, Wf, kh, kw, flat_idx.data_ptr(), k, Wp, sp, eps,
+    check(lib().isx_region_gather_l2(fmap.data_ptr(), B, Cc, Hf, Wf, kh, kw, flat_idx.data_ptr(), k, Wp, sp, eps,
                                      rows.data_ptr(), _stream()), "isx_region_gather_l2")
-    return rows
+    return rows[0] if single else rows
 
 
 def cosine_sim(Q, G, out=None):

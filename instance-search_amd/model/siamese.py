@@ -172,11 +172,29 @@ class RegionDescriptorNet(nn.Module):
         cls_out[0, :, :k] = c[0].reshape(c.size(1), -1)[:, flat_idx]
         return self.feature_reduc2(acc), cls_out
 
+    def _batched_gpu(self, x, c):
+        """Whole batch at once on the GPU: top-k windows of every image in one launch, all B*k window rows
+        gathered + normalised + shifted in one launch, ONE Linear over the (B*k, F) rows (the F x D weight is
+        streamed once per batch instead of once per window), per-image sum, L2."""
+        from isx import ops
+        B = x.size(0)
+        kh, kw = self.feature_size2d
+        k = min(c.size(2) * c.size(3), self.k)
+        flat_idx, _ = ops.region_topk(c.float(), k)                                   # (B, k)
+        rows = ops.region_gather_l2(x.float(), kh, kw, flat_idx, c.size(3), self.feature_reduc1[1].param.detach())
+        lin = self.feature_reduc1[2]
+        acc = F.linear(rows.view(B * k, -1), lin.weight, lin.bias).view(B, k, -1).sum(1)
+        cls_out = c.new_zeros(B, c.size(1), self.k)
+        cls_out[:, :, :k] = c.flatten(2).gather(2, flat_idx[:, None, :].expand(B, c.size(1), k))
+        return self.feature_reduc2(acc), cls_out
+
     def forward_single(self, x):
-        # the reference handles one image per call (model/siamese.py:184); a batch is walked image
-        # by image here (feature maps of one batch share a shape, the top-k windows do not)
+        # the reference handles one image per call (model/siamese.py:184); here a batch of same-sized
+        # images goes through together on the GPU, and image by image on the autograd / CPU path
         x = self.features(x)
         c = self.classifier(self.feature_reduc(x))
+        if _fast(x):
+            return self._batched_gpu(x, c)
         outs = [self._single_image(x[b:b + 1], c[b:b + 1]) for b in range(x.size(0))]
         return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)
 

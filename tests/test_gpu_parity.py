@@ -126,6 +126,23 @@ def test_region_topk_and_gather(ops, K, Hp, Wp, k):
     assert (rows[n:] == 0).all()
 
 
+def test_region_batched(ops):
+    """Batched region_topk / region_gather_l2 == the per-image calls == the oracle."""
+    rng = np.random.default_rng(9)
+    B, K, Hp, Wp, C, fs, k = 5, 17, 8, 6, 10, 3, 7
+    cls = rng.standard_normal((B, K, Hp, Wp), dtype=np.float32)
+    fmap = rng.standard_normal((B, C, Hp + fs - 1, Wp + fs - 1), dtype=np.float32)
+    sh = rng.standard_normal((C * fs * fs,), dtype=np.float32) * 0.05
+    idx, sc = ops.region_topk(dev(cls), k)
+    rows = ops.region_gather_l2(dev(fmap), fs, fs, idx, Wp, dev(sh))
+    assert idx.shape == (B, k) and rows.shape == (B, k, C * fs * fs)
+    for b in range(B):
+        oi, osc = O.region_topk(cls[b], k)
+        np.testing.assert_array_equal(host(idx)[b], oi)
+        np.testing.assert_array_equal(host(sc)[b], osc)
+        np.testing.assert_allclose(host(rows)[b], O.region_gather_l2(fmap[b], fs, fs, oi, Wp, sh), rtol=2e-6, atol=1e-7)
+
+
 def test_region_descriptor_golden(ops, golden):
     g = golden("region_desc.npz")
     for tag, k in (("k3", 3), ("k40", 40)):
