@@ -32,7 +32,7 @@ def test_argument_validation_without_gpu():
     assert lib.isx_cosine_sim(None, -1, None, 4, 8, None, None) == -1
     assert b"bad shape" in lib.isx_last_error()
     assert lib.isx_cosine_topk(None, 4, None, 4, 8, 0, 0, None, None, None, 0, None) == -1
-    assert lib.isx_region_topk(None, 4, 100, 100, 3, None, None, None) == -1
+    assert lib.isx_region_topk(None, 1, 4, 100, 100, 3, None, None, None) == -1
     assert b"4096" in lib.isx_last_error()
     assert lib.isx_topk_merge(None, None, 8, 4, 1024, None, None, None) == -1
     # empty problems are no-ops
