@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Side measurements of the other BASELINE configs on one MI355X (not the driver's bench line):
+extraction rate of the four approaches, retrieval + metric rates at config 2/3 scale.
+Prints one JSON object.   python tools/bench_paths.py [--quick]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
+import torch  # noqa: E402
+
+from isx import backbones, ops  # noqa: E402
+from model.siamese import DescriptorNet, RegionDescriptorNet, TuneClassif, TuneClassifSub  # noqa: E402
+from train import classif_regions as cr  # noqa: E402
+from utils.dataset import synthetic_descriptors  # noqa: E402
+
+
+def timed(f, n=3, w=1):
+    for _ in range(w):
+        f()
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(n):
+        f()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / n
+
+
+def main():
+    quick = "--quick" in sys.argv
+    out = {}
+    dev = "cuda"
+    with torch.no_grad():
+        # ---- extraction (fp32, channels-last activations, synthetic images)
+        x224 = torch.randn(256, 3, 224, 224, device=dev).to(memory_format=torch.channels_last)
+        x448 = torch.randn(64, 3, 448, 448, device=dev).to(memory_format=torch.channels_last)
+        cl = lambda m: m.to(dev).to(memory_format=torch.channels_last).eval()
+        g = cl(TuneClassif(backbones.resnet50(pretrained=True), 464))
+        slab = torch.empty(256, 2048, device=dev)
+        t = timed(lambda: ops.gap_l2(g.features(x224), out=slab))
+        out["extract_global_resnet50_224"] = {"images_per_s": 256 / t}
+        sub = cl(TuneClassifSub(backbones.resnet50(pretrained=True), 464, (7, 7)))
+        t = timed(lambda: cr._best_location_descriptors(sub(x448)[0]))
+        out["extract_classif_regions_resnet50_448"] = {"images_per_s": 64 / t, "map": "8x8 locations, 464 classes"}
+        dn = cl(DescriptorNet(backbones.resnet50(pretrained=True), 2048, (7, 7)))
+        t = timed(lambda: dn(x224))
+        out["extract_siamese_descriptor_resnet50_224"] = {"images_per_s": 256 / t, "head": "Linear(100352->2048)"}
+        rd = cl(RegionDescriptorNet(backbones.resnet50(pretrained=True), 6, 2048, (7, 7)))
+        t = timed(lambda: rd(x448))
+        out["extract_siamese_regions_resnet50_448"] = {"images_per_s": 64 / t, "k": 6}
+        a = cl(TuneClassif(backbones.alexnet(pretrained=True), 464))
+        a.classifier = torch.nn.Sequential()
+        t = timed(lambda: ops.l2norm_rows(a(x224)))
+        out["extract_global_alexnet_224"] = {"images_per_s": 256 / t}
+        del g, sub, dn, rd, a, x224, x448
+        torch.cuda.empty_cache()
+        # ---- retrieval + metrics
+        for (M, N) in ((1000, 10000),) + (() if quick else ((1000, 100000),)):
+            Q, G, ql, gl = synthetic_descriptors(N, M, 2048, device=dev)
+            Q, G = ops.l2norm_rows(Q), ops.l2norm_rows(G)
+            sim = torch.empty(M, N, device=dev)
+            t_sim = timed(lambda: ops.cosine_sim(Q, G, out=sim))
+            t_ap = timed(lambda: ops.average_precision_sim(sim, ql, gl))
+            t_p1 = timed(lambda: ops.topk_rows(sim, 1))
+            t_rank = timed(lambda: ops.average_precision(ops.rank_full(sim), ql, gl), n=2)
+            ap = ops.average_precision_sim(sim, ql, gl).cpu()
+            out["retrieval_%dx%d" % (M, N)] = {
+                "cosine_sim_ms": t_sim * 1e3, "tflops": 2.0 * M * N * 2048 / t_sim / 1e12, "dist_per_s": M * N / t_sim,
+                "ap_sort_free_ms": t_ap * 1e3, "p_at_1_ms": t_p1 * 1e3, "rank_full_plus_ap_ms": t_rank * 1e3,
+                "mAP": float(ap[~ap.isnan()].mean())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
