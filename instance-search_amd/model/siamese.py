@@ -76,7 +76,7 @@ class TuneClassif(nn.Module):
     def forward(self, x):
         x = self.features(x)
         x = self.feature_reduc(x)
-        return self.classifier(x.view(x.size(0), -1))
+        return self.classifier(x.reshape(x.size(0), -1))     # logical (C,h,w) order whatever the memory format
 
 
 class TuneClassifSub(TuneClassif):
