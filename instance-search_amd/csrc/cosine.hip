@@ -338,15 +338,14 @@ ISX_API int isx_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N
             if (rc) return rc;
             rc = launch_select(chunk, M, w, w, c0, k, carry, first, last, idx_base, top_score, top_idx, st, thr);
         } else if (first) {
-            // bootstrap chunk: plain GEMM, every group flagged, empty carry (all-zero keys sort last)
+            // bootstrap chunk: plain GEMM, every group present, empty carry (all-zero keys sort last)
             rc = launch_cosine_gemm(Q, M, G + c0 * D, w, D, chunk, w, st);
             if (rc) return rc;
-            if (hipMemsetAsync(gmax, 1, (size_t)M * ((w + 31) / 32), st) != hipSuccess ||
-                hipMemsetAsync(carry, 0, (size_t)M * k * 8, st) != hipSuccess) {
+            if (hipMemsetAsync(carry, 0, (size_t)M * k * 8, st) != hipSuccess) {
                 isx_set_error("isx_cosine_topk: hipMemsetAsync failed");
                 return ISX_ERR_HIP;
             }
-            rc = launch_select_groups(chunk, gmax, M, w, w, c0, k, carry, thr, last, idx_base, top_score, top_idx, st);
+            rc = launch_select_groups(chunk, nullptr /* all groups present */, M, w, w, c0, k, carry, thr, last, idx_base, top_score, top_idx, st);
         } else {
             rc = launch_cosine_gemm_filter(Q, M, G + c0 * D, w, D, chunk, w, thr, gmax, st);
             if (rc) return rc;

@@ -129,6 +129,46 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
     int cnt = k;                                   // uniform
     bool dirty = false;
 
+    if (!gf) {
+        // every group present (isx_topk_rows, bootstrap chunk): plain streaming scan, 256 scores per step
+        // (16-B loads when the row is 16-B aligned), append by shuffle prefix
+        const bool vec = ((((uintptr_t)r) & 15) == 0);
+        for (int64_t j0 = 0; j0 < Nc; j0 += 256) {
+            if (cnt > GS_CAP - 256) {                  // room for a full step
+                __syncthreads();
+                bitonic_sort_desc<64>(buf, GS_CAP);
+                for (int i = k + lane; i < GS_CAP; i += 64) buf[i] = 0ull;
+                __syncthreads();
+                cnt = k;
+                thr_key = buf[k - 1];
+                dirty = false;
+            }
+            const int64_t j = j0 + (int64_t)lane * 4;
+            float vv[4];
+            if (vec && j + 3 < Nc) {
+                const float4 v = *reinterpret_cast<const float4*>(r + j);
+                vv[0] = v.x; vv[1] = v.y; vv[2] = v.z; vv[3] = v.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) vv[q] = (j + q < Nc) ? r[j + q] : 0.0f;
+            }
+            uint64_t key[4];
+            bool take[4];
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                key[q] = (j + q < Nc) ? rank_key(vv[q], col_base + (uint32_t)(j + q)) : 0ull;
+                take[q] = key[q] > thr_key;
+                c += take[q] ? 1 : 0;
+            }
+            int total;
+            int off = cnt + wave_excl_prefix(c, lane, total);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (take[q]) buf[off++] = key[q];
+            cnt += total;
+            dirty = dirty || (total > 0);
+        }
+    } else
     for (int g0 = 0; g0 < ngrp; g0 += 64) {
         const int g = g0 + lane;
         const bool q = (g < ngrp) && (!gf || gf[g] != 0);
