@@ -47,19 +47,24 @@ def parse():
     ap.add_argument("--memory-format", default="channels_last", choices=["channels_last", "contiguous"],
                     help="layout of the backbone activations (same fp32 math; MIOpen's NHWC kernels are ~9%% faster); "
                          "isx_gap_l2 consumes either layout in place")
+    ap.add_argument("--no-fold-bn", action="store_true",
+                    help="keep BatchNorm as separate kernels (default: folded into the convolutions for inference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard-bench", action="store_true", help="skip the 10k x 125k retrieval-shard side measurement")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
 
-def build_net(name, dtype, device, channels_last=False):
+def build_net(name, dtype, device, channels_last=False, fold_bn=False):
     from isx import backbones
     from model.nn_utils import set_net_train
     from model.siamese import TuneClassif
     torch.manual_seed(0)
     net = TuneClassif(backbones.MODELS[name](pretrained=True, seed=0), 464)
     set_net_train(net, False)
+    if fold_bn:
+        from model.nn_utils import fold_batch_norm
+        net.features = fold_batch_norm(net.features)
     net = net.to(device)
     if dtype == "bf16" or channels_last:
         net = net.to(memory_format=torch.channels_last)
@@ -136,7 +141,7 @@ def main():
     _, G_cpu, _, _ = synthetic_descriptors(Ng, 1, D, seed=rank)
     shard = ops.l2norm_rows(G_cpu.to(dev))
     gallery = retrieval.ShardedGallery(shard, idx_base=rank * Ng)
-    net = build_net(args.backbone, args.backbone_dtype, dev, channels_last=cl)
+    net = build_net(args.backbone, args.backbone_dtype, dev, channels_last=cl, fold_bn=not args.no_fold_bn)
     q_local = torch.empty((B, D), device=dev)
     M = B * world
     sim = torch.empty((M, Ng), device=dev)
@@ -213,7 +218,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: ResNet-50 fully-conv global descriptors + top-%d cosine search, "
                                    "%d-row gallery shard per GPU, 224x224 synthetic images" % (k, Ng),
                        "images_per_gpu_per_step": B, "gallery_rows_per_gpu": Ng, "descriptor_dim": D, "k": k,
-                       "backbone": args.backbone, "backbone_dtype": args.backbone_dtype, "activation_layout": "NHWC" if cl else "NCHW", "parallelism": "gallery-row shards x%d + DP extraction" % world},
+                       "backbone": args.backbone, "backbone_dtype": args.backbone_dtype, "activation_layout": "NHWC" if cl else "NCHW", "bn_folded": not args.no_fold_bn, "parallelism": "gallery-row shards x%d + DP extraction" % world},
             "dist_per_s": images_per_s * Ng * world,
             "roofline": {"kernel": "cosine_gemm_kernel (isx_cosine_sim, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                          "achieved": gemm_flop / (gemm_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -113,6 +113,25 @@ def test_nn_utils():
     assert not w.training
 
 
+def test_fold_batch_norm_is_the_same_function():
+    from isx import backbones
+    from model.nn_utils import extract_layers, fold_batch_norm
+    torch.manual_seed(0)
+    for ctor in (backbones.resnet18, backbones.resnet50):
+        net = ctor(pretrained=True).eval()
+        for m in net.modules():                      # non-trivial running statistics
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+        feats, _, _ = extract_layers(net)
+        folded = fold_batch_norm(feats)
+        assert not any(isinstance(m, nn.BatchNorm2d) for m in folded.modules())
+        assert any(isinstance(m, nn.BatchNorm2d) for m in feats.modules())          # the original is untouched
+        x = torch.randn(2, 3, 64, 64)
+        with torch.no_grad():
+            a, b = feats(x), folded(x)
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max())
+
+
 def test_backbone_state_dict_keys_are_torchvision_compatible():
     from isx import backbones
     keys = list(backbones.resnet50().state_dict())
