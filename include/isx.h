@@ -62,6 +62,14 @@ int isx_gap_l2(const float* fmap, int64_t B, int C, int H, int W, float eps, flo
  * kernels of the backbone produce.  Same summation order, same result.  y: (B,C). */
 int isx_gap_l2_nhwc(const float* fmap, int64_t B, int C, int H, int W, float eps, float* y, isx_stream_t stream);
 
+/* Fused epilogue of the inference trunk's convolutions (BatchNorm folded, model/nn_utils.py fold_batch_norm):
+ * y[i] = act(y[i] + bias[c(i)] + (residual ? residual[i] : 0)), in place, c(i) = (i / inner) % C
+ * (inner = 1 for channels-last memory, H*W for NCHW), act = ReLU when relu != 0.  Replaces the separate
+ * bias-add / residual-add / ReLU kernels that follow every convolution (reference blocks:
+ * torchvision Bottleneck via model/nn_utils.py:56-71). */
+int isx_bias_act_inplace(float* y, const float* bias, const float* residual, int64_t n, int C, int64_t inner, int relu,
+                         isx_stream_t stream);
+
 /* model/siamese.py:67-71 nn.AvgPool2d(feature_size2d, stride=1) of TuneClassifSub /
  * RegionDescriptorNet.  fmap: (B,C,H,W); out: (B,C,H-kh+1,W-kw+1). */
 int isx_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out,

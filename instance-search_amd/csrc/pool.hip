@@ -368,3 +368,60 @@ ISX_API int isx_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, in
     ISX_CHECK_LAUNCH("isx_boxpool_s1");
     return ISX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Fused convolution epilogue for the inference trunk: y = act(y + bias[c] (+ residual)), in place.
+// After BatchNorm folding every convolution of the backbone is followed by bias-add, (residual add,)
+// ReLU; as separate framework kernels those are 4 (7 at the end of a residual block) full passes
+// over the activation; fused they are 2 (3).  HBM-bound streaming, 16-B accesses.
+// Channel of element i: (i / inner) % C  -- inner = 1 for channels-last (NHWC) memory, H*W for NCHW.
+namespace isx {
+
+template <bool NHWC4>
+__global__ __launch_bounds__(256) void bias_act_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                       const float* __restrict__ res, int64_t n4, int C, int64_t inner,
+                                                       int relu) {
+    float4* y4 = reinterpret_cast<float4*>(y);
+    const float4* r4 = reinterpret_cast<const float4*>(res);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 v = y4[i];
+        float4 b;
+        if (NHWC4) {
+            b = *reinterpret_cast<const float4*>(bias + (int)((i * 4) % C));          // C % 4 == 0: 4 consecutive channels
+        } else {
+            const float bb = bias[(int)(((i * 4) / inner) % C)];                        // inner % 4 == 0: one channel
+            b = make_float4(bb, bb, bb, bb);
+        }
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        if (res) { const float4 r = r4[i]; v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+        if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        y4[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_act_scalar_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                              const float* __restrict__ res, int64_t n, int C, int64_t inner,
+                                                              int relu) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = y[i] + bias[(int)((i / inner) % C)] + (res ? res[i] : 0.0f);
+        y[i] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+}  // namespace isx
+
+ISX_API int isx_bias_act_inplace(float* y, const float* bias, const float* residual, int64_t n, int C, int64_t inner, int relu,
+                                 isx_stream_t stream) {
+    ISX_REQUIRE(n >= 0 && C > 0 && inner > 0, "isx_bias_act_inplace: bad shape n=%lld C=%d inner=%lld", (long long)n, C, (long long)inner);
+    if (n == 0) return ISX_OK;
+    ISX_REQUIRE(y && bias, "isx_bias_act_inplace: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const bool al = (((uintptr_t)y | (uintptr_t)residual | (uintptr_t)bias) % 16 == 0) && (n % 4 == 0);
+    const int64_t n4 = n / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+    if (al && inner == 1 && C % 4 == 0) hipLaunchKernelGGL(isx::bias_act_kernel<true>, dim3(grid ? grid : 1), dim3(256), 0, st, y, bias, residual, n4, C, inner, relu);
+    else if (al && inner % 4 == 0) hipLaunchKernelGGL(isx::bias_act_kernel<false>, dim3(grid ? grid : 1), dim3(256), 0, st, y, bias, residual, n4, C, inner, relu);
+    else hipLaunchKernelGGL(isx::bias_act_scalar_kernel, dim3((unsigned)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384)), dim3(256), 0, st, y, bias, residual, n, C, inner, relu);
+    ISX_CHECK_LAUNCH("isx_bias_act_inplace");
+    return ISX_OK;
+}

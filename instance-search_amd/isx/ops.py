@@ -68,6 +68,28 @@ def gap_l2(fmap, eps=EPS, out=None):
     return y
 
 
+def bias_act_(y, bias, residual=None, relu=True):
+    """In place y = act(y + bias[channel] (+ residual)) on a dense (B,C,H,W) tensor in NCHW or channels-last
+    memory (the residual must share y's memory format)."""
+    if not (y.is_cuda and y.dtype == torch.float32):
+        raise _lib.IsxError("y must be a float32 CUDA tensor")
+    B, Cc, H, W = y.shape
+    if y.is_contiguous():
+        inner = H * W
+    elif y.is_contiguous(memory_format=torch.channels_last):
+        inner = 1
+    else:
+        raise _lib.IsxError("y must be dense NCHW or channels-last")
+    rp = 0
+    if residual is not None:
+        if residual.shape != y.shape or residual.stride() != y.stride() or residual.dtype != torch.float32:
+            raise _lib.IsxError("residual must match y's shape, dtype and memory format")
+        rp = residual.data_ptr()
+    check(lib().isx_bias_act_inplace(y.data_ptr(), _f32(bias, "bias").data_ptr(), rp, y.numel(), Cc, inner, 1 if relu else 0, _stream()),
+          "isx_bias_act_inplace")
+    return y
+
+
 def boxpool_s1(fmap, kh, kw):
     fmap = _f32(fmap, "fmap")
     B, Cc, H, W = fmap.shape

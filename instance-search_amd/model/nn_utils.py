@@ -71,31 +71,87 @@ def extract_layers(net):
     return net.features, nn.Sequential(), net.classifier
 
 
-def fold_batch_norm(features):
+class _ConvBiasAct(nn.Module):
+    """Bias-free convolution + fused `y = act(y + bias (+ residual))` epilogue (libisx `isx_bias_act_inplace` on
+    the GPU, plain torch otherwise)."""
+
+    def __init__(self, conv, relu):
+        super().__init__()
+        bias = conv.bias.detach().clone() if conv.bias is not None else torch.zeros(conv.out_channels)
+        self.conv = nn.Conv2d(conv.in_channels, conv.out_channels, conv.kernel_size, conv.stride, conv.padding, conv.dilation,
+                              conv.groups, bias=False)
+        self.conv.weight = nn.Parameter(conv.weight.detach().clone(), requires_grad=False)
+        self.bias = nn.Parameter(bias, requires_grad=False)
+        self.relu = relu
+
+    def forward(self, x, residual=None):
+        y = self.conv(x)
+        if y.is_cuda and y.dtype == torch.float32 and not torch.is_grad_enabled():
+            from isx import ops
+            if residual is not None and residual.stride() != y.stride():
+                residual = residual.contiguous(memory_format=torch.channels_last if not y.is_contiguous() else torch.contiguous_format)
+            return ops.bias_act_(y, self.bias, residual, self.relu)
+        y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
+        if residual is not None:
+            y = y + residual
+        return torch.relu(y) if self.relu else y
+
+
+class _FusedBlock(nn.Module):
+    """Inference form of a (BN-folded) BasicBlock / Bottleneck: relu(convN(...) + bias + identity) with every
+    bias / residual / ReLU fused into one in-place pass per convolution."""
+
+    def __init__(self, convs, downsample):
+        super().__init__()
+        self.convs = nn.ModuleList([_ConvBiasAct(c, relu=True) for c in convs])
+        self.downsample = _ConvBiasAct(downsample, relu=False) if downsample is not None else None
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        y = x
+        for c in self.convs[:-1]:
+            y = c(y)
+        return self.convs[-1](y, idt)
+
+
+def fold_batch_norm(features, fuse_epilogues=True):
     """Inference-only copy of a `features` trunk with every eval-mode BatchNorm2d folded into the
     convolution in front of it (w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps)).
-    Same function up to fp32 rounding (max relative deviation ~2e-6 on the ResNet-50 map); it removes one
-    read + write of every activation, worth +15 % images/s on the fp32 ResNet-50 trunk.  Not part of the
-    reference (its BN helpers, model/nn_utils.py:74-155, only copy / re-create / freeze BN layers)."""
+    Same function up to fp32 rounding (max relative deviation ~2e-6 on the ResNet-50 map).  With
+    `fuse_epilogues` the bias-add / residual-add / ReLU after each convolution run as ONE in-place HIP kernel
+    (`isx_bias_act_inplace`) instead of 4-7 separate passes over the activation.  Not part of the reference
+    (its BN helpers, model/nn_utils.py:74-155, only copy / re-create / freeze BN layers)."""
     import copy
     from torch.nn.utils.fusion import fuse_conv_bn_eval
 
     def fold_block(b):
-        b = copy.deepcopy(b)
-        for conv, bn in (('conv1', 'bn1'), ('conv2', 'bn2'), ('conv3', 'bn3')):
-            if hasattr(b, conv):
-                setattr(b, conv, fuse_conv_bn_eval(getattr(b, conv).eval(), getattr(b, bn).eval()))
-                setattr(b, bn, nn.Identity())
+        convs = [fuse_conv_bn_eval(copy.deepcopy(getattr(b, c)).eval(), copy.deepcopy(getattr(b, n)).eval())
+                 for c, n in (('conv1', 'bn1'), ('conv2', 'bn2'), ('conv3', 'bn3')) if hasattr(b, c)]
+        down = None
         if b.downsample is not None:
-            b.downsample = nn.Sequential(fuse_conv_bn_eval(b.downsample[0].eval(), b.downsample[1].eval()))
+            down = fuse_conv_bn_eval(copy.deepcopy(b.downsample[0]).eval(), copy.deepcopy(b.downsample[1]).eval())
+        if fuse_epilogues:
+            return _FusedBlock(convs, down)
+        b = copy.deepcopy(b)
+        for i, (c, n) in enumerate((('conv1', 'bn1'), ('conv2', 'bn2'), ('conv3', 'bn3'))):
+            if hasattr(b, c):
+                setattr(b, c, convs[i])
+                setattr(b, n, nn.Identity())
+        if down is not None:
+            b.downsample = nn.Sequential(down)
         return b
 
     mods, out, i = list(features), [], 0
     while i < len(mods):
         m = mods[i]
         if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
-            out.append(fuse_conv_bn_eval(copy.deepcopy(m).eval(), copy.deepcopy(mods[i + 1]).eval()))
+            conv = fuse_conv_bn_eval(copy.deepcopy(m).eval(), copy.deepcopy(mods[i + 1]).eval())
             i += 2
+            if fuse_epilogues and i < len(mods) and isinstance(mods[i], nn.ReLU):
+                out.append(_ConvBiasAct(conv, relu=True))      # conv + BN + ReLU -> conv, one fused epilogue
+                i += 1
+            else:
+                out.append(conv)
             continue
         out.append(fold_block(m) if isinstance(m, (models.Bottleneck, models.BasicBlock)) else copy.deepcopy(m))
         i += 1

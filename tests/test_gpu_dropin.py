@@ -131,6 +131,43 @@ def test_entry_point_on_gpu_matches_oracle(capsys, monkeypatch):
     assert O.precision1(ti, ql, gl)[0] == p1
 
 
+def test_bias_act_and_folded_trunk():
+    from isx import backbones, ops
+    from model.nn_utils import extract_layers, fold_batch_norm
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for shape in ((3, 8, 5, 7), (2, 64, 56, 56), (1, 6, 3, 3), (4, 2048, 7, 7)):
+        for cl in (False, True):
+            y = torch.randn(*shape, device="cuda", generator=g)
+            r = torch.randn(*shape, device="cuda", generator=g)
+            b = torch.randn(shape[1], device="cuda", generator=g)
+            if cl:
+                y, r = y.to(memory_format=torch.channels_last), r.to(memory_format=torch.channels_last)
+            for res in (None, r):
+                for relu in (True, False):
+                    want = y + b.view(1, -1, 1, 1) + (0 if res is None else res)
+                    want = torch.relu(want) if relu else want
+                    got = ops.bias_act_(y.clone(memory_format=torch.preserve_format), b, res, relu)
+                    assert torch.equal(got, want), (shape, cl, res is not None, relu)
+    torch.manual_seed(0)
+    net = backbones.resnet50(pretrained=True).eval()
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.1)
+    feats, _, _ = extract_layers(net)
+    feats = feats.cuda()
+    x = torch.randn(4, 3, 224, 224, device="cuda")
+    with torch.no_grad():
+        ref = feats(x)
+        for cl in (False, True):
+            f2 = fold_batch_norm(feats).cuda()
+            xi = x
+            if cl:
+                f2, xi = f2.to(memory_format=torch.channels_last), x.to(memory_format=torch.channels_last)
+            out = f2(xi)
+            assert float((out - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+            np.testing.assert_allclose(host(ops.gap_l2(out)), host(ops.gap_l2(ref)), rtol=1e-4, atol=1e-6)
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
