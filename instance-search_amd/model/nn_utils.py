@@ -99,12 +99,17 @@ class _ConvBiasAct(nn.Module):
 
 class _FusedBlock(nn.Module):
     """Inference form of a (BN-folded) BasicBlock / Bottleneck: relu(convN(...) + bias + identity) with every
-    bias / residual / ReLU fused into one in-place pass per convolution."""
+    bias / residual / ReLU fused into one in-place pass per convolution.  The projection shortcut keeps no
+    epilogue of its own: its bias is added to the last convolution's bias."""
 
     def __init__(self, convs, downsample):
         super().__init__()
         self.convs = nn.ModuleList([_ConvBiasAct(c, relu=True) for c in convs])
-        self.downsample = _ConvBiasAct(downsample, relu=False) if downsample is not None else None
+        self.downsample = None
+        if downsample is not None:
+            d = _ConvBiasAct(downsample, relu=False)
+            self.downsample = d.conv                                        # bias-free projection
+            self.convs[-1].bias = nn.Parameter(self.convs[-1].bias + d.bias, requires_grad=False)
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
