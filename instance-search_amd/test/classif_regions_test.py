@@ -4,7 +4,7 @@ from __future__ import print_function
 
 import sys
 
-from model.nn_utils import set_net_train
+from train._common import prepare_for_inference
 from train.classif_regions import P, get_class_net, get_embeddings, labels, test_classif_net
 from train.global_p import feature_sizes, image_sizes
 from . import _common as C
@@ -31,7 +31,7 @@ def main(dataset_full, model, weights, device, dba):
 
     print('Testing network on dataset with ID {0}'.format(dataset_id))
     class_net = get_class_net()
-    set_net_train(class_net, False)
+    prepare_for_inference(class_net, P)
     c, t = test_classif_net(class_net, test_set)
     print('Classification (TEST): {0} / {1} - acc: {2:.4f}'.format(c, t, float(c) / t))
     test_embeddings = get_embeddings(class_net, test_set, device, len(labels))

@@ -4,7 +4,7 @@ from __future__ import print_function
 
 import sys
 
-from model.nn_utils import set_net_train
+from train._common import prepare_for_inference
 from train.global_p import feature_sizes, image_sizes
 from train.siamese_regions import P, get_embeddings, get_siamese_net, labels
 from . import _common as C
@@ -35,7 +35,7 @@ def main(dataset_full, model, weights, device, feature_dim, regions_k, dba):
 
     print('Testing network on dataset with ID {0}'.format(dataset_id))
     net = get_siamese_net()
-    set_net_train(net, False)
+    prepare_for_inference(net, P)
     test_embeddings = get_embeddings(net, test_set, device, net.feature_size)
     ref_embeddings = get_embeddings(net, test_train_set, device, net.feature_size)
     return C.evaluate_retrieval(test_embeddings, ref_embeddings, test_set, test_train_set, device, labels, dba)

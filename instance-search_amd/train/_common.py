@@ -28,3 +28,13 @@ def load_weights(net, fname):
     if fname:
         net.load_state_dict(torch.load(fname, map_location='cpu'))
     return net
+
+
+def prepare_for_inference(net, P):
+    """eval mode (+ BatchNorm folding / fused epilogues when P.fold_bn): call once before get_embeddings."""
+    from model.nn_utils import fold_batch_norm, set_net_train
+    set_net_train(net, False)
+    if getattr(P, 'fold_bn', False) and any(isinstance(m, torch.nn.BatchNorm2d) for m in net.features.modules()):
+        dev = next(net.parameters()).device
+        net.features = fold_batch_norm(net.features).to(dev)
+    return net

@@ -58,65 +58,72 @@ def _dp():
     return (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
 
 
-def micro_batch_gen(last, i, is_final, batch, P, net, create_batch, batch_args, create_loss, reducer=None):
-    prev_val, mini_batch_size = last
-    n = len(batch)
-    tensors_in, labels_in = create_batch(batch, n, **batch_args)
-    tensors_out = net(*tensors_in)
-    loss, loss2 = create_loss(tensors_out, labels_in)
-    loss_micro = loss * n / mini_batch_size if P.train_loss_avg else loss
-    val = float(loss_micro.detach().reshape(-1)[0])
-    if loss2 is not None:
-        loss2_micro = loss2 * n / mini_batch_size if P.train_loss2_avg else loss2
-        loss_micro = loss_micro + P.train_loss2_alpha * loss2_micro
-        val += P.train_loss2_alpha * float(loss2_micro.detach().reshape(-1)[0])
-    if reducer is not None and is_final:
-        reducer.arm()                                # overlap the bucketed all-reduce with this last backward
-    loss_micro.backward()
-    return prev_val + val, mini_batch_size
+class _Stepper(object):
+    """One optimizer step = gradient accumulation over the micro-batches of this rank's slice of a mini-batch
+    (reference utils/train_general.py:51-74: micro_batch_gen / mini_batch_gen), then -- data parallel -- the
+    bucketed gradient all-reduce, overlapped with the backward of the last micro-batch."""
 
+    def __init__(self, P, net, make_batch, make_loss, reducer):
+        self.P, self.net, self.make_batch, self.make_loss, self.reducer = P, net, make_batch, make_loss, reducer
+        self.rank, self.world = _dp()
 
-def mini_batch_gen(last, i, is_final, batch, train_type, P, test_print, test_net, net, optimizer, testset_tuple, epoch, micro_args,
-                   reducer=None):
-    batch_count, score, running_loss = last
-    rank, world = _dp()
-    if reducer is not None:
-        reducer.zero_grad()
-    else:
-        optimizer.zero_grad()
-    lo, hi = (len(batch) * rank) // world, (len(batch) * (rank + 1)) // world
-    mine = batch[lo:hi]
-    args = dict(micro_args)
-    args['reducer'] = reducer
-    loss, _ = fold_batches(micro_batch_gen, (0.0, len(batch)), mine, P.train_micro_batch, add_args=args) if mine else (0.0, len(batch))
-    if reducer is not None:
-        reducer.finish()
-    if world > 1:
-        t = torch.tensor([loss], dtype=torch.float64, device=next(net.parameters()).device)
-        dist.all_reduce(t)
-        loss = float(t.item())
-    optimizer.step()
-    running_loss, score = output_stats(train_type, P, test_print, test_net, net, testset_tuple, epoch, batch_count, is_final, loss,
-                                       running_loss, score)
-    return batch_count + 1, score, running_loss
+    def _accumulate(self, total, start, is_last, triplets, mini_size, batch_args):
+        P = self.P
+        inputs, targets = self.make_batch(triplets, len(triplets), **batch_args)
+        loss, loss2 = self.make_loss(self.net(*inputs), targets)
+        share = len(triplets) / float(mini_size)
+        obj = loss * share if P.train_loss_avg else loss
+        if loss2 is not None:
+            obj = obj + P.train_loss2_alpha * (loss2 * share if P.train_loss2_avg else loss2)
+        if self.reducer is not None and is_last:
+            self.reducer.arm()                       # exchange buckets as this last backward fills them
+        obj.backward()
+        return total + float(obj.detach().reshape(-1)[0])
+
+    def step(self, optimizer, mini_batch, batch_args):
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            optimizer.zero_grad()
+        n = len(mini_batch)
+        mine = mini_batch[(n * self.rank) // self.world:(n * (self.rank + 1)) // self.world]
+        loss = 0.0
+        if mine:
+            loss = fold_batches(self._accumulate, 0.0, mine, self.P.train_micro_batch,
+                                add_args={'mini_size': n, 'batch_args': batch_args})
+        if self.reducer is not None:
+            self.reducer.finish()
+        if self.world > 1:
+            t = torch.tensor([loss], dtype=torch.float64, device=next(self.net.parameters()).device)
+            dist.all_reduce(t)
+            loss = float(t.item())
+        optimizer.step()
+        return loss
 
 
 def train_gen(train_type, P, test_print, test_net, net, train_set, testset_tuple, optimizer, create_epoch, create_batch, create_loss,
               best_score=0):
+    """Generic training driver (reference utils/train_general.py:77-105): per epoch anneal -> create_epoch ->
+    mini-batches of P.train_batch_size (a trailing partial one is dropped) -> statistics / evaluation."""
     set_net_train(net, True, bn_train=P.train_bn)
     rank, world = _dp()
     reducer = None
     if world > 1:
         from isx.dp import GradAllReducer
         reducer = GradAllReducer(list(net.parameters()))
+    stepper = _Stepper(P, net, create_batch, create_loss, reducer)
     for epoch in range(P.train_epochs):
         optimizer = anneal(net, optimizer, epoch, P.train_annealing)
         if world > 1:
             random.seed(getattr(P, 'train_seed', 0) + epoch)    # identical couple order on every rank
         dataset, batch_args = create_epoch(epoch, train_set, testset_tuple)
-        micro_args = {'P': P, 'net': net, 'create_batch': create_batch, 'batch_args': batch_args, 'create_loss': create_loss}
-        mini_args = {'train_type': train_type, 'P': P, 'test_print': test_print, 'test_net': test_net, 'net': net,
-                     'optimizer': optimizer, 'testset_tuple': testset_tuple, 'epoch': epoch, 'micro_args': micro_args,
-                     'reducer': reducer}
-        _, best_score, _ = fold_batches(mini_batch_gen, (0, best_score, 0.0), dataset, P.train_batch_size, cut_end=True, add_args=mini_args)
+
+        def one(state, start, is_final, mini_batch):
+            count, score, running = state
+            loss = stepper.step(optimizer, mini_batch, batch_args)
+            running, score = output_stats(train_type, P, test_print, test_net, net, testset_tuple, epoch, count, is_final, loss,
+                                          running, score)
+            return count + 1, score, running
+
+        _, best_score, _ = fold_batches(one, (0, best_score, 0.0), dataset, P.train_batch_size, cut_end=True)
     return best_score
