@@ -36,7 +36,13 @@ def main():
         # ---- extraction (fp32, channels-last activations, synthetic images)
         x224 = torch.randn(256, 3, 224, 224, device=dev).to(memory_format=torch.channels_last)
         x448 = torch.randn(64, 3, 448, 448, device=dev).to(memory_format=torch.channels_last)
-        cl = lambda m: m.to(dev).to(memory_format=torch.channels_last).eval()
+        from model.nn_utils import fold_batch_norm
+
+        def cl(m):
+            m = m.eval()
+            if any(isinstance(x, torch.nn.BatchNorm2d) for x in m.features.modules()):
+                m.features = fold_batch_norm(m.features)        # inference trunk: BN folded, fused epilogues
+            return m.to(dev).to(memory_format=torch.channels_last)
         g = cl(TuneClassif(backbones.resnet50(pretrained=True), 464))
         slab = torch.empty(256, 2048, device=dev)
         t = timed(lambda: ops.gap_l2(g.features(x224), out=slab))
