@@ -164,6 +164,22 @@ def test_data_parallel_training_matches_single_process(tmp_path):
     assert torch.equal(a["features.1.running_mean"], init["features.1.running_mean"])     # BN frozen (train_bn False)
 
 
+def test_region_training_runs_and_learns_on_cpu():
+    """siamese_regions training (triplet + window classification loss, micro-batch 1) end to end on a tiny set."""
+    from train import siamese_regions as sr
+    from utils.dataset import synthetic_image_set
+    torch.manual_seed(0); random.seed(0)
+    P = sr.P
+    P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim, P.regions_k = -1, "alexnet", (6, 6), 16, 3
+    P.train_epochs, P.train_batch_size, P.test_batch_size, P.train_loss_int, P.untrained_blocks = 1, 4, 4, 1000, 4
+    P.train_lr, P.train_epoch_switch = 1e-3, 1
+    tr = synthetic_image_set(8, 2, size=(3, 288, 288), seed=1)
+    te = synthetic_image_set(4, 2, size=(3, 288, 288), seed=2)
+    before = None
+    net, score = sr.main(tr, tr, te)
+    assert score >= 0 and any(p.grad is not None and float(p.grad.abs().sum()) > 0 for p in net.parameters() if p.requires_grad)
+
+
 def test_grad_all_reducer_single_process_is_noop():
     from isx.dp import GradAllReducer
     net = _TinyNet()
