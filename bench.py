@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=512, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=1024, help="images per GPU per step")
     ap.add_argument("--gallery", type=int, default=10000, help="gallery rows per GPU")
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--backbone", default="resnet50")

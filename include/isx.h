@@ -113,6 +113,17 @@ size_t isx_cosine_topk_workspace(int64_t M, int64_t N, int D, int k);
 int isx_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N, int D, int k, int64_t idx_base,
                     float* top_score, int64_t* top_idx, void* ws, size_t ws_bytes, isx_stream_t stream);
 
+/* ---- exact top-k with a half-precision filter (csrc/fast.hip) -------------------------------------
+ * Same call sites and the SAME RESULT, bit for bit, as isx_cosine_topk; the bulk of the arithmetic runs
+ * on the fp16 matrix cores (16x the fp32 MFMA rate) and only the candidates that can reach the top-k are
+ * re-scored with the exact fp32 fma chain.  Building blocks: */
+
+/* x (B,D) fp32 -> h (B,D) fp16 (round to nearest even), norm2[b] >= sum_j x^2, amax[b] = max_j |x|. */
+int isx_rows_to_f16(const float* x, int64_t B, int D, void* h, float* norm2, float* amax, isx_stream_t stream);
+
+/* approximate scores Qh . Gh^T (fp16 operands, fp32 accumulate).  D % 8 == 0, 16-B aligned operands. */
+int isx_cosine_sim_f16(const void* Qh, int64_t M, const void* Gh, int64_t N, int D, float* sim, isx_stream_t stream);
+
 /* utils/metrics.py:10-13 sim.max(1) / sim.kthvalue(...) on a materialised matrix: the k
  * best columns per row, canonical order.  sim: (M,N).  1 <= k <= 1024. */
 int isx_topk_rows(const float* sim, int64_t M, int64_t N, int k, int64_t idx_base, float* top_score,

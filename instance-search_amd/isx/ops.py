@@ -311,3 +311,25 @@ def triplet_loss_grads(anchor, pos, neg, loss_rows, scale, normalized=True):
                                      float(scale), 1 if normalized else 0, ga.data_ptr(), gp.data_ptr(), gn.data_ptr(), _stream()),
           "isx_triplet_loss_bwd")
     return ga, gp, gn
+
+
+# ---- half-precision filter path (csrc/fast.hip) ----------------------------------------------------
+def rows_to_f16(x):
+    """(h (B,D) float16, norm2 (B) upper bound of the squared row norm, amax (B) max |x|)."""
+    x = _f32(x, "x")
+    B, D = x.shape
+    h = torch.empty((B, D), device=x.device, dtype=torch.float16)
+    n2 = torch.empty((B,), device=x.device, dtype=torch.float32)
+    am = torch.empty((B,), device=x.device, dtype=torch.float32)
+    check(lib().isx_rows_to_f16(x.data_ptr(), B, D, h.data_ptr(), n2.data_ptr(), am.data_ptr(), _stream()), "isx_rows_to_f16")
+    return h, n2, am
+
+
+def cosine_sim_f16(Qh, Gh, out=None):
+    assert Qh.dtype == torch.float16 and Gh.dtype == torch.float16 and Qh.is_cuda and Gh.is_cuda
+    Qh, Gh = Qh.contiguous(), Gh.contiguous()
+    M, D = Qh.shape
+    N = Gh.shape[0]
+    sim = torch.empty((M, N), device=Qh.device, dtype=torch.float32) if out is None else out
+    check(lib().isx_cosine_sim_f16(Qh.data_ptr(), M, Gh.data_ptr(), N, D, sim.data_ptr(), _stream()), "isx_cosine_sim_f16")
+    return sim

@@ -60,7 +60,7 @@ def main():
         traffic = {"cosine_gemm_kernel": {}}
         for grid, tot in out.get("cosine_gemm_kernel", {}).items():
             tiles = int(grid) // 256
-            for shape, t in (("512x10000x2048", 4 * 79), ("512x10000x2048", 8 * 157), ("10000x32768x2048", 79 * 256)):
+            for shape, t in (("512x10000x2048", 8 * 157), ("1024x10000x2048", 8 * 157), ("10000x32768x2048", 79 * 256)):
                 if tiles == t:
                     traffic["cosine_gemm_kernel"][shape] = tot
         json.dump(traffic, open(os.path.join(HERE, "roofline_traffic.json"), "w"), indent=1)
