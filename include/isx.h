@@ -124,6 +124,19 @@ int isx_rows_to_f16(const float* x, int64_t B, int D, void* h, float* norm2, flo
 /* approximate scores Qh . Gh^T (fp16 operands, fp32 accumulate).  D % 8 == 0, 16-B aligned operands. */
 int isx_cosine_sim_f16(const void* Qh, int64_t M, const void* Gh, int64_t N, int D, float* sim, isx_stream_t stream);
 
+/* Gallery preparation, once per shard: Gh (N,D) fp16 = RNE(G * 2^s) with the power of two that brings
+ * max|G| into [2^13, 2^14); gstats[2] (device) = {max_j |g_j|^2 (upper bound), max |G|}. */
+int isx_gallery_to_f16(const float* G, int64_t N, int D, void* Gh, float* gstats, isx_stream_t stream);
+
+/* The search.  Gh/gstats: the cached output of isx_gallery_to_f16, or both NULL (converted per call into
+ * the workspace).  Output identical to isx_cosine_topk(Q, M, G, N, D, k, idx_base, ...) for every input:
+ * rows whose candidate window cannot be proven complete, k > 128, D % 8 != 0, unaligned or tiny galleries
+ * and out-of-range magnitudes all run the exact fp32 search. */
+size_t isx_cosine_topk_fast_workspace(int64_t M, int64_t N, int D, int k, int have_gallery_f16);
+int isx_cosine_topk_fast(const float* Q, int64_t M, const float* G, int64_t N, int D, int k, int64_t idx_base,
+                         const void* Gh, const float* gstats, float* top_score, int64_t* top_idx, void* ws,
+                         size_t ws_bytes, isx_stream_t stream);
+
 /* utils/metrics.py:10-13 sim.max(1) / sim.kthvalue(...) on a materialised matrix: the k
  * best columns per row, canonical order.  sim: (M,N).  1 <= k <= 1024. */
 int isx_topk_rows(const float* sim, int64_t M, int64_t N, int k, int64_t idx_base, float* top_score,

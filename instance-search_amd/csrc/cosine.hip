@@ -30,6 +30,7 @@ constexpr int GROUP_N = 16;            // n-tiles per scheduling group
 
 struct TileMap {
     int tiles_m, tiles_n;
+    const int* m_active;       // optional device scalar: only rows < *m_active are live (fast.hip fallback)
 };
 
 __device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int& tile_n) {
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
     int tile_m, tile_n;
     tile_of_block(tm, tile_m, tile_n);
     const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    if (tm.m_active && m0 >= *tm.m_active) return;          // uniform: whole tile beyond the live rows
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -195,8 +197,9 @@ void set_gemm_cfg(int c) { g_force_cfg = c; }
 
 template <int TM, int TN, int BK>
 static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                       const float* thr, uint8_t* gmax, hipStream_t st) {
+                       const float* thr, uint8_t* gmax, hipStream_t st, const int* m_active) {
     TileMap tm;
+    tm.m_active = m_active;
     tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
     tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
     const int ngrp = (int)((N + 31) / 32);
@@ -211,7 +214,7 @@ static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, 
 }
 
 static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                           const float* thr, uint8_t* gmax, hipStream_t st) {
+                           const float* thr, uint8_t* gmax, hipStream_t st, const int* m_active = nullptr) {
     if (M == 0 || N == 0) return ISX_OK;
     if (((M + 63) / 64) * ((N + 63) / 64) >= (1ll << 31)) { isx_set_error("cosine gemm: too many tiles for one grid"); return ISX_ERR_ARG; }
     const bool aligned = (D % 4 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);
@@ -232,22 +235,120 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     }
     if (g_force_cfg >= 0 && g_force_cfg < 4) best = g_force_cfg;
     switch (best) {
-        case 0: launch_cfg<2, 2, 16>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
-        case 1: launch_cfg<1, 2, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
-        case 2: launch_cfg<2, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
-        default: launch_cfg<1, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st); break;
+        case 0: launch_cfg<2, 2, 16>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active); break;
+        case 1: launch_cfg<1, 2, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active); break;
+        case 2: launch_cfg<2, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active); break;
+        default: launch_cfg<1, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active); break;
     }
     ISX_CHECK_LAUNCH("cosine_gemm");
     return ISX_OK;
 }
 
-int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc, hipStream_t st) {
-    return launch_gemm_any(Q, M, G, N, D, C, ldc, nullptr, nullptr, st);
+int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc, hipStream_t st,
+                       const int* m_active) {
+    return launch_gemm_any(Q, M, G, N, D, C, ldc, nullptr, nullptr, st, m_active);
 }
 
 int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                              const float* thr, uint8_t* gmax, hipStream_t st) {
-    return launch_gemm_any(Q, M, G, N, D, C, ldc, thr, gmax, st);
+                              const float* thr, uint8_t* gmax, hipStream_t st, const int* m_active) {
+    return launch_gemm_any(Q, M, G, N, D, C, ldc, thr, gmax, st, m_active);
+}
+
+// Workspace layout of isx_cosine_topk:
+//   [ carry keys: M*k u64 | thr: M f32 | group flags: M*ceil(Nc/32) u8 | score chunk: M*Nc f32 ]
+// The first column chunk (<= kFirstChunk columns) is materialised and selected in full; it leaves a
+// per-row lower bound thr of the final k-th score.  Every later chunk runs the FILTERING GEMM: only
+// 32-column groups whose best score reaches thr are stored and read back, so for typical data the
+// M x N matrix is never written -- just one float per 32 scores.  Exact for any data: in the worst
+// case (every group qualifies) the chunk is simply materialised in full, as in round 0.
+constexpr int64_t kFirstChunk = 8192;
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// ---- chunked running top-k driver (shared by isx_cosine_topk and the fast path of fast.hip) ------
+size_t topk_fixed_bytes(int64_t M, int k) { return align256((size_t)M * k * 8) + align256((size_t)M * 4); }
+size_t topk_chunk_bytes(int64_t M, int64_t nc) { return align256((size_t)M * ((nc + 31) / 32)) + (size_t)M * nc * 4; }
+
+int64_t topk_recommended_chunk(int64_t M, int64_t N) {
+    // whole matrix if it is <= 1 GiB, else column chunks of ~1 GiB (multiple of 2048 columns)
+    const size_t budget = (size_t)1 << 30;
+    int64_t nc = N;
+    if ((size_t)M * N * 4 > budget) {
+        nc = (int64_t)(budget / ((size_t)M * 4));
+        nc = nc / 2048 * 2048;
+        if (nc < 2048) nc = 2048;
+        if (nc > N) nc = N;
+    }
+    return nc;
+}
+
+int run_topk_chunks(const TopkJob& j) {
+    const int64_t M = j.M, N = j.N;
+    const int k = j.k, D = j.D;
+    hipStream_t st = j.st;
+    const size_t fixed_b = topk_fixed_bytes(M, k);
+    const int64_t min_nc = N < 128 ? N : 128;
+    if (!j.ws || ((uintptr_t)j.ws % 256) != 0 || j.ws_bytes < fixed_b + topk_chunk_bytes(M, min_nc)) {
+        isx_set_error("%s: workspace of %zu bytes too small or misaligned (need >= %zu, 256-B aligned)", j.who, j.ws_bytes,
+                      fixed_b + topk_chunk_bytes(M, min_nc));
+        return ISX_ERR_WORKSPACE;
+    }
+    // largest chunk width (multiple of 128 unless it covers N) whose flags + scores fit
+    int64_t nc = (int64_t)((j.ws_bytes - fixed_b) / ((size_t)M * 4));
+    if (nc > N) nc = N;
+    while (nc > min_nc && topk_chunk_bytes(M, nc) > j.ws_bytes - fixed_b) nc -= (nc > 4096 ? 1024 : 128);
+    if (nc < N) nc = nc >= 128 ? nc / 128 * 128 : nc;
+    if (nc < N && nc >= 4096) {
+        // a chunk launch runs ceil(tiles / 512) lock-step rounds of 128x128 tiles: trim the width (by at
+        // most 16 tiles) so that the last round is >= 90 % full
+        const int64_t tm_ = (M + 127) / 128;
+        for (int64_t tn = nc / 128, tries = 0; tries < 16 && tn > 16; --tn, ++tries) {
+            const int64_t rem = (tm_ * tn) % 512;
+            if (rem == 0 || rem >= 460) { nc = tn * 128; break; }
+        }
+    }
+    uint64_t* carry = (uint64_t*)j.ws;
+    float* thr = (float*)((char*)j.ws + align256((size_t)M * k * 8));
+    uint8_t* gflag = (uint8_t*)((char*)j.ws + fixed_b);
+    float* chunk = (float*)((char*)gflag + align256((size_t)M * ((nc + 31) / 32)));
+    const bool filter = (k <= kGroupSelectMaxK);
+    if (!filter && (j.Qh || !j.emit || j.m_active)) { isx_set_error("%s: k=%d unsupported on this path", j.who, k); return ISX_ERR_ARG; }
+    auto gemm = [&](int64_t c0, int64_t w, const float* t, uint8_t* gf) -> int {
+        if (j.Qh) return launch_gemm_f16(j.Qh, M, j.Gh + c0 * D, w, D, chunk, w, t, gf, st);
+        if (gf) return launch_cosine_gemm_filter(j.Q, M, j.G + c0 * D, w, D, chunk, w, t, gf, st, j.m_active);
+        return launch_cosine_gemm(j.Q, M, j.G + c0 * D, w, D, chunk, w, st, j.m_active);
+    };
+    int64_t c0 = 0;
+    while (c0 < N) {
+        const bool first = (c0 == 0);
+        int64_t w = N - c0 < nc ? N - c0 : nc;
+        if (first && filter && w > kFirstChunk && N >= 4 * kFirstChunk) w = kFirstChunk;   // short bootstrap chunk
+        const bool last = (c0 + w >= N);
+        const bool emit = last && j.emit;
+        int rc;
+        if (!filter) {
+            rc = gemm(c0, w, nullptr, nullptr);
+            if (rc) return rc;
+            rc = launch_select(chunk, M, w, w, c0, k, carry, first, last, j.idx_base, j.top_score, j.top_idx, st, thr);
+        } else if (first) {
+            // bootstrap chunk: plain GEMM, every group present, empty carry (all-zero keys sort last)
+            rc = gemm(c0, w, nullptr, nullptr);
+            if (rc) return rc;
+            if (hipMemsetAsync(carry, 0, (size_t)M * k * 8, st) != hipSuccess) {
+                isx_set_error("%s: hipMemsetAsync failed", j.who);
+                return ISX_ERR_HIP;
+            }
+            rc = launch_select_groups(chunk, nullptr /* all groups present */, M, w, w, c0, k, carry, thr, emit, j.idx_base, j.top_score,
+                                      j.top_idx, st, j.m_active, j.row_map);
+        } else {
+            rc = gemm(c0, w, thr, gflag);
+            if (rc) return rc;
+            rc = launch_select_groups(chunk, gflag, M, w, w, c0, k, carry, thr, emit, j.idx_base, j.top_score, j.top_idx, st, j.m_active,
+                                      j.row_map);
+        }
+        if (rc) return rc;
+        c0 += w;
+    }
+    return ISX_OK;
 }
 
 }  // namespace isx
@@ -263,31 +364,10 @@ ISX_API int isx_cosine_sim(const float* Q, int64_t M, const float* G, int64_t N,
     return launch_cosine_gemm(Q, M, G, N, D, sim, N, (hipStream_t)stream);
 }
 
-// Workspace layout of isx_cosine_topk:
-//   [ carry keys: M*k u64 | thr: M f32 | group flags: M*ceil(Nc/32) u8 | score chunk: M*Nc f32 ]
-// The first column chunk (<= kFirstChunk columns) is materialised and selected in full; it leaves a
-// per-row lower bound thr of the final k-th score.  Every later chunk runs the FILTERING GEMM: only
-// 32-column groups whose best score reaches thr are stored and read back, so for typical data the
-// M x N matrix is never written -- just one float per 32 scores.  Exact for any data: in the worst
-// case (every group qualifies) the chunk is simply materialised in full, as in round 0.
-constexpr int64_t kFirstChunk = 8192;
-static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
-static size_t topk_fixed_bytes(int64_t M, int k) { return align256((size_t)M * k * 8) + align256((size_t)M * 4); }
-static size_t topk_chunk_bytes(int64_t M, int64_t nc) { return align256((size_t)M * ((nc + 31) / 32)) + (size_t)M * nc * 4; }
-
 ISX_API size_t isx_cosine_topk_workspace(int64_t M, int64_t N, int D, int k) {
     (void)D;
     if (M <= 0 || N <= 0 || k <= 0) return 256;
-    // recommended: whole matrix if it is <= 1 GiB, else column chunks of ~1 GiB (multiple of 2048 columns)
-    const size_t budget = (size_t)1 << 30;
-    int64_t nc = N;
-    if ((size_t)M * N * 4 > budget) {
-        nc = (int64_t)(budget / ((size_t)M * 4));
-        nc = nc / 2048 * 2048;
-        if (nc < 2048) nc = 2048;
-        if (nc > N) nc = N;
-    }
-    return topk_fixed_bytes(M, k) + topk_chunk_bytes(M, nc);
+    return topk_fixed_bytes(M, k) + topk_chunk_bytes(M, topk_recommended_chunk(M, N));
     // minimum accepted by isx_cosine_topk: the same formula with nc = min(N, 128)
 }
 
@@ -300,59 +380,10 @@ ISX_API int isx_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N
     ISX_REQUIRE(Q && top_score && top_idx && (G || N == 0), "isx_cosine_topk: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (N == 0) return launch_select(nullptr, M, 0, 0, 0, k, nullptr, true, true, idx_base, top_score, top_idx, st);
-    const size_t fixed_b = topk_fixed_bytes(M, k);
-    const int64_t min_nc = N < 128 ? N : 128;
-    if (!ws || ((uintptr_t)ws % 256) != 0 || ws_bytes < fixed_b + topk_chunk_bytes(M, min_nc)) {
-        isx_set_error("isx_cosine_topk: workspace of %zu bytes too small or misaligned (need >= %zu, 256-B aligned)", ws_bytes,
-                      fixed_b + topk_chunk_bytes(M, min_nc));
-        return ISX_ERR_WORKSPACE;
-    }
-    // largest chunk width (multiple of 128 unless it covers N) whose gmax + scores fit
-    int64_t nc = (int64_t)((ws_bytes - fixed_b) / ((size_t)M * 4));
-    if (nc > N) nc = N;
-    while (nc > min_nc && topk_chunk_bytes(M, nc) > ws_bytes - fixed_b) nc -= (nc > 4096 ? 1024 : 128);
-    if (nc < N) nc = nc >= 128 ? nc / 128 * 128 : nc;
-    if (nc < N && nc >= 4096) {
-        // a chunk launch runs ceil(tiles / 512) lock-step rounds of 128x128 tiles: trim the width (by at
-        // most 16 tiles) so that the last round is >= 90 % full
-        const int64_t tm_ = (M + 127) / 128;
-        for (int64_t tn = nc / 128, tries = 0; tries < 16 && tn > 16; --tn, ++tries) {
-            const int64_t rem = (tm_ * tn) % 512;
-            if (rem == 0 || rem >= 460) { nc = tn * 128; break; }
-        }
-    }
-    uint64_t* carry = (uint64_t*)ws;
-    float* thr = (float*)((char*)ws + align256((size_t)M * k * 8));
-    uint8_t* gmax = (uint8_t*)((char*)ws + fixed_b);
-    float* chunk = (float*)((char*)gmax + align256((size_t)M * ((nc + 31) / 32)));
-    const bool filter = (k <= kGroupSelectMaxK);
-    int64_t c0 = 0;
-    while (c0 < N) {
-        const bool first = (c0 == 0);
-        int64_t w = N - c0 < nc ? N - c0 : nc;
-        if (first && filter && w > kFirstChunk && N >= 4 * kFirstChunk) w = kFirstChunk;   // short bootstrap chunk
-        const bool last = (c0 + w >= N);
-        int rc;
-        if (!filter) {
-            rc = launch_cosine_gemm(Q, M, G + c0 * D, w, D, chunk, w, st);
-            if (rc) return rc;
-            rc = launch_select(chunk, M, w, w, c0, k, carry, first, last, idx_base, top_score, top_idx, st, thr);
-        } else if (first) {
-            // bootstrap chunk: plain GEMM, every group present, empty carry (all-zero keys sort last)
-            rc = launch_cosine_gemm(Q, M, G + c0 * D, w, D, chunk, w, st);
-            if (rc) return rc;
-            if (hipMemsetAsync(carry, 0, (size_t)M * k * 8, st) != hipSuccess) {
-                isx_set_error("isx_cosine_topk: hipMemsetAsync failed");
-                return ISX_ERR_HIP;
-            }
-            rc = launch_select_groups(chunk, nullptr /* all groups present */, M, w, w, c0, k, carry, thr, last, idx_base, top_score, top_idx, st);
-        } else {
-            rc = launch_cosine_gemm_filter(Q, M, G + c0 * D, w, D, chunk, w, thr, gmax, st);
-            if (rc) return rc;
-            rc = launch_select_groups(chunk, gmax, M, w, w, c0, k, carry, thr, last, idx_base, top_score, top_idx, st);
-        }
-        if (rc) return rc;
-        c0 += w;
-    }
-    return ISX_OK;
+    TopkJob j{};
+    j.who = "isx_cosine_topk";
+    j.Q = Q; j.G = G; j.M = M; j.N = N; j.D = D; j.k = k;
+    j.idx_base = idx_base; j.top_score = top_score; j.top_idx = top_idx; j.emit = true;
+    j.ws = ws; j.ws_bytes = ws_bytes; j.st = st;
+    return run_topk_chunks(j);
 }

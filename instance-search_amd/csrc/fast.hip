@@ -19,12 +19,15 @@
 // that force step 4, adversarial orderings).  Reference call sites: the same as isx_cosine_topk
 // (test/classif_finetune_test.py:82 + utils/metrics.py:10-13,33).
 //
-// Error bound (unit roundoff u16 = 2^-11 for fp16 RNE, u32 = 2^-24): each product carries relative
-// error <= 2 u16 + u16^2, fp16 underflow adds <= 2^-24 absolute per element (2^-25 rounding of a
-// subnormal times |other| <= 1 after scaling... bounded by D * 2^-24 * |q|_inf |g|_inf), the fp32
-// accumulations of both S' and S add <= 2 * D * u32 * sum|q g|.  With sum |q_k g_k| <= |q| |g|:
-//   eps_i = (2^-10 + 2^-20 + 2 D 2^-24) |q_i| gmax + D 2^-23 qinf_i ginf      (computed per query)
-// Inputs must satisfy |x| < 6e4 (fp16 range); descriptors are unit vectors.
+// Error bound.  u16 = 2^-11 (fp16 RNE), u32 = 2^-24.  Operands are first multiplied by a power of two
+// (exact) that brings the largest |x| of the matrix into [2^13, 2^14): scores scale by the exact factor
+// sq*sg, and an element can lose relative precision in fp16 only when it is 2^27 times smaller than the
+// largest one (whether the hardware rounds fp16 subnormals gradually or flushes them).
+//   rounding of both operands       (2 u16 + u16^2) sum|q g|           <= (2^-10 + 2^-22) |q| |g|
+//   elements below the fp16 normal range   2^-14 / scale per element   <= 2 D 2^-27 qmax gmax
+//   fp32 accumulation, exact chain  (D-1) u32 sum|q g|,  MFMA chain (any order, truncation-safe) 2 D u32 sum|q g|
+//   eps_i = (2^-10 + 2^-22 + 3 D 2^-24) |q_i| max_j|g_j|  +  D 2^-26 qmax gmax        (inflated by 1 %)
+// Matrices whose largest |x| is outside [2^-20, 2^15], or not finite, take the exact fp32 path.
 #include <hip/hip_fp16.h>
 
 #include "isx_internal.hpp"
@@ -34,25 +37,60 @@ namespace isx {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-// ---- 1. fp32 -> fp16 rows (+ squared norm and max |x| per row) ---------------------------------
+// ---- 1. fp32 -> fp16 rows ------------------------------------------------------------------------
+// stats words are bit patterns of non-negative floats (unsigned order == float order) accumulated with
+// atomicMax: order independent, deterministic.  stats[0] = max squared row norm (upper bound), stats[1] = max |x|.
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ stats) {
+    float mx = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = fabsf(x[i]);
+        mx = (v > mx || v != v) ? v : mx;                 // NaN-propagating
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const float o = __shfl_xor(mx, s, 64);
+        mx = (o > mx || o != o) ? o : mx;
+    }
+    if (!(mx >= 0.0f)) mx = INFINITY;                     // NaN -> unusable
+    if ((threadIdx.x & 63) == 0) atomicMax(&stats[1], __float_as_uint(mx));
+}
+
+__device__ __forceinline__ bool f16_usable(float amax) { return amax >= 9.5367431640625e-7f && amax <= 32768.0f; }   // [2^-20, 2^15]
+__device__ __forceinline__ float f16_scale(float amax) {
+    return f16_usable(amax) ? ldexpf(1.0f, 13 - ilogbf(amax)) : 1.0f;
+}
+
+// stats (optional): scale from stats[1] (must be final: amax_kernel ran before), max norm2 into stats[0].
 __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restrict__ x, int64_t B, int D, _Float16* __restrict__ h,
-                                                          float* __restrict__ norm2, float* __restrict__ amax) {
+                                                          float* __restrict__ norm2, float* __restrict__ amax,
+                                                          unsigned* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= B) return;
+    const float scale = stats ? f16_scale(__uint_as_float(stats[1])) : 1.0f;
     const float* r = x + row * D;
     _Float16* o = h + row * D;
     float ss = 0.0f, mx = 0.0f;
     for (int j = lane; j < D; j += 64) {
         const float v = r[j];
-        o[j] = (_Float16)v;                      // RNE
+        o[j] = (_Float16)(v * scale);            // power-of-two scaling is exact; conversion RNE
         ss += v * v;
-        mx = fmaxf(mx, fabsf(v));
+        mx = (fabsf(v) > mx || v != v) ? fabsf(v) : mx;
     }
     ss = wave_sum(ss);
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s, 64));
-    if (lane == 0) { norm2[row] = ss * 1.000001f; amax[row] = mx; }     // slight inflation: norm2 is an upper bound
+    for (int s = 32; s > 0; s >>= 1) {
+        const float o2 = __shfl_xor(mx, s, 64);
+        mx = (o2 > mx || o2 != o2) ? o2 : mx;
+    }
+    ss *= 1.000001f;                                                    // slight inflation: norm2 is an upper bound
+    if (!(ss >= 0.0f)) ss = INFINITY;
+    if (!(mx >= 0.0f)) mx = INFINITY;
+    if (lane == 0) {
+        if (norm2) norm2[row] = ss;
+        if (amax) amax[row] = mx;
+        if (stats) atomicMax(&stats[0], __float_as_uint(ss));
+    }
 }
 
 // ---- 2. fp16 MFMA GEMM, 128x128 tile, BK = 64, same filter epilogue as the fp32 kernel ------------
@@ -179,7 +217,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16* __
     }
 }
 
-static int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C, int64_t ldc, const float* thr,
+int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C, int64_t ldc, const float* thr,
                            uint8_t* gflag, hipStream_t st) {
     if (M == 0 || N == 0) return ISX_OK;
     const int64_t tm = (M + 127) / 128, tn = (N + 127) / 128;
@@ -192,6 +230,188 @@ static int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int6
     return ISX_OK;
 }
 
+
+// ---- 3. exact re-scoring of the candidates inside the error window -------------------------------
+// One 256-thread workgroup per query row.  cand: the row's KL best APPROXIMATE keys (canonical order,
+// 0 = empty).  Window: approx >= a_k - 2 eps (a_k = k-th best approximate score).  Sufficient iff the
+// window ends inside the list (or the list holds the whole gallery).  Candidate t is re-scored by
+// thread t with the canonical fma chain; the candidate rows are staged through LDS 32 k-values at a
+// time (8 lanes fetch one 128-B row segment: coalesced) and read back conflict-free ([cand][36] floats).
+constexpr int RS_T = 256;
+constexpr int RS_BK = 32;
+constexpr int RS_LD = 36;
+
+__device__ __forceinline__ float fast_eps(float qn2, float qmax, float gn2, float gmax, int D) {
+    // eps = (2^-10 + 2^-22 + 3 D 2^-24) |q| |g|max + D 2^-26 qmax gmax, evaluated in fp32 and inflated by 1 %
+    const float c1 = 9.765625e-4f + 2.384185791015625e-7f + 3.0f * (float)D * 5.9604644775390625e-8f;
+    const float c2 = (float)D * 1.490116119384765625e-8f;
+    return 1.01f * (c1 * sqrtf(qn2) * sqrtf(gn2) + c2 * qmax * gmax);
+}
+
+__global__ __launch_bounds__(RS_T) void rescore_kernel(const float* __restrict__ Q, const float* __restrict__ G, int D, int64_t N, int KL, int k,
+                                                       const uint64_t* __restrict__ cand, const float* __restrict__ qnorm2,
+                                                       const float* __restrict__ qstats, const float* __restrict__ gstats,
+                                                       int64_t idx_base, float* __restrict__ top_score, int64_t* __restrict__ top_idx,
+                                                       int* __restrict__ ok) {
+    __shared__ __attribute__((aligned(16))) float tile[RS_T * RS_LD];     // 36 KB
+    __shared__ uint64_t keys[RS_T];
+    __shared__ int cnt_s[2];
+    const int t = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const uint64_t key = (t < KL) ? cand[row * KL + t] : 0ull;
+    keys[t] = key;
+    if (t < 2) cnt_s[t] = 0;
+    __syncthreads();
+    // approximate scores live in the scaled domain: S' ~ sq * sg * S
+    const float qmax = qstats[1], gmax = gstats[1];
+    const float sc = f16_scale(qmax) * f16_scale(gmax);
+    const float eps = fast_eps(qnorm2[row], qmax, gstats[0], gmax, D) * sc;
+    const int kk = (k < KL) ? k : KL;
+    const uint64_t kth = keys[kk - 1];                                    // 0 when the list holds fewer than k
+    const bool usable = f16_usable(qmax) && f16_usable(gmax) && (eps < 1e30f);
+    float floor_v = -INFINITY;
+    if (kth) floor_v = key_score(kth) - 2.0f * eps - 2e-7f * fabsf(key_score(kth));   // (fp32 rounding of this line covered)
+    const bool valid = key != 0ull;
+    const bool in_win = valid && (key_score(key) >= floor_v);
+    if (valid) atomicAdd(&cnt_s[0], 1);
+    if (in_win) atomicAdd(&cnt_s[1], 1);
+    __syncthreads();
+    const int nvalid = cnt_s[0], c = cnt_s[1];                            // the window is a prefix of the sorted list
+    const bool sufficient = usable && (N <= KL || c < KL) && (nvalid >= (N < KL ? (int)N : KL));
+    if (!sufficient) {
+        if (t == 0) ok[row] = 0;
+        return;
+    }
+    if (t == 0) ok[row] = 1;
+    // ---- exact scores of candidates 0..c-1 ----
+    const float* q = Q + row * D;
+    const int lr = t >> 3, lc = t & 7;                                    // staging role: row-in-pass, 16-B chunk
+    const int npass = (c + 31) >> 5;
+    const float* gp[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int ci = p * 32 + lr;
+        const uint64_t kc = keys[ci < c ? ci : 0];
+        gp[p] = G + (int64_t)key_idx(kc) * D + lc * 4;
+    }
+    float acc = 0.0f;
+    float4 reg[8];
+    auto load = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (p < npass) reg[p] = (k0 + lc * 4 < D) ? *reinterpret_cast<const float4*>(gp[p] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            if (p < npass) *reinterpret_cast<float4*>(&tile[(p * 32 + lr) * RS_LD + lc * 4]) = reg[p];
+    };
+    load(0);
+    store();
+    __syncthreads();
+    for (int k0 = 0; k0 < D; k0 += RS_BK) {
+        const bool more = (k0 + RS_BK < D);
+        if (more) load(k0 + RS_BK);
+        if (t < c) {
+            const int kn = (D - k0 < RS_BK) ? D - k0 : RS_BK;
+            if (kn == RS_BK) {
+#pragma unroll
+                for (int u = 0; u < RS_BK; u += 4) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(&tile[t * RS_LD + u]);
+                    acc = fmaf(q[k0 + u], g4.x, acc);
+                    acc = fmaf(q[k0 + u + 1], g4.y, acc);
+                    acc = fmaf(q[k0 + u + 2], g4.z, acc);
+                    acc = fmaf(q[k0 + u + 3], g4.w, acc);
+                }
+            } else {
+                for (int u = 0; u < kn; ++u) acc = fmaf(q[k0 + u], tile[t * RS_LD + u], acc);
+            }
+        }
+        __syncthreads();
+        if (more) {
+            store();
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    keys[t] = (t < c) ? rank_key(acc, key_idx(key)) : 0ull;
+    __syncthreads();
+    bitonic_sort_desc<RS_T>(keys, RS_T);
+    for (int i = t; i < k; i += RS_T) {
+        const uint64_t kx = (i < RS_T) ? keys[i] : 0ull;
+        top_score[row * k + i] = kx ? key_score(kx) : -INFINITY;
+        top_idx[row * k + i] = kx ? (idx_base + (int64_t)key_idx(kx)) : -1;
+    }
+}
+
+// ---- 4. rows whose window was not covered: compact, gather, exact fp32 search ---------------------
+__global__ __launch_bounds__(1024) void compact_rows_kernel(const int* __restrict__ ok, int M, int* __restrict__ list, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < M; i0 += 1024) {
+        const int i = i0 + t;
+        const bool bad = (i < M) && (ok[i] == 0);
+        const unsigned long long m = __ballot(bad);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (bad) list[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (t == 0) { int s2 = 0; for (int w = 0; w < 16; ++w) s2 += wsum[w]; base_s += s2; }
+        __syncthreads();
+    }
+    if (t == 0) *count = base_s;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ Q, int D, const int* __restrict__ list,
+                                                          const int* __restrict__ count, float* __restrict__ out) {
+    const int r = blockIdx.x;
+    if (r >= *count) return;
+    const float* src = Q + (int64_t)list[r] * D;
+    float* dst = out + (int64_t)r * D;
+    for (int j = threadIdx.x; j < D; j += 256) dst[j] = src[j];
+}
+
+static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
+static int fast_kl(int k) {
+    int kl = (2 * k + 32 + 31) / 32 * 32;
+    if (kl < 64) kl = 64;
+    if (kl > kGroupSelectMaxK) kl = kGroupSelectMaxK;
+    return kl;
+}
+constexpr int kFastMaxK = 128;
+
+struct FastLayout {
+    size_t qh, qn2, qstats, gh, gstats, ok, list, count, qbad, fixed_approx, fixed_exact, chunk, total;
+    int64_t nc;
+};
+static FastLayout fast_layout(int64_t M, int64_t N, int D, int k, bool own_gallery) {
+    FastLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += a256(bytes); return at; };
+    L.qh = take((size_t)M * D * 2);
+    L.qn2 = take((size_t)M * 4);
+    L.qstats = take(16);
+    L.gh = take(own_gallery ? (size_t)N * D * 2 : 0);
+    L.gstats = take(16);
+    L.ok = take((size_t)M * 4);
+    L.list = take((size_t)M * 4);
+    L.count = take(16);
+    L.qbad = take((size_t)M * D * 4);
+    // the two chunk pipelines run one after the other and share one area: [fixed | flags | chunk]
+    const int kl = fast_kl(k);
+    L.fixed_approx = topk_fixed_bytes(M, kl);
+    L.fixed_exact = topk_fixed_bytes(M, k);
+    L.chunk = o;
+    L.nc = topk_recommended_chunk(M, N);
+    L.total = o + L.fixed_approx + topk_chunk_bytes(M, L.nc);
+    return L;
+}
+
 }  // namespace isx
 
 using namespace isx;
@@ -201,9 +421,32 @@ ISX_API int isx_rows_to_f16(const float* x, int64_t B, int D, void* h, float* no
     ISX_REQUIRE(B >= 0 && D > 0 && B < (1ll << 33), "isx_rows_to_f16: bad shape B=%lld D=%d", (long long)B, D);
     if (B == 0) return ISX_OK;
     ISX_REQUIRE(x && h && norm2 && amax, "isx_rows_to_f16: null pointer");
-    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, B, D, (_Float16*)h, norm2, amax);
+    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, B, D, (_Float16*)h, norm2, amax,
+                       (unsigned*)nullptr);
     ISX_CHECK_LAUNCH("isx_rows_to_f16");
     return ISX_OK;
+}
+
+// stats must be zeroed (stream-ordered) before: pass 1 max |x|, pass 2 scaled conversion + max norm2.
+static int convert_scaled(const float* x, int64_t B, int D, _Float16* h, float* norm2, unsigned* stats, hipStream_t st) {
+    const int64_t n = B * D;
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, stats);
+    ISX_CHECK_LAUNCH("amax");
+    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x, B, D, h, norm2, (float*)nullptr, stats);
+    ISX_CHECK_LAUNCH("rows_to_f16");
+    return ISX_OK;
+}
+
+// Gallery preparation for isx_cosine_topk_fast: power-of-two scaled fp16 image of the rows + gstats[2] =
+// {max squared row norm (upper bound), max |x|}.  Done once per gallery shard and cached by the caller.
+ISX_API int isx_gallery_to_f16(const float* G, int64_t N, int D, void* Gh, float* gstats, isx_stream_t stream) {
+    ISX_REQUIRE(N >= 0 && D > 0 && N < (1ll << 33), "isx_gallery_to_f16: bad shape N=%lld D=%d", (long long)N, D);
+    ISX_REQUIRE(gstats && ((G && Gh) || N == 0), "isx_gallery_to_f16: null pointer");
+    if (hipMemsetAsync(gstats, 0, 8, (hipStream_t)stream) != hipSuccess) { isx_set_error("isx_gallery_to_f16: hipMemsetAsync failed"); return ISX_ERR_HIP; }
+    if (N == 0) return ISX_OK;
+    return convert_scaled(G, N, D, (_Float16*)Gh, nullptr, (unsigned*)gstats, (hipStream_t)stream);
 }
 
 // Approximate similarity matrix from fp16 operands (fp32 accumulate): building block / diagnostic of the
@@ -213,4 +456,97 @@ ISX_API int isx_cosine_sim_f16(const void* Qh, int64_t M, const void* Gh, int64_
     ISX_REQUIRE((Qh && Gh && sim) || M * N == 0, "isx_cosine_sim_f16: null pointer");
     ISX_REQUIRE((((uintptr_t)Qh | (uintptr_t)Gh) % 16) == 0, "isx_cosine_sim_f16: operands must be 16-B aligned");
     return launch_gemm_f16((const _Float16*)Qh, M, (const _Float16*)Gh, N, D, sim, N, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// Shapes the filter path does not cover run the fp32 path unchanged.
+static bool fast_applicable(int64_t M, int64_t N, int D, int k) {
+    return M > 0 && N > 0 && D % 8 == 0 && k <= kFastMaxK && M < (1ll << 31) && N > 4 * (int64_t)fast_kl(k);
+}
+
+ISX_API size_t isx_cosine_topk_fast_workspace(int64_t M, int64_t N, int D, int k, int have_gallery_f16) {
+    if (M <= 0 || N <= 0 || k <= 0 || D <= 0) return 256;
+    const size_t plain = isx_cosine_topk_workspace(M, N, D, k);
+    if (!fast_applicable(M, N, D, k)) return plain;
+    const size_t fast = fast_layout(M, N, D, k, !have_gallery_f16).total;
+    return fast > plain ? fast : plain;
+}
+
+ISX_API int isx_cosine_topk_fast(const float* Q, int64_t M, const float* G, int64_t N, int D, int k, int64_t idx_base,
+                                 const void* Gh, const float* gstats, float* top_score, int64_t* top_idx, void* ws,
+                                 size_t ws_bytes, isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && N >= 0 && D > 0, "isx_cosine_topk_fast: bad shape M=%lld N=%lld D=%d", (long long)M, (long long)N, D);
+    ISX_REQUIRE(k >= 1 && k <= kSelectMaxK, "isx_cosine_topk_fast: k=%d outside [1,%d]", k, kSelectMaxK);
+    ISX_REQUIRE((Gh == nullptr) == (gstats == nullptr), "isx_cosine_topk_fast: Gh and gstats go together");
+    const bool aligned = ((((uintptr_t)Q | (uintptr_t)G | (uintptr_t)Gh) % 16) == 0);
+    if (!fast_applicable(M, N, D, k) || !aligned)
+        return isx_cosine_topk(Q, M, G, N, D, k, idx_base, top_score, top_idx, ws, ws_bytes, stream);
+    ISX_REQUIRE(idx_base >= 0 && idx_base + N <= 0xFFFFFFFFll && N <= 0x7FFFFFFFll, "isx_cosine_topk_fast: gallery indices must stay below 2^32");
+    ISX_REQUIRE(Q && G && top_score && top_idx, "isx_cosine_topk_fast: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const bool own = (Gh == nullptr);
+    const FastLayout L = fast_layout(M, N, D, k, own);
+    const size_t need_min = L.chunk + L.fixed_approx + topk_chunk_bytes(M, 128);
+    if (!ws || ((uintptr_t)ws % 256) != 0 || ws_bytes < need_min) {
+        isx_set_error("isx_cosine_topk_fast: workspace of %zu bytes too small or misaligned (need >= %zu, 256-B aligned)", ws_bytes, need_min);
+        return ISX_ERR_WORKSPACE;
+    }
+    char* w = (char*)ws;
+    _Float16* qh = (_Float16*)(w + L.qh);
+    float* qn2 = (float*)(w + L.qn2);
+    float* qst = (float*)(w + L.qstats);
+    int* ok = (int*)(w + L.ok);
+    int* list = (int*)(w + L.list);
+    int* count = (int*)(w + L.count);
+    float* qbad = (float*)(w + L.qbad);
+    const int kl = fast_kl(k);
+    int rc;
+
+    // 1. fp16 operands
+    if (hipMemsetAsync(qst, 0, 8, st) != hipSuccess) { isx_set_error("isx_cosine_topk_fast: hipMemsetAsync failed"); return ISX_ERR_HIP; }
+    rc = convert_scaled(Q, M, D, qh, qn2, (unsigned*)qst, st);
+    if (rc) return rc;
+    const _Float16* gh = (const _Float16*)Gh;
+    const float* gs = gstats;
+    if (own) {
+        rc = isx_gallery_to_f16(G, N, D, w + L.gh, (float*)(w + L.gstats), stream);
+        if (rc) return rc;
+        gh = (const _Float16*)(w + L.gh);
+        gs = (const float*)(w + L.gstats);
+    }
+    // 2. the KL best approximate candidates per row (keys stay in the workspace)
+    TopkJob a{};
+    a.who = "isx_cosine_topk_fast";
+    a.Qh = qh; a.Gh = gh; a.M = M; a.N = N; a.D = D; a.k = kl;
+    a.idx_base = 0; a.emit = false;
+    a.ws = w + L.chunk; a.ws_bytes = ws_bytes - L.chunk; a.st = st;
+    rc = run_topk_chunks(a);
+    if (rc) return rc;
+    const uint64_t* cand = (const uint64_t*)(w + L.chunk);
+    // 3. exact re-scoring inside the error window
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)M), dim3(RS_T), 0, st, Q, G, D, N, kl, k, cand, qn2, qst, gs, idx_base, top_score, top_idx, ok);
+    ISX_CHECK_LAUNCH("rescore");
+    // 4. exact fp32 search for the rows that were not covered (usually none: every launch below exits at once)
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, st, ok, (int)M, list, count);
+    ISX_CHECK_LAUNCH("compact_rows");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)M), dim3(256), 0, st, Q, D, list, count, qbad);
+    ISX_CHECK_LAUNCH("gather_rows");
+    TopkJob e{};
+    e.who = "isx_cosine_topk_fast";
+    e.Q = qbad; e.G = G; e.M = M; e.N = N; e.D = D; e.k = k;
+    e.idx_base = idx_base; e.top_score = top_score; e.top_idx = top_idx; e.emit = true;
+    e.ws = w + L.chunk; e.ws_bytes = ws_bytes - L.chunk; e.st = st;
+    e.m_active = count; e.row_map = list;
+    return run_topk_chunks(e);
+}
+
+// Debug / test hook (not declared in include/isx.h): number of query rows of the LAST isx_cosine_topk_fast
+// call on this workspace that took the exact fp32 fallback (-1: the call ran the fp32 path as a whole).
+// Synchronises the device.
+ISX_API int isx_debug_fast_fallback_rows(const void* ws, int64_t M, int64_t N, int D, int k, int have_gallery_f16) {
+    if (!ws || !fast_applicable(M, N, D, k)) return -1;
+    const FastLayout L = fast_layout(M, N, D, k, !have_gallery_f16);
+    int c = -2;
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    if (hipMemcpy(&c, (const char*)ws + L.count, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    return c;
 }

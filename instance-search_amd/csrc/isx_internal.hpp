@@ -5,14 +5,19 @@
 namespace isx {
 
 // C[m][n] = sum_k Q[m][k] * G[n][k]  (k-ordered fp32 fma chain), C row stride ldc.
+// m_active (optional, device scalar): tiles whose first row is >= *m_active exit immediately.
 int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                       hipStream_t st);
+                       hipStream_t st, const int* m_active = nullptr);
 
 // Same GEMM with the filtering epilogue: the scores of a (row, 32-column group) are stored to C only
 // when one of them reaches thr[row] (a lower bound of the row's final k-th best score); gflag
 // (M, ngrp = ceil(N/32)) bytes say which groups were stored.
 int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                              const float* thr, uint8_t* gflag, hipStream_t st);
+                              const float* thr, uint8_t* gflag, hipStream_t st, const int* m_active = nullptr);
+
+// fp16-operand variant (fast.hip): approximate scores, fp32 accumulate; gflag == nullptr -> plain GEMM.
+int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C, int64_t ldc, const float* thr,
+                    uint8_t* gflag, hipStream_t st);
 
 // Per-row running top-k over a score chunk.  sim: (M, Nc) with row stride ld; column j
 // of the chunk is gallery row col_base + j.  carry: (M, k) u64 keys (canonical order,
@@ -26,10 +31,28 @@ int launch_select(const float* sim, int64_t M, int64_t Nc, int64_t ld, int64_t c
 // (thr[row] = score of the k-th key, -inf while fewer than k).
 int launch_select_groups(const float* sim, const uint8_t* gflag, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
                          uint64_t* carry, float* thr, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx,
-                         hipStream_t st);
+                         hipStream_t st, const int* m_active = nullptr, const int* row_map = nullptr);
+// m_active / row_map (optional, device): only rows < *m_active are processed and row r emits to output row row_map[r].
 
 constexpr int kGroupSelectMaxK = 256;
 
 constexpr int kSelectMaxK = 1024;
+
+// One chunked running-top-k search (cosine.hip).  fp32 operands (Q, G) or fp16 operands (Qh, Gh); with
+// emit the final lists go to top_score / top_idx, otherwise the keys stay in the workspace (carry at
+// ws + 0, thr after it).  Workspace layout: [carry M*k u64 | thr M f32 | flags | score chunk].
+struct TopkJob {
+    const char* who;
+    const float* Q; const float* G;
+    const _Float16* Qh; const _Float16* Gh;
+    int64_t M, N; int D, k;
+    int64_t idx_base; float* top_score; int64_t* top_idx; bool emit;
+    void* ws; size_t ws_bytes; hipStream_t st;
+    const int* m_active; const int* row_map;
+};
+int run_topk_chunks(const TopkJob& job);
+size_t topk_fixed_bytes(int64_t M, int k);
+size_t topk_chunk_bytes(int64_t M, int64_t nc);
+int64_t topk_recommended_chunk(int64_t M, int64_t N);
 
 }  // namespace isx

@@ -117,10 +117,12 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
                                                            int64_t Nc, int64_t ld, int ngrp, uint32_t col_base, int k,
                                                            uint64_t* __restrict__ carry, float* __restrict__ thr, int emit,
                                                            int64_t idx_base, float* __restrict__ top_score,
-                                                           int64_t* __restrict__ top_idx) {
+                                                           int64_t* __restrict__ top_idx, const int* __restrict__ m_active,
+                                                           const int* __restrict__ row_map) {
     __shared__ __attribute__((aligned(16))) uint64_t buf[GS_CAP];
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int64_t row = blockIdx.x;
+    if (m_active && row >= *m_active) return;
     const float* r = sim + row * ld;
     const uint8_t* gf = gflag ? gflag + row * (int64_t)ngrp : nullptr;     // null = every group present
     for (int i = lane; i < GS_CAP; i += 64) buf[i] = (carry && i < k) ? carry[row * k + i] : 0ull;   // null carry = empty list
@@ -206,10 +208,11 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
     __syncthreads();
     if (dirty) bitonic_sort_desc<64>(buf, GS_CAP);
     if (emit) {
+        const int64_t orow = row_map ? (int64_t)row_map[row] : row;
         for (int i = lane; i < k; i += 64) {
             const uint64_t kk = buf[i];
-            top_score[row * k + i] = kk ? key_score(kk) : -INFINITY;
-            top_idx[row * k + i] = kk ? (idx_base + (int64_t)key_idx(kk)) : -1;
+            top_score[orow * k + i] = kk ? key_score(kk) : -INFINITY;
+            top_idx[orow * k + i] = kk ? (idx_base + (int64_t)key_idx(kk)) : -1;
         }
     } else {
         for (int i = lane; i < k; i += 64) carry[row * k + i] = buf[i];
@@ -219,12 +222,12 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
 
 int launch_select_groups(const float* sim, const uint8_t* gflag, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
                          uint64_t* carry, float* thr, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx,
-                         hipStream_t st) {
+                         hipStream_t st, const int* m_active, const int* row_map) {
     if (M == 0) return ISX_OK;
     if (M >= (1ll << 31) || k > kGroupSelectMaxK) { isx_set_error("select_groups: unsupported M=%lld k=%d", (long long)M, k); return ISX_ERR_ARG; }
     const int ngrp = (int)((Nc + 31) / 32);
     hipLaunchKernelGGL(select_groups_kernel, dim3((unsigned)M), dim3(64), 0, st, sim, gflag, Nc, ld, ngrp, (uint32_t)col_base, k, carry, thr,
-                       emit ? 1 : 0, idx_base, top_score, top_idx);
+                       emit ? 1 : 0, idx_base, top_score, top_idx, m_active, row_map);
     ISX_CHECK_LAUNCH("select_groups");
     return ISX_OK;
 }

@@ -176,6 +176,44 @@ def cosine_topk(Q, G, k, idx_base=0, ws=None, out=None):
     return ts, ti
 
 
+def gallery_to_f16(G):
+    """(Gh (N,D) fp16 scaled image, gstats (2,) f32) -- the cached gallery side of cosine_topk_fast."""
+    G = _f32(G, "G")
+    N, D = G.shape
+    Gh = torch.empty((N, D), device=G.device, dtype=torch.float16)
+    gstats = torch.empty((2,), device=G.device, dtype=torch.float32)
+    check(lib().isx_gallery_to_f16(G.data_ptr(), N, D, Gh.data_ptr(), gstats.data_ptr(), _stream()), "isx_gallery_to_f16")
+    return Gh, gstats
+
+
+def cosine_topk_fast_workspace(M, N, D, k, have_gallery_f16=False):
+    return lib().isx_cosine_topk_fast_workspace(M, N, D, k, 1 if have_gallery_f16 else 0)
+
+
+def cosine_topk_fast(Q, G, k, idx_base=0, gallery_f16=None, ws=None, out=None):
+    """Same result as cosine_topk, bit for bit; fp16-MFMA filter + exact fp32 re-scoring.
+    gallery_f16: optional (Gh, gstats) from gallery_to_f16(G)."""
+    Q, G = _f32(Q, "Q"), _f32(G, "G")
+    M, D = Q.shape
+    N = G.shape[0]
+    assert G.shape[1] == D
+    gh = gs = 0
+    if gallery_f16 is not None:
+        Gh, gstats = gallery_f16
+        assert Gh.dtype == torch.float16 and Gh.shape == G.shape and Gh.is_contiguous() and gstats.numel() == 2
+        gh, gs = Gh.data_ptr(), gstats.data_ptr()
+    if ws is None:
+        ws = torch.empty((cosine_topk_fast_workspace(M, N, D, k, gallery_f16 is not None),), device=Q.device, dtype=torch.uint8)
+    if out is None:
+        ts = torch.empty((M, k), device=Q.device, dtype=torch.float32)
+        ti = torch.empty((M, k), device=Q.device, dtype=torch.int64)
+    else:
+        ts, ti = out
+    check(lib().isx_cosine_topk_fast(Q.data_ptr(), M, G.data_ptr(), N, D, k, idx_base, gh, gs, ts.data_ptr(), ti.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _stream()), "isx_cosine_topk_fast")
+    return ts, ti
+
+
 def topk_rows(sim, k, idx_base=0):
     sim = _f32(sim, "sim")
     M, N = sim.shape
