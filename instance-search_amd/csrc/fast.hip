@@ -217,13 +217,166 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16* __
     }
 }
 
+
+// ---- 2b. large-problem variant: 256x256 tile, 512 threads (8 waves as 2x4, wave tile 128x64), two LDS
+// stages (128 KB, one barrier per k-tile).  Half the L2->LDS traffic and 3/4 of the LDS reads per MFMA
+// of the 128x128 kernel: 870 vs 620-730 TFLOP/s on 10k x 32k x 2048 (same box, same data).  Same k
+// order, bit-identical scores.  Lab history: scratch/lab/f16_gemm_lab.hip (LDS-DMA staging was slower:
+// 780; the MFMA + ds_read loop alone runs at 1150).
+constexpr int GBM = 256, GBN = 256;
+constexpr int GSTAGE_B = (GBM + GBN) * HBK * 2;          // 64 KB
+
+template <bool FILTER>
+__global__ __launch_bounds__(512) void cosine_gemm_f16_big_kernel(const _Float16* __restrict__ Q, int64_t M,
+                                                                  const _Float16* __restrict__ G, int64_t N, int D,
+                                                                  float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n,
+                                                                  const float* __restrict__ thr, uint8_t* __restrict__ gflag, int ngrp) {
+    __shared__ __attribute__((aligned(16))) char S0[GSTAGE_B];
+    __shared__ __attribute__((aligned(16))) char S1[GSTAGE_B];
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    constexpr int GN = 8;
+    const int per_group = GN * tiles_m, gid = wg / per_group, first_n = gid * GN;
+    const int gsz = min(GN, tiles_n - first_n), within = wg - gid * per_group;
+    const int64_t m0 = (int64_t)(within / gsz) * GBM, n0 = (int64_t)(first_n + within % gsz) * GBN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // staging: 512 image rows (A then B) x 8 chunks of 16 B = 8 chunks per thread
+    const int sr = tid >> 3, sc = tid & 7;
+    const _Float16* gsrc[8];
+    int ldst[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (j & 3) * 64 + sr;
+        const bool isb = j >= 4;
+        int64_t gr = (isb ? n0 : m0) + row;
+        const int64_t lim = isb ? N : M;
+        gr = gr < lim ? gr : lim - 1;                         // clamp: rows past the edge are never stored
+        gsrc[j] = (isb ? G : Q) + gr * D + sc * 8;
+        ldst[j] = (isb ? GBM * 128 : 0) + row * 128 + ((sc ^ hswz(row)) << 4);
+    }
+    float4 reg[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) reg[j] = (k0 + sc * 8 < D) ? *reinterpret_cast<const float4*>(gsrc[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto lstore = [&](char* st) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(st + ldst[j]) = reg[j];
+    };
+    int a_off[4], b_off[2], a_sw[4], b_sw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + l31; a_off[i] = ra * 128; a_sw[i] = hswz(ra); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int rb = wn * 64 + j * 32 + l31; b_off[j] = GBM * 128 + rb * 128; b_sw[j] = hswz(rb); }
+    auto compute = [&](const char* cur) {
+#pragma unroll
+        for (int s = 0; s < HBK / 16; ++s) {
+            const int c = 2 * s + half;
+            half8 a[4], bb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(cur + a_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = *reinterpret_cast<const half8*>(cur + b_off[j] + ((c ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = (D + HBK - 1) / HBK;
+    gload(0);
+    lstore(S0);
+    __syncthreads();
+    if (nk > 1) gload(HBK);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even k-tile: compute from S0 while tile kt+1 goes to S1 and tile kt+2 is fetched
+        if (kt + 1 < nk) {
+            lstore(S1);
+            if (kt + 2 < nk) gload((kt + 2) * HBK);
+        }
+        compute(S0);
+        __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) {
+                lstore(S0);
+                if (kt + 3 < nk) gload((kt + 3) * HBK);
+            }
+            compute(S1);
+            __syncthreads();
+        }
+    }
+
+    // epilogue.  The main loop of this kernel is short (fp16 rate), so the epilogue is a visible share of a
+    // tile: thresholds come from LDS (one coalesced load per tile, then broadcast reads), addresses are
+    // advanced by adds.
+    float* thr_s = reinterpret_cast<float*>(S0);               // all waves are past their last S0 / S1 reads
+    if (FILTER) {
+        if (tid < GBM) thr_s[tid] = (m0 + tid < M) ? thr[m0 + tid] : INFINITY;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rbase = wm * 128 + i * 32 + 4 * half;          // tile row of e = 0
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t ng = n0 + wn * 64 + j * 32;
+            const int64_t n = ng + l31;
+            const bool n_ok = n < N;
+            float* cp = C + (m0 + rbase) * ldc + n;
+            uint8_t* fp = FILTER ? gflag + (m0 + rbase) * (int64_t)ngrp + (ng >> 5) : nullptr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ro = (e & 3) + 8 * (e >> 2);             // row offset inside the 32x32 tile
+                const bool row_ok = (m0 + rbase + ro < M);
+                const float v = acc[i][j][e];
+                if (FILTER) {
+                    const float t = thr_s[rbase + ro];
+                    const unsigned long long qm = __ballot(n_ok && v >= t);
+                    const bool qq = ((half ? (qm >> 32) : qm) & 0xFFFFFFFFull) != 0ull;
+                    if (row_ok && ng < N) {
+                        if (l31 == 0) fp[(int64_t)ro * ngrp] = qq ? 1 : 0;
+                        if (qq && n_ok) cp[(int64_t)ro * ldc] = v;
+                    }
+                } else {
+                    if (row_ok && n_ok) cp[(int64_t)ro * ldc] = v;
+                }
+            }
+        }
+    }
+}
+
+static int g_force_f16_tile = -1;        // debug / A-B hook: 0 = 128x128, 1 = 256x256, -1 = automatic
+
 int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C, int64_t ldc, const float* thr,
                            uint8_t* gflag, hipStream_t st) {
     if (M == 0 || N == 0) return ISX_OK;
     const int64_t tm = (M + 127) / 128, tn = (N + 127) / 128;
     if (tm * tn >= (1ll << 31)) { isx_set_error("f16 gemm: too many tiles"); return ISX_ERR_ARG; }
-    const dim3 grid((unsigned)(tm * tn)), block(256);
     const int ngrp = (int)((N + 31) / 32);
+    // 256x256 tiles (one 512-thread workgroup per CU) once they fill the chip for >= 2 rounds
+    const int64_t btm = (M + GBM - 1) / GBM, btn = (N + GBN - 1) / GBN;
+    const bool big = g_force_f16_tile >= 0 ? g_force_f16_tile == 1 : (btm * btn >= 512);
+    if (big) {
+        const dim3 grid((unsigned)(btm * btn)), block(512);
+        if (gflag) hipLaunchKernelGGL(cosine_gemm_f16_big_kernel<true>, grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
+        else hipLaunchKernelGGL(cosine_gemm_f16_big_kernel<false>, grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
+        ISX_CHECK_LAUNCH("cosine_gemm_f16_big");
+        return ISX_OK;
+    }
+    const dim3 grid((unsigned)(tm * tn)), block(256);
     if (gflag) hipLaunchKernelGGL(cosine_gemm_f16_kernel<true>, grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)tm, (int)tn, thr, gflag, ngrp);
     else hipLaunchKernelGGL(cosine_gemm_f16_kernel<false>, grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)tm, (int)tn, thr, gflag, ngrp);
     ISX_CHECK_LAUNCH("cosine_gemm_f16");
@@ -538,6 +691,9 @@ ISX_API int isx_cosine_topk_fast(const float* Q, int64_t M, const float* G, int6
     e.m_active = count; e.row_map = list;
     return run_topk_chunks(e);
 }
+
+// Debug / A-B hook (not declared in include/isx.h): force the fp16 GEMM tile (0 = 128x128, 1 = 256x256, -1 = automatic).
+ISX_API void isx_debug_set_f16_tile(int t) { g_force_f16_tile = t; }
 
 // Debug / test hook (not declared in include/isx.h): number of query rows of the LAST isx_cosine_topk_fast
 // call on this workspace that took the exact fp32 fallback (-1: the call ran the fp32 path as a whole).

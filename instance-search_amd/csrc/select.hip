@@ -105,13 +105,73 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Running top-k update from a chunk produced by the FILTERING GEMM epilogue (cosine.hip): one wave
-// (64-thread workgroup) per query row.  gflag marks the 32-column groups the GEMM stored (those with
-// a score reaching the row's threshold); nothing else can change the list.  The wave scans the flag
-// row 64 groups at a time, then
-// reads two qualifying 128-B segments per step (one per half-wave).  Candidates beating the k-th
-// key go to a 512-key LDS buffer that is bitonic-sorted and cut to k when it fills.
-constexpr int GS_CAP = 512;
+// Running top-k update from a chunk produced by the FILTERING GEMM epilogue (cosine.hip, fast.hip): one
+// wave (64-thread workgroup) per query row.  gflag marks the 32-column groups the GEMM stored (those
+// with a score reaching the row's threshold); nothing else can change the list.  The wave scans the
+// flag row 64 groups at a time, then reads up to eight qualifying 128-B segments per step (four
+// independent loads per half-wave, so the memory latency of a step is paid once, not four times).
+//
+// LDS buffer: buf[0, k) = the current list, sorted (canonical order, 0 = empty);  buf[k, cnt) = keys
+// that beat the k-th key since the last flush, unsorted.  A flush sorts ONLY the new keys (bitonic
+// over next_pow2(m) <= 512 entries) and merges the two sorted runs by rank: every key finds its final
+// position with one binary search in the other run, positions >= k are dropped.  (Sorting the whole
+// buffer instead made this kernel LDS-write-bound: 55 compare-exchange stages over 1024 keys per flush.)
+constexpr int GS_NEW = 512;                        // capacity of the unsorted run
+constexpr int GS_BUF = kGroupSelectMaxK + GS_NEW;  // 768 keys = 6 KB
+
+// count of entries greater than key in run[0, n) (n a power of two or 0; sorted descending; zeros last)
+__device__ __forceinline__ int count_greater(const uint64_t* run, int n, uint64_t key) {
+    int lo = 0;
+    for (int step = n >> 1; step > 0; step >>= 1)
+        if (run[lo + step - 1] > key) lo += step;
+    if (n > 0 && lo < n && run[lo] > key) ++lo;
+    return lo;
+}
+
+// Returns with cnt == k, buf[0,k) sorted.  Uniform control flow; all 64 lanes call it.
+__device__ __forceinline__ void gs_flush(uint64_t* buf, int k, int kp2, int cnt, int lane) {
+    const int m = cnt - k;
+    if (m <= 0) return;
+    int P = 64;
+    while (P < m) P <<= 1;
+    uint64_t* B = buf + k;
+    for (int i = m + lane; i < P; i += 64) B[i] = 0ull;
+    bitonic_sort_desc<64>(B, P);                   // starts and ends with a barrier
+    // ranks: list entry i moves down by the number of new keys above it, new key t by the number of
+    // list entries above it (all keys are distinct: a column is scored once)
+    uint64_t ka[kGroupSelectMaxK / 64], kb[GS_NEW / 64];
+    int pa[kGroupSelectMaxK / 64], pb[GS_NEW / 64];
+#pragma unroll
+    for (int r = 0; r < kGroupSelectMaxK / 64; ++r) {
+        const int i = lane + 64 * r;
+        ka[r] = (i < k) ? buf[i] : 0ull;
+        pa[r] = ka[r] ? i + count_greater(B, P, ka[r]) : GS_BUF;
+    }
+#pragma unroll
+    for (int r = 0; r < GS_NEW / 64; ++r) {
+        const int t = lane + 64 * r;
+        kb[r] = (t < m) ? B[t] : 0ull;
+        pb[r] = GS_BUF;
+        if (r * 64 < m && kb[r]) {
+            // list run: kp2 = next_pow2(k) entries are addressable (entries in [k, kp2) belong to B: mask them)
+            int lo = 0;
+            for (int step = kp2 >> 1; step > 0; step >>= 1) {
+                const int j = lo + step - 1;
+                if (j < k && buf[j] > kb[r]) lo += step;
+            }
+            if (lo < k && buf[lo] > kb[r]) ++lo;
+            pb[r] = t + lo;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kGroupSelectMaxK / 64; ++r)
+        if (pa[r] < k) buf[pa[r]] = ka[r];
+#pragma unroll
+    for (int r = 0; r < GS_NEW / 64; ++r)
+        if (pb[r] < k) buf[pb[r]] = kb[r];
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gflag,
                                                            int64_t Nc, int64_t ld, int ngrp, uint32_t col_base, int k,
@@ -119,31 +179,28 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
                                                            int64_t idx_base, float* __restrict__ top_score,
                                                            int64_t* __restrict__ top_idx, const int* __restrict__ m_active,
                                                            const int* __restrict__ row_map) {
-    __shared__ __attribute__((aligned(16))) uint64_t buf[GS_CAP];
+    __shared__ __attribute__((aligned(16))) uint64_t buf[GS_BUF];
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int64_t row = blockIdx.x;
     if (m_active && row >= *m_active) return;
     const float* r = sim + row * ld;
     const uint8_t* gf = gflag ? gflag + row * (int64_t)ngrp : nullptr;     // null = every group present
-    for (int i = lane; i < GS_CAP; i += 64) buf[i] = (carry && i < k) ? carry[row * k + i] : 0ull;   // null carry = empty list
+    for (int i = lane; i < k; i += 64) buf[i] = carry ? carry[row * k + i] : 0ull;   // null carry = empty list
     __syncthreads();
+    int kp2 = 1;
+    while (kp2 < k) kp2 <<= 1;
     uint64_t thr_key = buf[k - 1];
     int cnt = k;                                   // uniform
-    bool dirty = false;
 
     if (!gf) {
         // every group present (isx_topk_rows, bootstrap chunk): plain streaming scan, 256 scores per step
         // (16-B loads when the row is 16-B aligned), append by shuffle prefix
         const bool vec = ((((uintptr_t)r) & 15) == 0);
         for (int64_t j0 = 0; j0 < Nc; j0 += 256) {
-            if (cnt > GS_CAP - 256) {                  // room for a full step
-                __syncthreads();
-                bitonic_sort_desc<64>(buf, GS_CAP);
-                for (int i = k + lane; i < GS_CAP; i += 64) buf[i] = 0ull;
-                __syncthreads();
+            if (cnt - k > GS_NEW - 256) {              // room for a full step
+                gs_flush(buf, k, kp2, cnt, lane);
                 cnt = k;
                 thr_key = buf[k - 1];
-                dirty = false;
             }
             const int64_t j = j0 + (int64_t)lane * 4;
             float vv[4];
@@ -168,45 +225,48 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
 #pragma unroll
             for (int q = 0; q < 4; ++q) if (take[q]) buf[off++] = key[q];
             cnt += total;
-            dirty = dirty || (total > 0);
         }
     } else
     for (int g0 = 0; g0 < ngrp; g0 += 64) {
         const int g = g0 + lane;
-        const bool q = (g < ngrp) && (!gf || gf[g] != 0);
+        const bool q = (g < ngrp) && (gf[g] != 0);
         unsigned long long mask = __ballot(q);
         while (mask) {
-            // two qualifying groups per step: lower half-wave takes the first, upper half the second
-            const int ga = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            int gb = -1;
-            if (mask) { gb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
-            const int gsel = half ? gb : ga;
-            const int64_t col = (int64_t)(g0 + gsel) * 32 + l31;
-            const bool in = (gsel >= 0) && (col < Nc);
-            uint64_t key = 0;
-            if (in) key = rank_key(r[col], col_base + (uint32_t)col);
-            const bool take = in && key > thr_key;
-            const unsigned long long tm = __ballot(take);
-            if (tm) {
-                const int pos = cnt + __popcll(tm & ((1ull << lane) - 1ull));
-                if (take) buf[pos] = key;
-                cnt += __popcll(tm);
-                dirty = true;
-                if (cnt > GS_CAP - 64) {           // the next step could add up to 64 more
-                    __syncthreads();
-                    bitonic_sort_desc<64>(buf, GS_CAP);
-                    for (int i = k + lane; i < GS_CAP; i += 64) buf[i] = 0ull;
-                    __syncthreads();
-                    cnt = k;
-                    thr_key = buf[k - 1];
-                    dirty = false;
+            if (cnt - k > GS_NEW - 256) {          // this step can add up to 4 x 64 keys
+                gs_flush(buf, k, kp2, cnt, lane);
+                cnt = k;
+                thr_key = buf[k - 1];
+            }
+            // up to eight qualifying groups per step: sub-step u gives one to each half-wave
+            int64_t col[4];
+            float v[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                int ga = -1, gb = -1;
+                if (mask) { ga = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+                if (mask) { gb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+                const int gsel = half ? gb : ga;
+                col[u] = (int64_t)(g0 + gsel) * 32 + l31;
+                in[u] = (gsel >= 0) && (col[u] < Nc);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = in[u] ? r[col[u]] : 0.0f;      // four loads in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t key = in[u] ? rank_key(v[u], col_base + (uint32_t)col[u]) : 0ull;
+                const bool take = in[u] && key > thr_key;
+                const unsigned long long tm = __ballot(take);
+                if (tm) {
+                    const int pos = cnt + __popcll(tm & ((1ull << lane) - 1ull));
+                    if (take) buf[pos] = key;
+                    cnt += __popcll(tm);
                 }
             }
         }
     }
     __syncthreads();
-    if (dirty) bitonic_sort_desc<64>(buf, GS_CAP);
+    gs_flush(buf, k, kp2, cnt, lane);
     if (emit) {
         const int64_t orow = row_map ? (int64_t)row_map[row] : row;
         for (int i = lane; i < k; i += 64) {

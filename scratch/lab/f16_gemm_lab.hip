@@ -1,0 +1,273 @@
+// Lab: fp16 MFMA GEMM variants for the filter pass (C = Qh . Gh^T, fp32 accumulate).
+// build: hipcc -O3 --offload-arch=gfx950 -o scratch/lab/f16_gemm_lab scratch/lab/f16_gemm_lab.hip -Linstance-search_amd/csrc -lisx -Wl,-rpath,$PWD/instance-search_amd/csrc
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <cmath>
+
+extern "C" int isx_cosine_sim_f16(const void* Qh, int64_t M, const void* Gh, int64_t N, int D, float* sim, void* stream);
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// ---------------- variant B: 256x256 tile, 512 threads (8 waves 2x4, wave tile 128x64), BK=64, 2 LDS stages ----
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int STAGE_B = (BM + BN) * BK * 2;      // 64 KB
+__device__ __forceinline__ int hswz(int row) { return (row >> 1) & 7; }
+
+template <int ABL>
+__global__ __launch_bounds__(512) void gemm_b(const _Float16* __restrict__ Q, int64_t M, const _Float16* __restrict__ G, int64_t N, int D,
+                                              float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    constexpr int GN = 8;
+    const int per_group = GN * tiles_m, gid = wg / per_group, first_n = gid * GN;
+    const int gsz = min(GN, tiles_n - first_n), within = wg - gid * per_group;
+    const int64_t m0 = (int64_t)(within / gsz) * BM, n0 = (int64_t)(first_n + within % gsz) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // staging: 512 rows x 8 chunks = 4096 chunks / 512 threads = 8 per thread: rows r = j*64 + tid/8 (j<4: A rows, j>=4: B rows)
+    const int sr = tid >> 3, sc = tid & 7;
+    const _Float16* gsrc[8];
+    int ldst[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (j & 3) * 64 + sr;                  // 0..255 within A or B
+        const bool isb = j >= 4;
+        int64_t gr = (isb ? n0 : m0) + row;
+        const int64_t lim = isb ? N : M;
+        gr = gr < lim ? gr : lim - 1;
+        gsrc[j] = (isb ? G : Q) + gr * D + sc * 8;
+        ldst[j] = (isb ? BM * 128 : 0) + row * 128 + ((sc ^ hswz(row)) << 4);
+    }
+    float4 reg[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) reg[j] = (k0 + sc * 8 < D) ? *reinterpret_cast<const float4*>(gsrc[j] + k0) : make_float4(0, 0, 0, 0);
+    };
+    auto lstore = [&](char* st) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(st + ldst[j]) = reg[j];
+    };
+    int a_off[4], b_off[2], a_sw[4], b_sw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + l31; a_off[i] = ra * 128; a_sw[i] = hswz(ra); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int rb = wn * 64 + j * 32 + l31; b_off[j] = BM * 128 + rb * 128; b_sw[j] = hswz(rb); }
+
+    const int nk = (D + BK - 1) / BK;
+    gload(0);
+    lstore(lds);
+    __syncthreads();
+    if (nk > 1) gload(BK);
+    for (int kt = 0; kt < nk; ++kt) {
+        char* cur = lds + (kt & 1) * STAGE_B;
+        char* nxt = lds + ((kt + 1) & 1) * STAGE_B;
+        if (kt + 1 < nk) {
+            if (ABL < 2) lstore(nxt);
+            if (kt + 2 < nk && ABL < 1) gload((kt + 2) * BK);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int c = 2 * s + half;
+            half8 a[4], bb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(cur + a_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = *reinterpret_cast<const half8*>(cur + b_off[j] + ((c ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < M && n < N) C[m * ldc + n] = acc[i][j][e];
+            }
+        }
+}
+
+template <int ABL>
+static void launch_b(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C) {
+    const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)gemm_b<ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B); }
+    hipLaunchKernelGGL(gemm_b<ABL>, dim3(tm * tn), dim3(512), 2 * STAGE_B, 0, Q, M, G, N, D, C, N, tm, tn);
+}
+
+
+// ---------------- variant C: as B, tiles brought in by LDS-DMA (global_load_lds_dwordx4), two static stages ----
+template <int PRE>
+__global__ __launch_bounds__(512) void gemm_c(const _Float16* __restrict__ Q, int64_t M, const _Float16* __restrict__ G, int64_t N, int D,
+                                              float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(1024))) char S0[STAGE_B];
+    __shared__ __attribute__((aligned(1024))) char S1[STAGE_B];
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    constexpr int GN = 8;
+    const int per_group = GN * tiles_m, gid = wg / per_group, first_n = gid * GN;
+    const int gsz = min(GN, tiles_n - first_n), within = wg - gid * per_group;
+    const int64_t m0 = (int64_t)(within / gsz) * BM, n0 = (int64_t)(first_n + within % gsz) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // DMA pieces: wave w fills image rows [w*64, w*64+64) (8 pieces of 8 rows); lane -> row = piece*8 + lane/8, slot = lane%8
+    const _Float16* gsrc[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const int row = wave * 64 + p * 8 + (lane >> 3);    // 0..511: A rows then B rows
+        const bool isb = row >= BM;
+        const int rr = isb ? row - BM : row;
+        int64_t gr = (isb ? n0 : m0) + rr;
+        const int64_t lim = isb ? N : M;
+        gr = gr < lim ? gr : lim - 1;
+        const int c = (lane & 7) ^ hswz(rr);
+        gsrc[p] = (isb ? G : Q) + gr * D + c * 8;
+    }
+    auto dma = [&](char* st, int k0) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[p] + k0),
+                                             (__attribute__((address_space(3))) void*)(st + (wave * 64 + p * 8) * 128), 16, 0, 0);
+    };
+    int a_off[4], b_off[2], a_sw[4], b_sw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + l31; a_off[i] = ra * 128; a_sw[i] = hswz(ra); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int rb = wn * 64 + j * 32 + l31; b_off[j] = BM * 128 + rb * 128; b_sw[j] = hswz(rb); }
+
+    auto compute = [&](const char* cur) {
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int c = 2 * s + half;
+            half8 a[4], bb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(cur + a_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = *reinterpret_cast<const half8*>(cur + b_off[j] + ((c ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int nk = D / BK;                      // D % 64 == 0 required
+    dma(S0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 1 < nk) dma(S1, (kt + 1) * BK);
+        compute(S0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) dma(S0, (kt + 2) * BK);
+            compute(S1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < M && n < N) C[m * ldc + n] = acc[i][j][e];
+            }
+        }
+}
+
+static void launch_c(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C) {
+    const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_c<0>, dim3(tm * tn), dim3(512), 0, 0, Q, M, G, N, D, C, N, tm, tn);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <class F>
+static float time_ms(F f, int it = 5) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    f(); CK(hipDeviceSynchronize());
+    hipEventRecord(a);
+    for (int i = 0; i < it; ++i) f();
+    hipEventRecord(b); CK(hipEventSynchronize(b));
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms / it;
+}
+
+int main(int argc, char** argv) {
+    const int64_t M = argc > 1 ? atoll(argv[1]) : 10000, N = argc > 2 ? atoll(argv[2]) : 32768;
+    const int D = argc > 3 ? atoi(argv[3]) : 2048;
+    std::vector<_Float16> hq((size_t)M * D), hg((size_t)N * D);
+    uint32_t s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((int)(s >> 8) & 0xFFFF) / 65536.0f - 0.5f; };
+    for (auto& v : hq) v = (_Float16)(rnd() * 0.05f);
+    for (auto& v : hg) v = (_Float16)(rnd() * 0.05f);
+    _Float16 *dq, *dg; float *c0, *c1;
+    CK(hipMalloc(&dq, hq.size() * 2)); CK(hipMalloc(&dg, hg.size() * 2));
+    CK(hipMalloc(&c0, (size_t)M * N * 4)); CK(hipMalloc(&c1, (size_t)M * N * 4));
+    CK(hipMemcpy(dq, hq.data(), hq.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dg, hg.data(), hg.size() * 2, hipMemcpyHostToDevice));
+    const double fl = 2.0 * M * N * D;
+    float t = time_ms([&] { isx_cosine_sim_f16(dq, M, dg, N, D, c0, nullptr); });
+    printf("baseline 128x128      : %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
+    t = time_ms([&] { launch_b<0>(dq, M, dg, N, D, c1); });
+    CK(hipGetLastError());
+    printf("B 256x256 2-stage     : %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
+    // compare
+    std::vector<float> h0((size_t)M * N), h1((size_t)M * N);
+    CK(hipMemcpy(h0.data(), c0, h0.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(h1.data(), c1, h1.size() * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0; double mx = 0;
+    for (size_t i = 0; i < h0.size(); ++i) { if (h0[i] != h1[i]) { ++bad; mx = fmax(mx, fabs((double)h0[i] - h1[i])); } }
+    printf("B vs baseline: %zu mismatches (max diff %.3g)\n", bad, mx);
+    CK(hipMemset(c1, 0, (size_t)M * N * 4));
+    t = time_ms([&] { launch_c(dq, M, dg, N, D, c1); });
+    CK(hipGetLastError());
+    printf("C 256x256 LDS-DMA     : %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
+    CK(hipMemcpy(h1.data(), c1, h1.size() * 4, hipMemcpyDeviceToHost));
+    bad = 0; mx = 0;
+    for (size_t i = 0; i < h0.size(); ++i) { if (h0[i] != h1[i]) { ++bad; mx = fmax(mx, fabs((double)h0[i] - h1[i])); } }
+    printf("C vs baseline: %zu mismatches (max diff %.3g)\n", bad, mx);
+    t = time_ms([&] { launch_b<1>(dq, M, dg, N, D, c1); });
+    printf("B abl1 (no global loads in loop): %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
+    t = time_ms([&] { launch_b<2>(dq, M, dg, N, D, c1); });
+    printf("B abl2 (no loads, no LDS stores): %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
+    return 0;
+}
