@@ -40,17 +40,23 @@ typedef float f32x16_t __attribute__((ext_vector_type(16)));
 // ---- 1. fp32 -> fp16 rows ------------------------------------------------------------------------
 // stats words are bit patterns of non-negative floats (unsigned order == float order) accumulated with
 // atomicMax: order independent, deterministic.  stats[0] = max squared row norm (upper bound), stats[1] = max |x|.
+__device__ __forceinline__ float nanmax(float a, float b) { return (b > a || b != b) ? b : a; }     // NaN-propagating
+
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t n, unsigned* __restrict__ stats) {
     float mx = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float v = fabsf(x[i]);
-        mx = (v > mx || v != v) ? v : mx;                 // NaN-propagating
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nth = (int64_t)gridDim.x * 256;
+    if ((((uintptr_t)x) & 15) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = tid; i < n4; i += nth) {
+            const float4 v = reinterpret_cast<const float4*>(x)[i];
+            mx = nanmax(nanmax(mx, fabsf(v.x)), nanmax(fabsf(v.y), nanmax(fabsf(v.z), fabsf(v.w))));
+        }
+        for (int64_t i = (n4 << 2) + tid; i < n; i += nth) mx = nanmax(mx, fabsf(x[i]));
+    } else {
+        for (int64_t i = tid; i < n; i += nth) mx = nanmax(mx, fabsf(x[i]));
     }
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        const float o = __shfl_xor(mx, s, 64);
-        mx = (o > mx || o != o) ? o : mx;
-    }
+    for (int s = 32; s > 0; s >>= 1) mx = nanmax(mx, __shfl_xor(mx, s, 64));
     if (!(mx >= 0.0f)) mx = INFINITY;                     // NaN -> unusable
     if ((threadIdx.x & 63) == 0) atomicMax(&stats[1], __float_as_uint(mx));
 }
@@ -71,18 +77,31 @@ __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restric
     const float* r = x + row * D;
     _Float16* o = h + row * D;
     float ss = 0.0f, mx = 0.0f;
-    for (int j = lane; j < D; j += 64) {
-        const float v = r[j];
-        o[j] = (_Float16)(v * scale);            // power-of-two scaling is exact; conversion RNE
-        ss += v * v;
-        mx = (fabsf(v) > mx || v != v) ? fabsf(v) : mx;
+    if ((D & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)h)) & 15) == 0) {
+        // 8 elements per lane and step: two 16-B loads, one 16-B store
+        for (int j = lane * 8; j < D; j += 512) {
+            const float4 v0 = *reinterpret_cast<const float4*>(r + j), v1 = *reinterpret_cast<const float4*>(r + j + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            half8 hv;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                hv[q] = (_Float16)(v[q] * scale);    // power-of-two scaling is exact; conversion RNE
+                ss += v[q] * v[q];
+                mx = nanmax(mx, fabsf(v[q]));
+            }
+            *reinterpret_cast<half8*>(o + j) = hv;
+        }
+    } else {
+        for (int j = lane; j < D; j += 64) {
+            const float v = r[j];
+            o[j] = (_Float16)(v * scale);
+            ss += v * v;
+            mx = nanmax(mx, fabsf(v));
+        }
     }
     ss = wave_sum(ss);
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) {
-        const float o2 = __shfl_xor(mx, s, 64);
-        mx = (o2 > mx || o2 != o2) ? o2 : mx;
-    }
+    for (int s = 32; s > 0; s >>= 1) mx = nanmax(mx, __shfl_xor(mx, s, 64));
     ss *= 1.000001f;                                                    // slight inflation: norm2 is an upper bound
     if (!(ss >= 0.0f)) ss = INFINITY;
     if (!(mx >= 0.0f)) mx = INFINITY;

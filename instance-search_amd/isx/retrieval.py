@@ -3,7 +3,9 @@
 The reference is single-device (one torch.mm, test/classif_finetune_test.py:82); this is the
 MI355X-native extension the north star asks for.  One process per GPU; rank p holds gallery
 rows [lo_p, hi_p) (contiguous split).  A search is
-    1. local fused cosine top-k on the shard with idx_base = lo_p     (libisx isx_cosine_topk)
+    1. local fused cosine top-k on the shard with idx_base = lo_p     (libisx isx_cosine_topk_fast:
+       fp16-MFMA filter + exact fp32 re-scoring, bit-identical to isx_cosine_topk; the fp16 image of
+       the shard is built once and cached)
     2. ONE all-gather of the (M,k) fp32 scores and (M,k) int64 global indices over RCCL/xGMI
        (12 B per entry: 12 MB per rank at M = 10k, k = 100 -- tiny next to the GEMM)
     3. canonical merge of the P*k candidates per query                  (libisx isx_topk_merge)
@@ -35,11 +37,14 @@ def _canonical_topk_cpu(scores, idx, k):
     return s1.gather(1, order2)[:, :k], i1.gather(1, order2)[:, :k]
 
 
-def local_topk(Q, G, k, idx_base=0, ws=None):
-    """Canonical top-k of Q @ G.T on one shard, global indices."""
+def local_topk(Q, G, k, idx_base=0, ws=None, gallery_f16=None):
+    """Canonical top-k of Q @ G.T on one shard, global indices.  gallery_f16: the cached
+    ops.gallery_to_f16(G) pair selects the filter + exact re-scoring path (same result)."""
     M = Q.size(0)
     if Q.is_cuda:
         from . import ops
+        if gallery_f16 is not None:
+            return ops.cosine_topk_fast(Q, G, k, idx_base=idx_base, gallery_f16=gallery_f16, ws=ws)
         return ops.cosine_topk(Q, G, k, idx_base=idx_base, ws=ws)
     sim = Q @ G.t()
     n = G.size(0)
@@ -88,12 +93,14 @@ class NativeComm(object):
 class ShardedGallery(object):
     """This rank's slice of a row-sharded descriptor gallery."""
 
-    def __init__(self, shard, idx_base, group=None, native_comm=None):
+    def __init__(self, shard, idx_base, group=None, native_comm=None, fast=True):
         self.shard = shard.contiguous()
         self.idx_base = int(idx_base)
         self.group = group
         self.native_comm = native_comm        # NativeComm: all-gather issued by libisx instead of torch.distributed
+        self.fast = bool(fast) and self.shard.is_cuda
         self._ws = None
+        self._f16 = None                      # (Gh, gstats), built on first search
 
     @classmethod
     def from_full(cls, gallery, group=None):
@@ -107,14 +114,20 @@ class ShardedGallery(object):
         if not self.shard.is_cuda:
             return None
         from . import ops
-        need = ops.cosine_topk_workspace(M, self.shard.size(0), self.shard.size(1), k)
+        if self.fast:
+            need = ops.cosine_topk_fast_workspace(M, self.shard.size(0), self.shard.size(1), k, True)
+        else:
+            need = ops.cosine_topk_workspace(M, self.shard.size(0), self.shard.size(1), k)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=self.shard.device)
         return self._ws
 
     def search(self, Q, k):
         """Global canonical top-k for the (replicated) query block Q: (scores (M,k), idx (M,k))."""
-        s, i = local_topk(Q, self.shard, k, self.idx_base, self._workspace(Q.size(0), k))
+        if self.fast and self._f16 is None and self.shard.size(0) > 0:
+            from . import ops
+            self._f16 = ops.gallery_to_f16(self.shard)
+        s, i = local_topk(Q, self.shard, k, self.idx_base, self._workspace(Q.size(0), k), self._f16 if self.fast else None)
         if self.native_comm is not None and s.is_cuda:
             if self.native_comm.nranks == 1:
                 return s, i

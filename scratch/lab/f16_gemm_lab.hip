@@ -218,6 +218,357 @@ static void launch_c(const _Float16* Q, int64_t M, const _Float16* G, int64_t N,
     hipLaunchKernelGGL(gemm_c<0>, dim3(tm * tn), dim3(512), 0, 0, Q, M, G, N, D, C, N, tm, tn);
 }
 
+// ---------------- variant E: as D with asm loads and explicit vmcnt waits; as B, but two staging register sets, unconditional loads (D % 64 == 0), LDS stores
+// interleaved with the MFMAs of the running k-tile ----
+template <int SCHED>
+__global__ __launch_bounds__(512) void gemm_e(const _Float16* __restrict__ Q, int64_t M, const _Float16* __restrict__ G, int64_t N, int D,
+                                              float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char S0[STAGE_B];
+    __shared__ __attribute__((aligned(16))) char S1[STAGE_B];
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    constexpr int GN = 8;
+    const int per_group = GN * tiles_m, gid = wg / per_group, first_n = gid * GN;
+    const int gsz = min(GN, tiles_n - first_n), within = wg - gid * per_group;
+    const int64_t m0 = (int64_t)(within / gsz) * BM, n0 = (int64_t)(first_n + within % gsz) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int sr = tid >> 3, sc = tid & 7;
+    const _Float16* gsrc[8];
+    int ldst[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (j & 3) * 64 + sr;
+        const bool isb = j >= 4;
+        int64_t gr = (isb ? n0 : m0) + row;
+        const int64_t lim = isb ? N : M;
+        gr = gr < lim ? gr : lim - 1;
+        gsrc[j] = (isb ? G : Q) + gr * D + sc * 8;
+        ldst[j] = (isb ? BM * 128 : 0) + row * 128 + ((sc ^ hswz(row)) << 4);
+    }
+    int a_off[4], b_off[2], a_sw[4], b_sw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + l31; a_off[i] = ra * 128; a_sw[i] = hswz(ra); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int rb = wn * 64 + j * 32 + l31; b_off[j] = BM * 128 + rb * 128; b_sw[j] = hswz(rb); }
+
+    float4 rA[8], rB[8];
+    // loads by inline asm: the compiler's waitcnt pass cannot count them, the waits below are explicit
+    auto gload = [&](float4 (&reg)[8], int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(reg[j]) : "v"(gsrc[j] + k0) : "memory");
+    };
+    // compute one k-tile from cur while the staged registers go to nxt, two stores per k16 step
+    auto step = [&](const char* cur, char* nxt, const float4 (&reg)[8]) {
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int c = 2 * s + half;
+            half8 a[4], bb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(cur + a_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = *reinterpret_cast<const half8*>(cur + b_off[j] + ((c ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bb[j], acc[i][j], 0, 0, 0);
+                if (i == 1) *reinterpret_cast<float4*>(nxt + ldst[2 * s]) = reg[2 * s];
+                if (i == 3) *reinterpret_cast<float4*>(nxt + ldst[2 * s + 1]) = reg[2 * s + 1];
+            }
+            if (SCHED) {
+                // 6 ds_read, then (2 MFMA, ...) with the two ds_write after MFMA 4 and 8
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+        }
+    };
+
+    const int nk = D / BK;
+    gload(rA, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(S0 + ldst[j]) = rA[j];
+    __syncthreads();
+    gload(rA, BK);                                   // nk even and >= 2 (D % 128 == 0)
+    for (int kt = 0; kt < nk; kt += 2) {
+        // loads past the last tile re-read it (their stores land in a stage nobody reads again): straight-line
+        // code, so the compiler can count outstanding loads exactly (vmcnt(8), not vmcnt(0))
+        gload(rB, min(kt + 2, nk - 1) * BK);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // rA (the 8 older loads) has landed
+        step(S0, S1, rA);
+        __syncthreads();
+        gload(rA, min(kt + 3, nk - 1) * BK);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        step(S1, S0, rB);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < M && n < N) C[m * ldc + n] = acc[i][j][e];
+            }
+        }
+}
+
+template <int SCHED>
+static void launch_e(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C) {
+    const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_e<SCHED>, dim3(tm * tn), dim3(512), 0, 0, Q, M, G, N, D, C, N, tm, tn);
+}
+
+// ---------------- variant D: as B, but two staging register sets, unconditional loads (D % 64 == 0), LDS stores
+// interleaved with the MFMAs of the running k-tile ----
+template <int SCHED>
+__global__ __launch_bounds__(512) void gemm_d(const _Float16* __restrict__ Q, int64_t M, const _Float16* __restrict__ G, int64_t N, int D,
+                                              float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char S0[STAGE_B];
+    __shared__ __attribute__((aligned(16))) char S1[STAGE_B];
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    constexpr int GN = 8;
+    const int per_group = GN * tiles_m, gid = wg / per_group, first_n = gid * GN;
+    const int gsz = min(GN, tiles_n - first_n), within = wg - gid * per_group;
+    const int64_t m0 = (int64_t)(within / gsz) * BM, n0 = (int64_t)(first_n + within % gsz) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int sr = tid >> 3, sc = tid & 7;
+    const _Float16* gsrc[8];
+    int ldst[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (j & 3) * 64 + sr;
+        const bool isb = j >= 4;
+        int64_t gr = (isb ? n0 : m0) + row;
+        const int64_t lim = isb ? N : M;
+        gr = gr < lim ? gr : lim - 1;
+        gsrc[j] = (isb ? G : Q) + gr * D + sc * 8;
+        ldst[j] = (isb ? BM * 128 : 0) + row * 128 + ((sc ^ hswz(row)) << 4);
+    }
+    int a_off[4], b_off[2], a_sw[4], b_sw[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + l31; a_off[i] = ra * 128; a_sw[i] = hswz(ra); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const int rb = wn * 64 + j * 32 + l31; b_off[j] = BM * 128 + rb * 128; b_sw[j] = hswz(rb); }
+
+    float4 rA[8], rB[8];
+    auto gload = [&](float4 (&reg)[8], int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) reg[j] = *reinterpret_cast<const float4*>(gsrc[j] + k0);
+    };
+    // compute one k-tile from cur while the staged registers go to nxt, two stores per k16 step
+    auto step = [&](const char* cur, char* nxt, const float4 (&reg)[8]) {
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            const int c = 2 * s + half;
+            half8 a[4], bb[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(cur + a_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bb[j] = *reinterpret_cast<const half8*>(cur + b_off[j] + ((c ^ b_sw[j]) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bb[j], acc[i][j], 0, 0, 0);
+                if (i == 1) *reinterpret_cast<float4*>(nxt + ldst[2 * s]) = reg[2 * s];
+                if (i == 3) *reinterpret_cast<float4*>(nxt + ldst[2 * s + 1]) = reg[2 * s + 1];
+            }
+            if (SCHED) {
+                // 6 ds_read, then (2 MFMA, ...) with the two ds_write after MFMA 4 and 8
+                __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+        }
+    };
+
+    const int nk = D / BK;
+    gload(rA, 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<float4*>(S0 + ldst[j]) = rA[j];
+    __syncthreads();
+    gload(rA, BK);                                   // nk even and >= 2 (D % 128 == 0)
+    for (int kt = 0; kt < nk; kt += 2) {
+        // loads past the last tile re-read it (their stores land in a stage nobody reads again): straight-line
+        // code, so the compiler can count outstanding loads exactly (vmcnt(8), not vmcnt(0))
+        gload(rB, min(kt + 2, nk - 1) * BK);
+        step(S0, S1, rA);
+        __syncthreads();
+        gload(rA, min(kt + 3, nk - 1) * BK);
+        step(S1, S0, rB);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < M && n < N) C[m * ldc + n] = acc[i][j][e];
+            }
+        }
+}
+
+template <int SCHED>
+static void launch_d(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C) {
+    const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_d<SCHED>, dim3(tm * tn), dim3(512), 0, 0, Q, M, G, N, D, C, N, tm, tn);
+}
+
+// ---------------- variant F: A (queries) through LDS as in B; B (gallery) fragments straight from a PRE-TILED
+// global image Gt[row group of 32][k16 step][lane][8 halfs] (one coalesced 1 KiB load per fragment), no LDS for B ----
+constexpr int STAGE_A = BM * BK * 2;     // 32 KB
+__global__ __launch_bounds__(512) void gemm_f(const _Float16* __restrict__ Q, int64_t M, const _Float16* __restrict__ Gt, int64_t N, int D,
+                                              float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char S0[STAGE_A];
+    __shared__ __attribute__((aligned(16))) char S1[STAGE_A];
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    constexpr int GN = 8;
+    const int per_group = GN * tiles_m, gid = wg / per_group, first_n = gid * GN;
+    const int gsz = min(GN, tiles_n - first_n), within = wg - gid * per_group;
+    const int64_t m0 = (int64_t)(within / gsz) * BM, n0 = (int64_t)(first_n + within % gsz) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, l31 = lane & 31, half = lane >> 5;
+
+    f32x16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int sr = tid >> 3, sc = tid & 7;
+    const _Float16* gsrc[4];
+    int ldst[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = j * 64 + sr;
+        int64_t gr = m0 + row;
+        gr = gr < M ? gr : M - 1;
+        gsrc[j] = Q + gr * D + sc * 8;
+        ldst[j] = row * 128 + ((sc ^ hswz(row)) << 4);
+    }
+    int a_off[4], a_sw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ra = wm * 128 + i * 32 + l31; a_off[i] = ra * 128; a_sw[i] = hswz(ra); }
+    // B fragment source: row group (n0/32 + wn*2 + j), k16 step ks -> + ks * 512 halfs; lane * 8 halfs
+    const int64_t ngroups = (N + 31) / 32;
+    const _Float16* bsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        int64_t g = n0 / 32 + wn * 2 + j;
+        g = g < ngroups ? g : ngroups - 1;
+        bsrc[j] = Gt + g * (int64_t)32 * D + lane * 8;
+    }
+    float4 aS[4];
+    half8 b0[4][2], b1[4][2];
+    auto aload = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(aS[j]) : "v"(gsrc[j] + k0) : "memory");
+    };
+    auto bload = [&](half8 (&bf)[4][2], int k0) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bf[s2][j]) : "v"(bsrc[j] + (int64_t)(k0 / 16 + s2) * 512) : "memory");
+    };
+    auto astore = [&](char* st) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(st + ldst[j]) = aS[j];
+    };
+    auto compute = [&](const char* cur, const half8 (&bf)[4][2]) {
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 16; ++s2) {
+            const int c = 2 * s2 + half;
+            half8 a[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const half8*>(cur + a_off[i] + ((c ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], bf[s2][j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int nk = D / BK;                       // even, >= 2
+    aload(0);
+    bload(b0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    astore(S0);
+    __syncthreads();
+    aload(BK);
+    bload(b1, BK);
+    for (int kt = 0; kt < nk; kt += 2) {
+        // even: compute tile kt (S0, b0); A tile kt+1 (in aS) -> S1; fetch A tile kt+2 and B frags kt+2
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // aS and b0 landed (the 8 b1 loads may still fly)
+        astore(S1);
+        aload(min(kt + 2, nk - 1) * BK);
+        compute(S0, b0);
+        bload(b0, min(kt + 2, nk - 1) * BK);
+        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // aS landed (the 8 b0 loads may still fly)
+        astore(S0);
+        aload(min(kt + 3, nk - 1) * BK);
+        compute(S1, b1);
+        bload(b1, min(kt + 3, nk - 1) * BK);
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = m0 + wm * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (m < M && n < N) C[m * ldc + n] = acc[i][j][e];
+            }
+        }
+}
+
+static void launch_f(const _Float16* Q, int64_t M, const _Float16* Gt, int64_t N, int D, float* C) {
+    const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
+    hipLaunchKernelGGL(gemm_f, dim3(tm * tn), dim3(512), 0, 0, Q, M, Gt, N, D, C, N, tm, tn);
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <class F>
@@ -265,6 +616,48 @@ int main(int argc, char** argv) {
     bad = 0; mx = 0;
     for (size_t i = 0; i < h0.size(); ++i) { if (h0[i] != h1[i]) { ++bad; mx = fmax(mx, fabs((double)h0[i] - h1[i])); } }
     printf("C vs baseline: %zu mismatches (max diff %.3g)\n", bad, mx);
+    {
+        // pre-tiled gallery image
+        const int64_t ng = (N + 31) / 32;
+        std::vector<_Float16> ht((size_t)ng * 32 * D);
+        for (int64_t g = 0; g < ng; ++g)
+            for (int ks = 0; ks < D / 16; ++ks)
+                for (int ln = 0; ln < 64; ++ln) {
+                    int64_t row = g * 32 + (ln & 31); if (row >= N) row = N - 1;
+                    const int k = ks * 16 + (ln >> 5) * 8;
+                    for (int x = 0; x < 8; ++x) ht[((size_t)(g * (D / 16) + ks) * 64 + ln) * 8 + x] = hg[(size_t)row * D + k + x];
+                }
+        _Float16* dt; CK(hipMalloc(&dt, ht.size() * 2));
+        CK(hipMemcpy(dt, ht.data(), ht.size() * 2, hipMemcpyHostToDevice));
+        CK(hipMemset(c1, 0, (size_t)M * N * 4));
+        t = time_ms([&] { launch_f(dq, M, dt, N, D, c1); });
+        CK(hipGetLastError());
+        printf("F 256x256 B direct     : %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
+        CK(hipMemcpy(h1.data(), c1, h1.size() * 4, hipMemcpyDeviceToHost));
+        bad = 0; mx = 0;
+        for (size_t i = 0; i < h0.size(); ++i) { if (h0[i] != h1[i]) { ++bad; mx = fmax(mx, fabs((double)h0[i] - h1[i])); } }
+        printf("F vs baseline: %zu mismatches (max diff %.3g)\n", bad, mx);
+    }
+    for (int v = 1; v < 2; ++v) {
+        CK(hipMemset(c1, 0, (size_t)M * N * 4));
+        t = time_ms([&] { if (v) launch_e<1>(dq, M, dg, N, D, c1); else launch_e<0>(dq, M, dg, N, D, c1); });
+        CK(hipGetLastError());
+        printf("E%d 256x256 asm loads  : %.3f ms  %.0f TF\n", v, t, fl / t * 1e-9);
+        CK(hipMemcpy(h1.data(), c1, h1.size() * 4, hipMemcpyDeviceToHost));
+        bad = 0; mx = 0;
+        for (size_t i = 0; i < h0.size(); ++i) { if (h0[i] != h1[i]) { ++bad; mx = fmax(mx, fabs((double)h0[i] - h1[i])); } }
+        printf("E%d vs baseline: %zu mismatches (max diff %.3g)\n", v, bad, mx);
+    }
+    for (int v = 0; v < 0; ++v) {
+        CK(hipMemset(c1, 0, (size_t)M * N * 4));
+        t = time_ms([&] { if (v) launch_d<1>(dq, M, dg, N, D, c1); else launch_d<0>(dq, M, dg, N, D, c1); });
+        CK(hipGetLastError());
+        printf("D%d 256x256 interleaved: %.3f ms  %.0f TF\n", v, t, fl / t * 1e-9);
+        CK(hipMemcpy(h1.data(), c1, h1.size() * 4, hipMemcpyDeviceToHost));
+        bad = 0; mx = 0;
+        for (size_t i = 0; i < h0.size(); ++i) { if (h0[i] != h1[i]) { ++bad; mx = fmax(mx, fabs((double)h0[i] - h1[i])); } }
+        printf("D%d vs baseline: %zu mismatches (max diff %.3g)\n", v, bad, mx);
+    }
     t = time_ms([&] { launch_b<1>(dq, M, dg, N, D, c1); });
     printf("B abl1 (no global loads in loop): %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
     t = time_ms([&] { launch_b<2>(dq, M, dg, N, D, c1); });

@@ -1,0 +1,210 @@
+"""isx_cosine_topk_fast (fp16-MFMA filter + exact fp32 re-scoring, csrc/fast.hip) must return the SAME
+bits as the CPU oracle / isx_cosine_topk for every input: random unit vectors, post-ReLU descriptors,
+dense clusters that overflow the candidate window (exact-fallback rows), exact ties, adversarial
+column orders, un-normalised magnitudes, values far below the fp16 normal range, NaN-free extremes.
+Also: the fp16 building blocks against numpy's IEEE half arithmetic (incl. subnormals)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def unit(rng, n, d):
+    x = rng.standard_normal((n, d), dtype=np.float32)
+    return (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from isx import ops as o
+    return o
+
+
+def fallback_rows(ws, M, N, D, k, cached):
+    from isx._lib import lib
+    f = lib().isx_debug_fast_fallback_rows
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    return f(ws.data_ptr(), M, N, D, k, 1 if cached else 0)
+
+
+def run_fast(ops, Q, G, k, idx_base=0, cached=True):
+    Qd, Gd = dev(Q), dev(G)
+    M, D = Q.shape
+    N = G.shape[0]
+    gh = ops.gallery_to_f16(Gd) if cached else None
+    ws = torch.empty((ops.cosine_topk_fast_workspace(M, N, D, k, cached),), dtype=torch.uint8, device="cuda")
+    ts, ti = ops.cosine_topk_fast(Qd, Gd, k, idx_base=idx_base, gallery_f16=gh, ws=ws)
+    return host(ts), host(ti), fallback_rows(ws, M, N, D, k, cached)
+
+
+def check_vs_oracle(ops, Q, G, k, idx_base=0, cached=True):
+    want_s, want_i = O.cosine_topk(Q, G, k, idx_base=idx_base)
+    ts, ti, fb = run_fast(ops, Q, G, k, idx_base, cached)
+    np.testing.assert_array_equal(ti, want_i)
+    np.testing.assert_array_equal(ts.view(np.int32), want_s.view(np.int32))
+    return fb
+
+
+@pytest.mark.parametrize("M,N,D,k", [(37, 3000, 64, 10), (130, 9000, 256, 100), (5, 40000, 48, 1), (64, 12000, 128, 128),
+                                     (257, 20000, 512, 33), (3, 70000, 8, 5)])
+@pytest.mark.parametrize("cached", [True, False])
+def test_random_unit_vectors(ops, M, N, D, k, cached):
+    rng = np.random.default_rng(N + k)
+    Q, G = unit(rng, M, D), unit(rng, N, D)
+    G[N // 2] = G[3]
+    G[N - 1] = G[3]                               # duplicated rows: exact ties, index order decides
+    fb = check_vs_oracle(ops, Q, G, k, idx_base=11, cached=cached)
+    assert fb >= 0                                # the filter path ran (not the whole-call fp32 delegate)
+
+
+def test_post_relu_descriptors(ops):
+    rng = np.random.default_rng(5)
+    Q = np.maximum(rng.standard_normal((200, 512), dtype=np.float32), 0)
+    G = np.maximum(rng.standard_normal((20000, 512), dtype=np.float32), 0)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    G /= np.linalg.norm(G, axis=1, keepdims=True)
+    check_vs_oracle(ops, Q, G, 50)
+
+
+def test_dense_clusters_take_the_exact_fallback(ops):
+    """Every gallery row is a 1e-4 perturbation of one of 8 centres: thousands of scores fall inside the
+    error window of the k-th best, the KL candidates cannot cover it, the rows must be recomputed exactly."""
+    rng = np.random.default_rng(7)
+    c = unit(rng, 8, 256)
+    G = c[rng.integers(0, 8, 20000)] + 1e-4 * rng.standard_normal((20000, 256), dtype=np.float32)
+    G = (G / np.linalg.norm(G, axis=1, keepdims=True)).astype(np.float32)
+    Q = unit(rng, 150, 256)
+    fb = check_vs_oracle(ops, Q, G, 20)
+    assert fb == 150
+
+
+def test_mixed_rows_some_fallback(ops):
+    rng = np.random.default_rng(8)
+    c = unit(rng, 1, 256)
+    G = np.concatenate([unit(rng, 10000, 256), c + 1e-5 * rng.standard_normal((2000, 256), dtype=np.float32)]).astype(np.float32)
+    Q = np.concatenate([unit(rng, 100, 256), c + 1e-3 * rng.standard_normal((100, 256), dtype=np.float32)]).astype(np.float32)
+    fb = check_vs_oracle(ops, Q, G, 30, idx_base=5)
+    assert 0 < fb < 200                           # near-centre queries fall back, the others do not
+
+
+@pytest.mark.parametrize("order", ["ascending", "descending"])
+def test_adversarial_column_order(ops, order):
+    rng = np.random.default_rng(9)
+    M, N, D, k = 21, 40000, 64, 100
+    Q, G = unit(rng, M, D), unit(rng, N, D)
+    s0 = G @ Q[0]
+    G = G[np.argsort(s0 if order == "ascending" else -s0)]
+    G[9000] = G[17]; G[39999] = G[17]; G[8191] = G[8192]
+    check_vs_oracle(ops, Q, G, k)
+
+
+@pytest.mark.parametrize("qs,gs", [(300.0, 1000.0), (1e-4, 1e-3), (1.0, 1e-6), (3e4, 3e4)])
+def test_unnormalised_magnitudes(ops, qs, gs):
+    rng = np.random.default_rng(13)
+    Q, G = unit(rng, 80, 128) * np.float32(qs), unit(rng, 8000, 128) * np.float32(gs)
+    fb = check_vs_oracle(ops, Q, G, 10)
+    assert fb >= 0
+
+
+def test_out_of_fp16_range_runs_exact(ops):
+    rng = np.random.default_rng(14)
+    Q, G = unit(rng, 50, 128) * np.float32(1e6), unit(rng, 8000, 128)
+    fb = check_vs_oracle(ops, Q, G, 10)
+    assert fb == 50                               # max|Q| > 2^15: every row takes the exact path
+
+
+def test_wide_dynamic_range_inside_rows(ops):
+    """Half of every row is 1e-7 times smaller than the rest (below the fp16 normal range even after scaling)."""
+    rng = np.random.default_rng(15)
+    Q = np.concatenate([unit(rng, 90, 128), 1e-7 * unit(rng, 90, 128)], axis=1).astype(np.float32)
+    G = np.concatenate([unit(rng, 9000, 128), 1e-7 * unit(rng, 9000, 128)], axis=1).astype(np.float32)
+    check_vs_oracle(ops, Q, G, 10)
+
+
+@pytest.mark.parametrize("M,N,D,k", [(10, 200, 64, 10), (10, 5000, 60, 10), (10, 5000, 64, 200)])
+def test_shapes_outside_the_filter_delegate_to_fp32(ops, M, N, D, k):
+    rng = np.random.default_rng(16)
+    Q, G = unit(rng, M, D), unit(rng, N, D)
+    fb = check_vs_oracle(ops, Q, G, k, cached=False)
+    assert fb == -1
+
+
+def test_big_tiles_and_many_chunks(ops):
+    """Large enough for the 256x256 fp16 tile and several filtered chunks; compared with isx_cosine_topk."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Q = torch.randn(3000, 256, device="cuda", generator=g)
+    G = torch.randn(60000, 256, device="cuda", generator=g)
+    Q, G = ops.l2norm_rows(Q), ops.l2norm_rows(G)
+    ref = ops.cosine_topk(Q, G, 100, idx_base=7)
+    got = ops.cosine_topk_fast(Q, G, 100, idx_base=7, gallery_f16=ops.gallery_to_f16(G))
+    assert torch.equal(ref[1], got[1])
+    assert torch.equal(ref[0].view(torch.int32), got[0].view(torch.int32))
+    # small workspace: narrow chunks, same answer
+    need = ops.cosine_topk_fast_workspace(3000, 60000, 256, 100, True)
+    ws = torch.empty((need // 3,), dtype=torch.uint8, device="cuda")
+    got = ops.cosine_topk_fast(Q, G, 100, idx_base=7, gallery_f16=ops.gallery_to_f16(G), ws=ws)
+    assert torch.equal(ref[1], got[1]) and torch.equal(ref[0].view(torch.int32), got[0].view(torch.int32))
+
+
+# ------------------------------------------------------------------ building blocks
+def test_rows_to_f16_matches_ieee_half(ops):
+    rng = np.random.default_rng(20)
+    x = rng.standard_normal((67, 200), dtype=np.float32)
+    x[0, :50] = rng.standard_normal(50).astype(np.float32) * 1e-6       # fp16 subnormal range
+    x[1, :8] = [65504.0, -65504.0, 6.1e-5, 5.96e-8, 2.9e-8, 0.0, -0.0, 1.0009765625]
+    h, n2, am = ops.rows_to_f16(dev(x))
+    np.testing.assert_array_equal(host(h).view(np.uint16), x.astype(np.float16).view(np.uint16))     # RNE, gradual underflow
+    assert (host(n2) >= (x.astype(np.float64) ** 2).sum(1) * (1 - 1e-6)).all()
+    np.testing.assert_array_equal(host(am), np.abs(x).max(1))
+
+
+@pytest.mark.parametrize("M,N,D", [(130, 257, 64), (300, 1000, 200), (257, 600, 2048)])
+def test_f16_gemm_is_exact_on_half_inputs(ops, M, N, D):
+    """fp16 products are exact in fp32; only the fp32 accumulation rounds: <= D * 2^-23 relative to sum |q g|.
+    Rows include fp16 SUBNORMALS: the matrix cores must not flush them (the error bound of the fast path
+    assumes flushing at worst, this documents the actual behaviour)."""
+    rng = np.random.default_rng(D)
+    q = rng.standard_normal((M, D)).astype(np.float16)
+    g = rng.standard_normal((N, D)).astype(np.float16)
+    q[0] = (rng.standard_normal(D) * 3e-6).astype(np.float16)            # subnormal halves
+    g[0] = (rng.standard_normal(D) * 3e-6).astype(np.float16)
+    sim = host(ops.cosine_sim_f16(dev(q), dev(g)))
+    want = q.astype(np.float64) @ g.astype(np.float64).T
+    bound = (np.abs(q.astype(np.float64)) @ np.abs(g.astype(np.float64)).T) * D * 2.0 ** -23 + 1e-30
+    assert (np.abs(sim - want) <= bound).all()
+    assert np.abs(sim[0, 1:]).max() > 0                                  # subnormal operands contributed
+
+
+def test_gallery_to_f16_scaling(ops):
+    rng = np.random.default_rng(21)
+    G = unit(rng, 500, 64) * np.float32(0.3)
+    gh, gstats = ops.gallery_to_f16(dev(G))
+    amax = np.abs(G).max()
+    scale = 2.0 ** (13 - np.floor(np.log2(amax)))
+    np.testing.assert_array_equal(host(gh).view(np.uint16), (G * np.float32(scale)).astype(np.float16).view(np.uint16))
+    st = host(gstats)
+    assert st[1] == amax and st[0] >= (G.astype(np.float64) ** 2).sum(1).max() * (1 - 1e-6)
+
+
+def test_sharded_gallery_fast_equals_fp32(ops):
+    from isx.retrieval import ShardedGallery
+    g = torch.Generator(device="cuda").manual_seed(4)
+    Q = ops.l2norm_rows(torch.randn(500, 128, device="cuda", generator=g))
+    G = ops.l2norm_rows(torch.randn(30000, 128, device="cuda", generator=g))
+    a = ShardedGallery(G, 1000, fast=False).search(Q, 20)
+    b = ShardedGallery(G, 1000, fast=True).search(Q, 20)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
