@@ -70,6 +70,16 @@ int isx_gap_l2_nhwc(const float* fmap, int64_t B, int C, int H, int W, float eps
 int isx_bias_act_inplace(float* y, const float* bias, const float* residual, int64_t n, int C, int64_t inner, int relu,
                          isx_stream_t stream);
 
+/* 1x1 stride-1 convolution of the inference trunk on channels-last activations, epilogue fused: one
+ * fp32-MFMA GEMM over the M = B*H*W pixels,
+ *   y[m][co] = act(sum_ci x[m][ci] * w[co][ci] + bias[co] + (residual ? residual[m][co] : 0)),
+ * the sum a ci-ordered fp32 fma chain (bit-exact vs the oracle).  Replaces conv1 / conv3 / downsample of the
+ * torchvision Bottleneck (the `features` trunk built by model/ModelDefinition.py and split by
+ * model/nn_utils.py:56-71; run from model/siamese.py:20,107,151) together with their bias / residual / ReLU
+ * passes.  x: (M,Cin), w: (Cout,Cin), y / residual: (M,Cout); y must not alias x or residual. */
+int isx_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float* w, int Cout, const float* bias,
+                     const float* residual, int relu, float* y, isx_stream_t stream);
+
 /* model/siamese.py:67-71 nn.AvgPool2d(feature_size2d, stride=1) of TuneClassifSub /
  * RegionDescriptorNet.  fmap: (B,C,H,W); out: (B,C,H-kh+1,W-kw+1). */
 int isx_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out,

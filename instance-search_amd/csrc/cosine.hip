@@ -88,7 +88,9 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 }
 
 // Block tile (64*TM) x (64*TN): 4 waves as 2x2, each wave TM x TN MFMA tiles of 32x32.
-template <bool ALIGNED, int TM, int TN, bool FILTER, int BK>
+// EPI: 0 = store scores, 1 = top-k filter (thr, gflag, ngrp), 2 = 1x1-convolution epilogue: thr = bias[n],
+// gflag = residual (float, same layout as C) or null, ngrp = relu flag
+template <bool ALIGNED, int TM, int TN, int EPI, int BK>
 __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
                                                           const float* __restrict__ G, int64_t N, int D,
                                                           float* __restrict__ C, int64_t ldc, TileMap tm,
@@ -115,6 +117,24 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // convolution epilogue on 64x64 tiles (short K loops, residual layers): fetch the residual values before
+    // the main loop so that their latency overlaps the operand loads and the MFMAs
+    constexpr bool PRE_RES = (EPI == 2 && TM * TN == 1);
+    float pre_res[PRE_RES ? 16 : 1];
+    // epilogue addressing of the convolution mode: wave-uniform row pointers (SGPRs) + one 32-bit lane offset
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
+    if (PRE_RES) {
+        const float* res = reinterpret_cast<const float*>(gflag);
+        const int ncol = (int)(n0 + wn_u * 32) + l31;
+        const int lane_off = 4 * half * (int)ldc + ncol;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t mu = m0 + wm_u * 32 + (e & 3) + 8 * (e >> 2);        // uniform
+            const float* rp = res + mu * ldc;
+            pre_res[e] = (res && ncol < N && mu + 4 * half < M) ? rp[lane_off] : 0.0f;
+        }
+    }
 
     float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
     const int nk = (D + BK - 1) / BK;
@@ -154,6 +174,30 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    if (EPI == 2) {
+        const float* res = reinterpret_cast<const float*>(gflag);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ncol = (int)(n0 + wn_u * (32 * TN) + j * 32) + l31;
+                const bool n_ok = ncol < N;
+                const float bias_v = n_ok ? thr[ncol] : 0.0f;
+                const int lane_off = 4 * half * (int)ldc + ncol;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t mu = m0 + wm_u * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2);     // uniform
+                    if (n_ok && mu + 4 * half < M) {
+                        float y = acc[i][j][e] + bias_v;
+                        if (PRE_RES) { if (res) y += pre_res[e]; }
+                        else if (res) y += (res + mu * ldc)[lane_off];
+                        (C + mu * ldc)[lane_off] = ngrp ? fmaxf(y, 0.0f) : y;
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -164,7 +208,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
             for (int e = 0; e < 16; ++e) {
                 const int64_t m = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
                 const float v = acc[i][j][e];
-                if (FILTER) {
+                if (EPI == 1) {
                     // fused top-k filter: a 32-column group of row m is stored only if one of its scores
                     // can still enter the row's top-k (score >= thr[m], a lower bound of the final k-th
                     // score); one flag byte per (row, group) tells the select kernel which groups exist.
@@ -197,14 +241,17 @@ void set_gemm_cfg(int c) { g_force_cfg = c; }
 
 template <int TM, int TN, int BK>
 static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                       const float* thr, uint8_t* gmax, hipStream_t st, const int* m_active) {
+                       const float* thr, uint8_t* gmax, hipStream_t st, const int* m_active, int epi, int relu) {
     TileMap tm;
     tm.m_active = m_active;
     tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
     tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
     const int ngrp = (int)((N + 31) / 32);
     const dim3 grid((unsigned)(tm.tiles_m * tm.tiles_n)), block(256);
-    if (gmax) {
+    if (epi == 2) {
+        if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, 2, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, relu);
+        else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, 2, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, relu);
+    } else if (gmax) {
         if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, true, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
         else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, true, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
     } else {
@@ -214,7 +261,8 @@ static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, 
 }
 
 static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
-                           const float* thr, uint8_t* gmax, hipStream_t st, const int* m_active = nullptr) {
+                           const float* thr, uint8_t* gmax, hipStream_t st, const int* m_active = nullptr, int epi = -1, int relu = 0) {
+    if (epi < 0) epi = gmax ? 1 : 0;
     if (M == 0 || N == 0) return ISX_OK;
     if (((M + 63) / 64) * ((N + 63) / 64) >= (1ll << 31)) { isx_set_error("cosine gemm: too many tiles for one grid"); return ISX_ERR_ARG; }
     const bool aligned = (D % 4 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);
@@ -233,12 +281,16 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
         const double t = rounds * k.wg_per_cu * (k.tm * k.tn) / k.eff;
         if (t < best_t) { best_t = t; best = c; }
     }
+    // convolution epilogue with a residual read, or a very short K loop: the launch is bound by the bytes of
+    // the epilogue, which 64x64 tiles (6 resident workgroups per CU) overlap best (measured on the ResNet-50
+    // shapes: 64->256 +res 3.2 vs 4.7 ms, 128->512 1.75 vs 2.7, 256->1024 1.15 vs 1.65, 512->2048 0.97 vs 1.19)
+    if (epi == 2) best = (gmax != nullptr) ? 3 : 2;      // without a residual 128x64 tiles (5 waves/SIMD) win or tie on every trunk shape
     if (g_force_cfg >= 0 && g_force_cfg < 4) best = g_force_cfg;
     switch (best) {
-        case 0: launch_cfg<2, 2, 16>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active); break;
-        case 1: launch_cfg<1, 2, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active); break;
-        case 2: launch_cfg<2, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active); break;
-        default: launch_cfg<1, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active); break;
+        case 0: launch_cfg<2, 2, 16>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
+        case 1: launch_cfg<1, 2, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
+        case 2: launch_cfg<2, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
+        default: launch_cfg<1, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
     }
     ISX_CHECK_LAUNCH("cosine_gemm");
     return ISX_OK;
@@ -354,6 +406,17 @@ int run_topk_chunks(const TopkJob& j) {
 }  // namespace isx
 
 using namespace isx;
+
+// 1x1 stride-1 convolution on NHWC activations: one GEMM over the pixels with the bias / residual / ReLU epilogue fused
+// (the backbone layers of model/ModelDefinition.py's torchvision ResNets inside `features`, model/siamese.py:20,107,151).
+ISX_API int isx_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float* w, int Cout, const float* bias, const float* residual,
+                             int relu, float* y, isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && Cin > 0 && Cout > 0, "isx_conv1x1_nhwc: bad shape M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout);
+    if (M == 0) return ISX_OK;
+    ISX_REQUIRE(x && w && bias && y, "isx_conv1x1_nhwc: null pointer");
+    ISX_REQUIRE(y != x && y != residual, "isx_conv1x1_nhwc: y must not alias x or residual");
+    return launch_gemm_any(x, M, w, Cout, Cin, y, Cout, bias, (uint8_t*)residual, (hipStream_t)stream, nullptr, 2, relu ? 1 : 0);
+}
 
 // Debug / A-B hook (not declared in include/isx.h): force a tile shape (0..3), -1 = automatic.
 ISX_API void isx_debug_set_gemm_cfg(int c) { set_gemm_cfg(c); }

@@ -90,6 +90,28 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
+def conv1x1_nhwc(x, weight, bias, residual=None, relu=True):
+    """1x1 stride-1 convolution of a channels-last (B,Cin,H,W) fp32 tensor with the epilogue fused:
+    act(conv(x, weight) + bias (+ residual)) as ONE fp32-MFMA GEMM over the B*H*W pixels.  weight: (Cout,Cin[,1,1]).
+    Returns a channels-last (B,Cout,H,W) tensor."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.IsxError("x must be a channels-last float32 CUDA tensor (B,C,H,W)")
+    B, Cin, H, W = x.shape
+    w = _f32(weight.reshape(weight.shape[0], -1), "weight")
+    Cout = w.shape[0]
+    if w.shape[1] != Cin:
+        raise _lib.IsxError("weight must be (Cout, Cin)")
+    y = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    rp = 0
+    if residual is not None:
+        if residual.shape != y.shape or residual.dtype != torch.float32 or not residual.is_contiguous(memory_format=torch.channels_last):
+            raise _lib.IsxError("residual must be a channels-last float32 tensor of the output's shape")
+        rp = residual.data_ptr()
+    check(lib().isx_conv1x1_nhwc(x.data_ptr(), B * H * W, Cin, w.data_ptr(), Cout, _f32(bias, "bias").data_ptr(), rp,
+                                 1 if relu else 0, y.data_ptr(), _stream()), "isx_conv1x1_nhwc")
+    return y
+
+
 def boxpool_s1(fmap, kh, kw):
     fmap = _f32(fmap, "fmap")
     B, Cc, H, W = fmap.shape

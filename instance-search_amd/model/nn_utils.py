@@ -83,9 +83,23 @@ class _ConvBiasAct(nn.Module):
         self.conv.weight = nn.Parameter(conv.weight.detach().clone(), requires_grad=False)
         self.bias = nn.Parameter(bias, requires_grad=False)
         self.relu = relu
+        self.plain = False            # True: no epilogue of its own (projection shortcut, bias merged elsewhere)
+
+    def _pointwise(self):
+        c = self.conv
+        return c.kernel_size == (1, 1) and c.padding == (0, 0) and c.groups == 1 and c.dilation == (1, 1) and c.stride == (1, 1)
 
     def forward(self, x, residual=None):
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self._pointwise()
+                and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
+            # 1x1 convolution on channels-last activations: one fp32-MFMA GEMM over the pixels, epilogue fused
+            from isx import ops
+            if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+                residual = residual.contiguous(memory_format=torch.channels_last)
+            return ops.conv1x1_nhwc(x, self.conv.weight, self.bias, residual, self.relu)
         y = self.conv(x)
+        if self.plain:
+            return y
         if y.is_cuda and y.dtype == torch.float32 and not torch.is_grad_enabled():
             from isx import ops
             if residual is not None and residual.stride() != y.stride():
@@ -108,8 +122,10 @@ class _FusedBlock(nn.Module):
         self.downsample = None
         if downsample is not None:
             d = _ConvBiasAct(downsample, relu=False)
-            self.downsample = d.conv                                        # bias-free projection
-            self.convs[-1].bias = nn.Parameter(self.convs[-1].bias + d.bias, requires_grad=False)
+            d.bias = nn.Parameter(torch.zeros_like(d.bias), requires_grad=False)
+            d.plain = True
+            self.convs[-1].bias = nn.Parameter(self.convs[-1].bias + _ConvBiasAct(downsample, relu=False).bias, requires_grad=False)
+            self.downsample = d                                             # projection (its bias lives in the last conv's epilogue)
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)

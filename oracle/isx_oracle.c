@@ -205,6 +205,19 @@ ISXO_API void isxo_cosine_sim(const float* Q, int64_t M, const float* G, int64_t
         for (int64_t j = 0; j < N; ++j) sim[i * N + j] = dot_fma(Q + i * D, G + j * D, D);
 }
 
+/* 1x1 stride-1 convolution over NHWC pixels with the folded-BN epilogue of the inference trunk
+ * (torchvision Bottleneck conv1 / conv3 / downsample as used through model/nn_utils.py:56-71 extract_layers):
+ * y[m][co] = act(sum_ci x[m][ci] * w[co][ci] (fma chain, ci ascending) + bias[co] (+ res[m][co])). */
+ISXO_API void isxo_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float* w, int Cout, const float* bias,
+                                const float* res, int relu, float* y) {
+    for (int64_t m = 0; m < M; ++m)
+        for (int co = 0; co < Cout; ++co) {
+            float v = dot_fma(x + m * Cin, w + (int64_t)co * Cin, Cin) + bias[co];
+            if (res) v += res[m * Cout + co];
+            y[m * Cout + co] = relu ? fmaxf(v, 0.0f) : v;
+        }
+}
+
 /* Fused form of  torch.mm -> (sort | topk): per query the k best gallery rows in
  * canonical order, global index = idx_base + local row.  Entries beyond N are
  * (-inf, -1). */

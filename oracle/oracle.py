@@ -105,6 +105,16 @@ def cosine_sim(Q, G):
     return sim
 
 
+def conv1x1_nhwc(x, w, bias, res=None, relu=True):
+    """x: (M, Cin) pixels, w: (Cout, Cin), res: (M, Cout) or None -> (M, Cout)."""
+    x = _f32(x); w = _f32(w); bias = _f32(bias); M, Cin = x.shape; Cout = w.shape[0]
+    y = np.empty((M, Cout), np.float32)
+    r = _f32(res) if res is not None else None
+    lib().isxo_conv1x1_nhwc(_p(x, F32P), C.c_int64(M), Cin, _p(w, F32P), Cout, _p(bias, F32P),
+                            _p(r, F32P) if r is not None else None, 1 if relu else 0, _p(y, F32P))
+    return y
+
+
 def cosine_topk(Q, G, k, idx_base=0):
     Q = _f32(Q); G = _f32(G); M, D = Q.shape; N = G.shape[0]
     ts = np.empty((M, k), np.float32); ti = np.empty((M, k), np.int64)

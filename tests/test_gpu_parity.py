@@ -388,3 +388,29 @@ def test_full_size_properties(ops):
     s1, i1 = ops.cosine_topk(G[:2000], G, 1)
     assert torch.equal(i1[:, 0], torch.arange(2000, device="cuda"))
     assert bool(((s1[:, 0] - 1).abs() < 1e-5).all())
+
+
+# ------------------------------------------------------------------ 1x1 convolution of the trunk (fused epilogue)
+@pytest.mark.parametrize("M,Cin,Cout", [(1, 4, 4), (50, 64, 256), (300, 256, 64), (777, 512, 128), (130, 2048, 512), (64, 100, 36), (257, 24, 130)])
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (True, False)])
+def test_conv1x1_nhwc(ops, M, Cin, Cout, res, relu):
+    from isx._lib import lib
+    rng = np.random.default_rng(M + Cin)
+    x = np.maximum(rng.standard_normal((M, Cin), dtype=np.float32), 0)
+    w = rng.standard_normal((Cout, Cin), dtype=np.float32) * np.float32(Cin ** -0.5)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    r = rng.standard_normal((M, Cout), dtype=np.float32) if res else None
+    want = O.conv1x1_nhwc(x, w, b, r, relu)
+    # as a (1, Cin, M, 1) channels-last image
+    xt = dev(x).view(1, M, 1, Cin).permute(0, 3, 1, 2)
+    rt = dev(r).view(1, M, 1, Cout).permute(0, 3, 1, 2) if res else None
+    y = ops.conv1x1_nhwc(xt, dev(w), dev(b), rt, relu)
+    got = host(y.permute(0, 2, 3, 1).reshape(M, Cout))
+    np.testing.assert_array_equal(got, want)                      # MFMA fp32 == fma chain: bit-exact
+    # and against torch's convolution (different summation order): fp32 tolerance
+    ref = torch.nn.functional.conv2d(xt, dev(w).view(Cout, Cin, 1, 1), dev(b))
+    if res:
+        ref = ref + rt
+    if relu:
+        ref = torch.relu(ref)
+    np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1).reshape(M, Cout)), rtol=1e-4, atol=1e-4)
