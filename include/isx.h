@@ -80,6 +80,14 @@ int isx_bias_act_inplace(float* y, const float* bias, const float* residual, int
 int isx_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float* w, int Cout, const float* bias,
                      const float* residual, int relu, float* y, isx_stream_t stream);
 
+/* 3x3 convolution (padding 1, stride 1 or 2) of the same trunk, channels-last, as an implicit GEMM on the fp32
+ * matrix cores: M = B*Ho*Wo output pixels, K = 9*Cin in (kh, kw, ci) order (one fp32 fma chain per output, bit-exact
+ * vs the oracle), epilogue act(. + bias[co] + residual) fused.  Replaces conv2 of the torchvision Bottleneck and the
+ * convolutions of BasicBlock (same call sites as isx_conv1x1_nhwc).  x: (B,H,W,Cin); w_ohwi: (Cout,3,3,Cin);
+ * y / residual: (B,Ho,Wo,Cout), Ho = (H-1)/stride + 1.  Cin % 32 == 0. */
+int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, const float* w_ohwi, int Cout, int stride,
+                     const float* bias, const float* residual, int relu, float* y, isx_stream_t stream);
+
 /* model/siamese.py:67-71 nn.AvgPool2d(feature_size2d, stride=1) of TuneClassifSub /
  * RegionDescriptorNet.  fmap: (B,C,H,W); out: (B,C,H-kh+1,W-kw+1). */
 int isx_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out,

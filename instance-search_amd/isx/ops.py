@@ -112,6 +112,28 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True):
     return y
 
 
+def conv3x3_nhwc(x, w_ohwi, bias, stride=1, residual=None, relu=True):
+    """3x3 convolution (padding 1, stride 1|2) of a channels-last (B,Cin,H,W) fp32 tensor, epilogue fused.
+    w_ohwi: (Cout,3,3,Cin) contiguous (= conv.weight.permute(0,2,3,1)).  Returns channels-last (B,Cout,Ho,Wo)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.IsxError("x must be a channels-last float32 CUDA tensor (B,C,H,W)")
+    B, Cin, H, W = x.shape
+    w = _f32(w_ohwi, "w_ohwi")
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, 3, 3, Cin):
+        raise _lib.IsxError("w_ohwi must be (Cout, 3, 3, Cin)")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    rp = 0
+    if residual is not None:
+        if residual.shape != y.shape or residual.dtype != torch.float32 or not residual.is_contiguous(memory_format=torch.channels_last):
+            raise _lib.IsxError("residual must be a channels-last float32 tensor of the output's shape")
+        rp = residual.data_ptr()
+    check(lib().isx_conv3x3_nhwc(x.data_ptr(), B, H, W, Cin, w.data_ptr(), Cout, stride, _f32(bias, "bias").data_ptr(), rp,
+                                 1 if relu else 0, y.data_ptr(), _stream()), "isx_conv3x3_nhwc")
+    return y
+
+
 def boxpool_s1(fmap, kh, kw):
     fmap = _f32(fmap, "fmap")
     B, Cc, H, W = fmap.shape

@@ -3,6 +3,8 @@ model/nn_utils.py (extract_layers :56-71, convolutionalize :26-39, get_feature_s
 set_untrained_blocks :6-23, set_net_train :160-163), written against isx.backbones instead
 of torchvision.  The BN copy/replace helpers (:74-134) are training-time surgery and are
 out of scope."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -71,6 +73,15 @@ def extract_layers(net):
     return net.features, nn.Sequential(), net.classifier
 
 
+# A/B switches (environment).  ISX_CONV1X1=0 sends the 1x1 trunk convolutions back to MIOpen.  ISX_CONV3X3: "auto"
+# (default) runs the implicit-GEMM kernel where it wins on MI355X -- Cin <= 128, the wide-image layers whose separate
+# epilogue pass costs as much as a fifth of the convolution (measured at B = 1024: 64->64 @56 2.08 vs 2.55 ms,
+# 128->128 @56/2 2.01 vs 2.23; from Cin = 256 on MIOpen's igemm + epilogue is 3-5 % faster) -- "1" everywhere, "0" never.
+_CONV3X3_MODE = os.environ.get("ISX_CONV3X3", "auto")
+_IMPLICIT_GEMM_3X3 = _CONV3X3_MODE != "0"
+_GEMM_1X1 = os.environ.get("ISX_CONV1X1", "1") != "0"
+
+
 class _ConvBiasAct(nn.Module):
     """Bias-free convolution + fused `y = act(y + bias (+ residual))` epilogue (libisx `isx_bias_act_inplace` on
     the GPU, plain torch otherwise)."""
@@ -84,12 +95,28 @@ class _ConvBiasAct(nn.Module):
         self.bias = nn.Parameter(bias, requires_grad=False)
         self.relu = relu
         self.plain = False            # True: no epilogue of its own (projection shortcut, bias merged elsewhere)
+        self._w_ohwi = None           # (Cout,3,3,Cin) copy of a 3x3 weight for the implicit-GEMM kernel, built on first use
 
     def _pointwise(self):
         c = self.conv
-        return c.kernel_size == (1, 1) and c.padding == (0, 0) and c.groups == 1 and c.dilation == (1, 1) and c.stride == (1, 1)
+        return _GEMM_1X1 and c.kernel_size == (1, 1) and c.padding == (0, 0) and c.groups == 1 and c.dilation == (1, 1) and c.stride == (1, 1)
+
+    def _three_by_three(self):
+        c = self.conv
+        return (_IMPLICIT_GEMM_3X3 and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.groups == 1 and c.dilation == (1, 1)
+                and c.stride in ((1, 1), (2, 2)) and c.in_channels % 32 == 0
+                and (_CONV3X3_MODE == "1" or c.in_channels <= 128))
 
     def forward(self, x, residual=None):
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self._three_by_three()
+                and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
+            # 3x3 convolution on channels-last activations: implicit GEMM on the fp32 matrix cores, epilogue fused
+            from isx import ops
+            if self._w_ohwi is None or self._w_ohwi.device != x.device:
+                self._w_ohwi = self.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+            if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
+                residual = residual.contiguous(memory_format=torch.channels_last)
+            return ops.conv3x3_nhwc(x, self._w_ohwi, self.bias, self.conv.stride[0], residual, self.relu)
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self._pointwise()
                 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
             # 1x1 convolution on channels-last activations: one fp32-MFMA GEMM over the pixels, epilogue fused

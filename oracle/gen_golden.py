@@ -369,5 +369,57 @@ def main():
         print("  %-28s %8d B" % (f_, os.path.getsize(os.path.join(OUT, f_))))
 
 
+def trunk_block():
+    """One ResNet bottleneck block (the unit of the `features` trunk the reference takes from torchvision,
+    model/nn_utils.py:56-71) evaluated by torch itself in eval mode: conv1x1-BN-ReLU, conv3x3(stride 2)-BN-ReLU,
+    conv1x1-BN, + conv1x1(stride 2)-BN shortcut, ReLU; and a stride-1 identity-shortcut block on its output.
+    torch.nn.functional.conv2d / batch_norm are the third-party algorithms (PyTorch, this image: 2.10) the
+    oracle's isxo_conv1x1_nhwc / isxo_conv3x3_nhwc + BN folding restate."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.manual_seed(20260302)
+
+    def bn(c):
+        m = nn.BatchNorm2d(c).eval()
+        m.weight.data = torch.rand(c) + 0.5
+        m.bias.data = torch.randn(c) * 0.1
+        m.running_mean.data = torch.randn(c) * 0.1
+        m.running_var.data = torch.rand(c) + 0.5
+        return m
+
+    out = {}
+    x = torch.relu(torch.randn(2, 64, 9, 8))
+    out["x"] = x
+    y = x
+    for blk, (cin, mid, cout, stride) in enumerate(((64, 32, 128, 2), (128, 32, 128, 1))):
+        convs = [nn.Conv2d(cin, mid, 1, bias=False), nn.Conv2d(mid, mid, 3, stride, 1, bias=False), nn.Conv2d(mid, cout, 1, bias=False)]
+        bns = [bn(mid), bn(mid), bn(cout)]
+        with torch.no_grad():
+            idt = y
+            if stride != 1 or cin != cout:
+                dconv, dbn = nn.Conv2d(cin, cout, 1, stride, bias=False), bn(cout)
+                idt = dbn(dconv(y))
+                out["b%d_dw" % blk] = dconv.weight
+                for k_, v_ in (("g", dbn.weight), ("b", dbn.bias), ("m", dbn.running_mean), ("v", dbn.running_var)):
+                    out["b%d_d%s" % (blk, k_)] = v_
+            t = y
+            for i, (c, b_) in enumerate(zip(convs, bns)):
+                t = b_(c(t))
+                if i < 2:
+                    t = torch.relu(t)
+                out["b%d_w%d" % (blk, i)] = c.weight
+                for k_, v_ in (("g", b_.weight), ("b", b_.bias), ("m", b_.running_mean), ("v", b_.running_var)):
+                    out["b%d_%s%d" % (blk, k_, i)] = v_
+            y = torch.relu(t + idt)
+        out["y%d" % blk] = y
+    out["eps"] = np.float32(1e-5)
+    npz("trunk_block.npz", **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "trunk":
+        os.makedirs(OUT, exist_ok=True)
+        trunk_block()
+    else:
+        main()
+        trunk_block()

@@ -218,6 +218,33 @@ ISXO_API void isxo_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float*
         }
 }
 
+/* 3x3 convolution, padding 1, stride 1|2, NHWC, weights (Cout,3,3,Cin), folded-BN epilogue (conv2 of the torchvision
+ * Bottleneck / BasicBlock convolutions inside `features`): fma chain over (kh, kw, ci) in that order; padding taps
+ * contribute fma(0, w, acc). */
+ISXO_API void isxo_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, const float* w, int Cout, int stride,
+                                const float* bias, const float* res, int relu, float* y) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    for (int64_t b = 0; b < B; ++b)
+        for (int ho = 0; ho < Ho; ++ho)
+            for (int wo = 0; wo < Wo; ++wo) {
+                const int64_t m = (b * Ho + ho) * Wo + wo;
+                for (int co = 0; co < Cout; ++co) {
+                    float acc = 0.0f;
+                    for (int kh = 0; kh < 3; ++kh)
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int hi = ho * stride - 1 + kh, wi = wo * stride - 1 + kw;
+                            const int ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+                            const float* xp = x + ((b * H + (ok ? hi : 0)) * W + (ok ? wi : 0)) * (int64_t)Cin;
+                            const float* wp = w + (((int64_t)co * 3 + kh) * 3 + kw) * Cin;
+                            for (int ci = 0; ci < Cin; ++ci) acc = fmaf(ok ? xp[ci] : 0.0f, wp[ci], acc);
+                        }
+                    float v = acc + bias[co];
+                    if (res) v += res[m * Cout + co];
+                    y[m * Cout + co] = relu ? fmaxf(v, 0.0f) : v;
+                }
+            }
+}
+
 /* Fused form of  torch.mm -> (sort | topk): per query the k best gallery rows in
  * canonical order, global index = idx_base + local row.  Entries beyond N are
  * (-inf, -1). */

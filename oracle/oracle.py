@@ -115,6 +115,17 @@ def conv1x1_nhwc(x, w, bias, res=None, relu=True):
     return y
 
 
+def conv3x3_nhwc(x, w_ohwi, bias, stride=1, res=None, relu=True):
+    """x: (B,H,W,Cin), w_ohwi: (Cout,3,3,Cin), res: (B,Ho,Wo,Cout) or None -> (B,Ho,Wo,Cout); padding 1."""
+    x = _f32(x); w = _f32(w_ohwi); bias = _f32(bias); B, H, W, Cin = x.shape; Cout = w.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = np.empty((B, Ho, Wo, Cout), np.float32)
+    r = _f32(res) if res is not None else None
+    lib().isxo_conv3x3_nhwc(_p(x, F32P), C.c_int64(B), H, W, Cin, _p(w, F32P), Cout, stride, _p(bias, F32P),
+                            _p(r, F32P) if r is not None else None, 1 if relu else 0, _p(y, F32P))
+    return y
+
+
 def cosine_topk(Q, G, k, idx_base=0):
     Q = _f32(Q); G = _f32(G); M, D = Q.shape; N = G.shape[0]
     ts = np.empty((M, k), np.float32); ti = np.empty((M, k), np.int64)

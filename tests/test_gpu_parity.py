@@ -414,3 +414,34 @@ def test_conv1x1_nhwc(ops, M, Cin, Cout, res, relu):
     if relu:
         ref = torch.relu(ref)
     np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1).reshape(M, Cout)), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(1, 4, 4, 32, 32, 1), (2, 7, 7, 64, 64, 1), (3, 8, 6, 64, 128, 2), (2, 14, 14, 128, 96, 1),
+                                                   (1, 9, 11, 256, 130, 2), (5, 5, 5, 32, 64, 1), (2, 1, 1, 32, 32, 1), (1, 3, 2, 512, 512, 2)])
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
+def test_conv3x3_nhwc(ops, B, H, W, Cin, Cout, stride, res, relu):
+    from isx._lib import lib
+    rng = np.random.default_rng(H * 100 + Cin + stride)
+    x = np.maximum(rng.standard_normal((B, H, W, Cin), dtype=np.float32), 0)
+    w = rng.standard_normal((Cout, 3, 3, Cin), dtype=np.float32) * np.float32((9 * Cin) ** -0.5)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = rng.standard_normal((B, Ho, Wo, Cout), dtype=np.float32) if res else None
+    want = O.conv3x3_nhwc(x, w, b, stride, r, relu)
+    xt = dev(x).permute(0, 3, 1, 2)                        # channels-last view of (B,Cin,H,W)
+    rt = dev(r).permute(0, 3, 1, 2) if res else None
+    set_cfg = lib().isx_debug_set_conv_cfg
+    try:
+        for cfg in (-1, 0, 2, 3):                          # every instantiated tile shape: same bits
+            set_cfg(cfg)
+            y = ops.conv3x3_nhwc(xt, dev(w), dev(b), stride, rt, relu)
+            got = host(y.permute(0, 2, 3, 1))
+            np.testing.assert_array_equal(got, want)
+    finally:
+        set_cfg(-1)
+    ref = torch.nn.functional.conv2d(xt, dev(w).permute(0, 3, 1, 2), dev(b), stride=stride, padding=1)
+    if res:
+        ref = ref + rt
+    if relu:
+        ref = torch.relu(ref)
+    np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1)), rtol=1e-4, atol=1e-4)

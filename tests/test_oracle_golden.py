@@ -158,3 +158,35 @@ def test_masked_sums():
     mask = ql[:, None] == gl[None, :]
     assert abs(sp - sim[mask].astype(np.float64).sum()) < 1e-12
     assert abs(sa - sim.astype(np.float64).sum()) < 1e-12
+
+
+def _fold(w, g, b, m, v, eps):
+    """BatchNorm (eval) folded into the preceding bias-free convolution, fp32 like torch's fuse_conv_bn_eval."""
+    s = (g / np.sqrt(v + eps)).astype(np.float32)
+    return (w * s.reshape(-1, 1, 1, 1)).astype(np.float32), (b - m * s).astype(np.float32)
+
+
+def test_trunk_block(golden):
+    """isxo_conv1x1_nhwc / isxo_conv3x3_nhwc + BN folding == torch's conv2d / batch_norm on two bottleneck blocks
+    (projection shortcut with stride 2, then identity shortcut)."""
+    g = golden("trunk_block.npz")
+    eps = float(g["eps"])
+    y = np.ascontiguousarray(g["x"].transpose(0, 2, 3, 1))                   # NHWC
+    for blk, stride in ((0, 2), (1, 1)):
+        f = [_fold(g["b%d_w%d" % (blk, i)], g["b%d_g%d" % (blk, i)], g["b%d_b%d" % (blk, i)], g["b%d_m%d" % (blk, i)], g["b%d_v%d" % (blk, i)], eps)
+             for i in range(3)]
+        B, H, W, C = y.shape
+        idt = y
+        bias3 = f[2][1]
+        if "b%d_dw" % blk in g:
+            dw, db = _fold(g["b%d_dw" % blk], g["b%d_dg" % blk], g["b%d_db" % blk], g["b%d_dm" % blk], g["b%d_dv" % blk], eps)
+            xs = np.ascontiguousarray(y[:, ::stride, ::stride])
+            idt = O.conv1x1_nhwc(xs.reshape(-1, C), dw.reshape(dw.shape[0], -1), np.zeros(dw.shape[0], np.float32), None, False)
+            idt = idt.reshape(xs.shape[0], xs.shape[1], xs.shape[2], -1)
+            bias3 = bias3 + db                                                # shortcut bias merged into the last epilogue
+        t = O.conv1x1_nhwc(y.reshape(-1, C), f[0][0].reshape(f[0][0].shape[0], -1), f[0][1], None, True).reshape(B, H, W, -1)
+        t = O.conv3x3_nhwc(t, np.ascontiguousarray(f[1][0].transpose(0, 2, 3, 1)), f[1][1], stride, None, True)
+        Bo, Ho, Wo, Cm = t.shape
+        y = O.conv1x1_nhwc(t.reshape(-1, Cm), f[2][0].reshape(f[2][0].shape[0], -1), bias3, idt.reshape(-1, idt.shape[-1]), True)
+        y = y.reshape(Bo, Ho, Wo, -1)
+        np.testing.assert_allclose(y.transpose(0, 3, 1, 2), g["y%d" % blk], rtol=2e-5, atol=2e-5)
