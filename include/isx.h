@@ -70,6 +70,12 @@ int isx_gap_l2_nhwc(const float* fmap, int64_t B, int C, int H, int W, float eps
 int isx_bias_act_inplace(float* y, const float* bias, const float* residual, int64_t n, int C, int64_t inner, int relu,
                          isx_stream_t stream);
 
+/* Stem of the same trunk: relu(conv7x7 + bias) -> MaxPool2d(3, stride 2, padding 1) (torchvision ResNet stem as split
+ * by model/nn_utils.py:56-71), epilogue and pooling in ONE pass over the channels-last convolution output:
+ * out[b][ho][wo][c] = relu(max_{3x3 window, in bounds} y[b][2ho-1+kh][2wo-1+kw][c] + bias[c]).
+ * y: (B,H,W,C), out: (B,Ho,Wo,C), Ho = (H-1)/2 + 1; C % 4 == 0. */
+int isx_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int H, int W, int C, float* out, isx_stream_t stream);
+
 /* 1x1 stride-1 convolution of the inference trunk on channels-last activations, epilogue fused: one
  * fp32-MFMA GEMM over the M = B*H*W pixels,
  *   y[m][co] = act(sum_ci x[m][ci] * w[co][ci] + bias[co] + (residual ? residual[m][co] : 0)),

@@ -408,7 +408,52 @@ __global__ __launch_bounds__(256) void bias_act_scalar_kernel(float* __restrict_
     }
 }
 
+// Stem epilogue: relu(conv + bias) followed by MaxPool2d(3, stride 2, padding 1), channels-last, one pass.
+// relu(. + b) is monotonic, so the window maximum is taken first: out = relu(max_window(y) + bias[c]).
+// One thread per (output pixel, 4 channels): nine 16-B loads, consecutive threads on consecutive channels.
+__global__ __launch_bounds__(256) void bias_relu_maxpool_nhwc_kernel(const float* __restrict__ y, const float* __restrict__ bias, int64_t n4,
+                                                                     int C4, int H, int W, int Ho, int Wo, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int wo = (int)(p % Wo);
+        p /= Wo;
+        const int ho = (int)(p % Ho);
+        const int64_t b = p / Ho;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = ho * 2 - 1 + kh;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = wo * 2 - 1 + kw;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 v = reinterpret_cast<const float4*>(y)[((b * H + hi) * W + wi) * C4 + c4];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        const float4 bb = reinterpret_cast<const float4*>(bias)[c4];
+        m.x = fmaxf(m.x + bb.x, 0.f); m.y = fmaxf(m.y + bb.y, 0.f); m.z = fmaxf(m.z + bb.z, 0.f); m.w = fmaxf(m.w + bb.w, 0.f);
+        reinterpret_cast<float4*>(out)[i] = m;
+    }
+}
+
 }  // namespace isx
+
+ISX_API int isx_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int H, int W, int C, float* out, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "isx_bias_relu_maxpool_nhwc: bad shape B=%lld H=%d W=%d C=%d (C %% 4 == 0)", (long long)B, H, W, C);
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(y && bias && out && y != out, "isx_bias_relu_maxpool_nhwc: null or aliased pointer");
+    ISX_REQUIRE((((uintptr_t)y | (uintptr_t)bias | (uintptr_t)out) % 16) == 0, "isx_bias_relu_maxpool_nhwc: 16-B alignment required");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int64_t n4 = B * Ho * Wo * (C / 4);
+    const int64_t blocks = (n4 + 255) / 256;
+    hipLaunchKernelGGL(isx::bias_relu_maxpool_nhwc_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, y, bias,
+                       n4, C / 4, H, W, Ho, Wo, out);
+    ISX_CHECK_LAUNCH("isx_bias_relu_maxpool_nhwc");
+    return ISX_OK;
+}
 
 ISX_API int isx_bias_act_inplace(float* y, const float* bias, const float* residual, int64_t n, int C, int64_t inner, int relu,
                                  isx_stream_t stream) {

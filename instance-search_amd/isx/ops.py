@@ -90,6 +90,17 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
+def bias_relu_maxpool(y, bias):
+    """relu(y + bias[c]) -> MaxPool2d(3, 2, 1) of a channels-last (B,C,H,W) fp32 tensor in one pass."""
+    if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.IsxError("y must be a channels-last float32 CUDA tensor (B,C,H,W)")
+    B, Cc, H, W = y.shape
+    out = torch.empty((B, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=y.device, dtype=torch.float32, memory_format=torch.channels_last)
+    check(lib().isx_bias_relu_maxpool_nhwc(y.data_ptr(), _f32(bias, "bias").data_ptr(), B, H, W, Cc, out.data_ptr(), _stream()),
+          "isx_bias_relu_maxpool_nhwc")
+    return out
+
+
 def conv1x1_nhwc(x, weight, bias, residual=None, relu=True):
     """1x1 stride-1 convolution of a channels-last (B,Cin,H,W) fp32 tensor with the epilogue fused:
     act(conv(x, weight) + bias (+ residual)) as ONE fp32-MFMA GEMM over the B*H*W pixels.  weight: (Cout,Cin[,1,1]).

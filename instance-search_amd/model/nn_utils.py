@@ -138,6 +138,36 @@ class _ConvBiasAct(nn.Module):
         return torch.relu(y) if self.relu else y
 
 
+class _StemConvPool(nn.Module):
+    """conv + folded BN + ReLU + MaxPool2d(3, 2, 1) of the ResNet stem: the bias / ReLU epilogue and the pooling run
+    as ONE pass over the convolution output (libisx `isx_bias_relu_maxpool_nhwc`) on channels-last GPU tensors."""
+
+    def __init__(self, conv, pool):
+        super().__init__()
+        self.cba = _ConvBiasAct(conv, relu=True)
+        self.pool = pool
+
+    def forward(self, x):
+        c = self.cba
+        if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and c.conv.out_channels % 4 == 0):
+            y = c.conv(x)
+            if y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous():
+                from isx import ops
+                return ops.bias_relu_maxpool(y, c.bias)
+            return self.pool(ops_bias_act(y, c.bias, c.relu))
+        return self.pool(c(x))
+
+
+def ops_bias_act(y, bias, relu):
+    from isx import ops
+    return ops.bias_act_(y, bias, None, relu)
+
+
+def _is_stem_pool(m):
+    return (isinstance(m, nn.MaxPool2d) and m.kernel_size in (3, (3, 3)) and m.stride in (2, (2, 2)) and m.padding in (1, (1, 1))
+            and m.dilation in (1, (1, 1)) and not m.ceil_mode)
+
+
 class _FusedBlock(nn.Module):
     """Inference form of a (BN-folded) BasicBlock / Bottleneck: relu(convN(...) + bias + identity) with every
     bias / residual / ReLU fused into one in-place pass per convolution.  The projection shortcut keeps no
@@ -195,7 +225,10 @@ def fold_batch_norm(features, fuse_epilogues=True):
         if isinstance(m, nn.Conv2d) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
             conv = fuse_conv_bn_eval(copy.deepcopy(m).eval(), copy.deepcopy(mods[i + 1]).eval())
             i += 2
-            if fuse_epilogues and i < len(mods) and isinstance(mods[i], nn.ReLU):
+            if fuse_epilogues and i + 1 < len(mods) and isinstance(mods[i], nn.ReLU) and _is_stem_pool(mods[i + 1]):
+                out.append(_StemConvPool(conv, copy.deepcopy(mods[i + 1])))     # stem: epilogue + pooling in one pass
+                i += 2
+            elif fuse_epilogues and i < len(mods) and isinstance(mods[i], nn.ReLU):
                 out.append(_ConvBiasAct(conv, relu=True))      # conv + BN + ReLU -> conv, one fused epilogue
                 i += 1
             else:

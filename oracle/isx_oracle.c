@@ -205,6 +205,25 @@ ISXO_API void isxo_cosine_sim(const float* Q, int64_t M, const float* G, int64_t
         for (int64_t j = 0; j < N; ++j) sim[i * N + j] = dot_fma(Q + i * D, G + j * D, D);
 }
 
+/* relu(y + bias) -> MaxPool2d(3, stride 2, padding 1) on an NHWC map (torchvision ResNet stem after the folded BN). */
+ISXO_API void isxo_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int H, int W, int C, float* out) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    for (int64_t b = 0; b < B; ++b)
+        for (int ho = 0; ho < Ho; ++ho)
+            for (int wo = 0; wo < Wo; ++wo)
+                for (int c = 0; c < C; ++c) {
+                    float m = -INFINITY;
+                    for (int kh = 0; kh < 3; ++kh)
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int hi = ho * 2 - 1 + kh, wi = wo * 2 - 1 + kw;
+                            if (hi < 0 || hi >= H || wi < 0 || wi >= W) continue;
+                            const float v = fmaxf(y[((b * H + hi) * W + wi) * (int64_t)C + c] + bias[c], 0.0f);   /* relu first, as the reference does */
+                            m = fmaxf(m, v);
+                        }
+                    out[((b * Ho + ho) * Wo + wo) * (int64_t)C + c] = m;
+                }
+}
+
 /* 1x1 stride-1 convolution over NHWC pixels with the folded-BN epilogue of the inference trunk
  * (torchvision Bottleneck conv1 / conv3 / downsample as used through model/nn_utils.py:56-71 extract_layers):
  * y[m][co] = act(sum_ci x[m][ci] * w[co][ci] (fma chain, ci ascending) + bias[co] (+ res[m][co])). */

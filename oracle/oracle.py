@@ -105,6 +105,13 @@ def cosine_sim(Q, G):
     return sim
 
 
+def bias_relu_maxpool_nhwc(y, bias):
+    y = _f32(y); bias = _f32(bias); B, H, W, Cc = y.shape
+    out = np.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), np.float32)
+    lib().isxo_bias_relu_maxpool_nhwc(_p(y, F32P), _p(bias, F32P), C.c_int64(B), H, W, Cc, _p(out, F32P))
+    return out
+
+
 def conv1x1_nhwc(x, w, bias, res=None, relu=True):
     """x: (M, Cin) pixels, w: (Cout, Cin), res: (M, Cout) or None -> (M, Cout)."""
     x = _f32(x); w = _f32(w); bias = _f32(bias); M, Cin = x.shape; Cout = w.shape[0]

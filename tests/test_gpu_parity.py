@@ -445,3 +445,14 @@ def test_conv3x3_nhwc(ops, B, H, W, Cin, Cout, stride, res, relu):
     if relu:
         ref = torch.relu(ref)
     np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1)), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(1, 1, 1, 4), (2, 7, 9, 8), (3, 112, 112, 64), (2, 12, 13, 36), (1, 2, 2, 4)])
+def test_bias_relu_maxpool(ops, B, H, W, C):
+    rng = np.random.default_rng(H + C)
+    y = rng.standard_normal((B, H, W, C), dtype=np.float32)
+    b = rng.standard_normal(C, dtype=np.float32)
+    got = host(ops.bias_relu_maxpool(dev(y).permute(0, 3, 1, 2), dev(b)).permute(0, 2, 3, 1))
+    np.testing.assert_array_equal(got, O.bias_relu_maxpool_nhwc(y, b))
+    ref = torch.nn.functional.max_pool2d(torch.relu(dev(y).permute(0, 3, 1, 2) + dev(b).view(1, -1, 1, 1)), 3, 2, 1)
+    np.testing.assert_array_equal(got, host(ref.permute(0, 2, 3, 1)))
