@@ -58,7 +58,11 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1) mx = nanmax(mx, __shfl_xor(mx, s, 64));
     if (!(mx >= 0.0f)) mx = INFINITY;                     // NaN -> unusable
-    if ((threadIdx.x & 63) == 0) atomicMax(&stats[1], __float_as_uint(mx));
+    // one atomic per workgroup (16 k same-address atomics from one per wave cost 0.2 ms on their own)
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(&stats[1], __float_as_uint(nanmax(nanmax(wmax[0], wmax[1]), nanmax(wmax[2], wmax[3]))));
 }
 
 __device__ __forceinline__ bool f16_usable(float amax) { return amax >= 9.5367431640625e-7f && amax <= 32768.0f; }   // [2^-20, 2^15]
@@ -69,10 +73,15 @@ __device__ __forceinline__ float f16_scale(float amax) {
 // stats (optional): scale from stats[1] (must be final: amax_kernel ran before), max norm2 into stats[0].
 __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restrict__ x, int64_t B, int D, _Float16* __restrict__ h,
                                                           float* __restrict__ norm2, float* __restrict__ amax,
-                                                          unsigned* __restrict__ stats) {
+                                                          unsigned* __restrict__ stats, int want_norm_max) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B) return;
+    __shared__ float wn2[4];
+    if (lane == 0) wn2[threadIdx.x >> 6] = 0.0f;
+    if (row >= B) {
+        if (want_norm_max) __syncthreads();
+        return;
+    }
     const float scale = stats ? f16_scale(__uint_as_float(stats[1])) : 1.0f;
     const float* r = x + row * D;
     _Float16* o = h + row * D;
@@ -108,7 +117,11 @@ __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restric
     if (lane == 0) {
         if (norm2) norm2[row] = ss;
         if (amax) amax[row] = mx;
-        if (stats) atomicMax(&stats[0], __float_as_uint(ss));
+        wn2[threadIdx.x >> 6] = ss;
+    }
+    if (want_norm_max) {                                   // uniform per launch; one atomic per workgroup
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&stats[0], __float_as_uint(fmaxf(fmaxf(wn2[0], wn2[1]), fmaxf(wn2[2], wn2[3]))));
     }
 }
 
@@ -594,19 +607,19 @@ ISX_API int isx_rows_to_f16(const float* x, int64_t B, int D, void* h, float* no
     if (B == 0) return ISX_OK;
     ISX_REQUIRE(x && h && norm2 && amax, "isx_rows_to_f16: null pointer");
     hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, B, D, (_Float16*)h, norm2, amax,
-                       (unsigned*)nullptr);
+                       (unsigned*)nullptr, 0);
     ISX_CHECK_LAUNCH("isx_rows_to_f16");
     return ISX_OK;
 }
 
 // stats must be zeroed (stream-ordered) before: pass 1 max |x|, pass 2 scaled conversion + max norm2.
-static int convert_scaled(const float* x, int64_t B, int D, _Float16* h, float* norm2, unsigned* stats, hipStream_t st) {
+static int convert_scaled(const float* x, int64_t B, int D, _Float16* h, float* norm2, unsigned* stats, int want_norm_max, hipStream_t st) {
     const int64_t n = B * D;
     int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, stats);
     ISX_CHECK_LAUNCH("amax");
-    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x, B, D, h, norm2, (float*)nullptr, stats);
+    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x, B, D, h, norm2, (float*)nullptr, stats, want_norm_max);
     ISX_CHECK_LAUNCH("rows_to_f16");
     return ISX_OK;
 }
@@ -618,7 +631,7 @@ ISX_API int isx_gallery_to_f16(const float* G, int64_t N, int D, void* Gh, float
     ISX_REQUIRE(gstats && ((G && Gh) || N == 0), "isx_gallery_to_f16: null pointer");
     if (hipMemsetAsync(gstats, 0, 8, (hipStream_t)stream) != hipSuccess) { isx_set_error("isx_gallery_to_f16: hipMemsetAsync failed"); return ISX_ERR_HIP; }
     if (N == 0) return ISX_OK;
-    return convert_scaled(G, N, D, (_Float16*)Gh, nullptr, (unsigned*)gstats, (hipStream_t)stream);
+    return convert_scaled(G, N, D, (_Float16*)Gh, nullptr, (unsigned*)gstats, 1, (hipStream_t)stream);
 }
 
 // Approximate similarity matrix from fp16 operands (fp32 accumulate): building block / diagnostic of the
@@ -675,7 +688,7 @@ ISX_API int isx_cosine_topk_fast(const float* Q, int64_t M, const float* G, int6
 
     // 1. fp16 operands
     if (hipMemsetAsync(qst, 0, 8, st) != hipSuccess) { isx_set_error("isx_cosine_topk_fast: hipMemsetAsync failed"); return ISX_ERR_HIP; }
-    rc = convert_scaled(Q, M, D, qh, qn2, (unsigned*)qst, st);
+    rc = convert_scaled(Q, M, D, qh, qn2, (unsigned*)qst, 0, st);
     if (rc) return rc;
     const _Float16* gh = (const _Float16*)Gh;
     const float* gs = gstats;

@@ -19,8 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def main():
     tag, stats = sys.argv[1], sys.argv[2]
     rows = list(csv.DictReader(open(stats)))
-    keep = [r for r in rows if "isx::" in r["Name"]]
-    others = [r for r in rows if "isx::" not in r["Name"]][:12]
+    keep = [r for r in rows if "isx::" in r["Name"] or "_ZN3isx" in r["Name"]]
+    others = [r for r in rows if "isx::" not in r["Name"] and "_ZN3isx" not in r["Name"]][:12]
     with open(os.path.join(HERE, tag + "_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
@@ -33,7 +33,7 @@ def main():
     if os.path.exists(trace):
         per = collections.defaultdict(list)
         for r in csv.DictReader(open(trace)):
-            if "isx::" in r["Kernel_Name"]:
+            if "isx::" in r["Kernel_Name"] or "_ZN3isx" in r["Kernel_Name"]:
                 per[(r["Kernel_Name"].split("(")[0][:90], r["Grid_Size_X"], r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         with open(os.path.join(HERE, tag + "_isx_kernels_by_shape.csv"), "w", newline="") as f:
             w = csv.writer(f)
@@ -44,7 +44,7 @@ def main():
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for cname, path in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
             for r in csv.DictReader(open(path)):
-                if r["Counter_Name"] == cname and "isx::" in r["Kernel_Name"]:
+                if r["Counter_Name"] == cname and ("isx::" in r["Kernel_Name"] or "_ZN3isx" in r["Kernel_Name"]):
                     per[(r["Kernel_Name"][:100], r["Grid_Size"])][cname].append(float(r["Counter_Value"]))
         out = {}
         with open(os.path.join(HERE, tag + "_pmc_hbm.csv"), "w", newline="") as f:
@@ -60,8 +60,9 @@ def main():
         traffic = {"cosine_gemm_kernel": {}}
         for grid, tot in out.get("cosine_gemm_kernel", {}).items():
             tiles = int(grid) // 256
-            for shape, t in (("512x10000x2048", 8 * 157), ("1024x10000x2048", 8 * 157), ("10000x32768x2048", 79 * 256)):
-                if tiles == t:
+            # bench step 1024 x 10000: whichever tile shape the launcher picked (128x128, 64x128, 128x64, 64x64)
+            for shape, ts in (("1024x10000x2048", (8 * 79, 16 * 79, 8 * 157, 16 * 157)), ("10000x32768x2048", (79 * 256,))):
+                if tiles in ts:
                     traffic["cosine_gemm_kernel"][shape] = tot
         json.dump(traffic, open(os.path.join(HERE, "roofline_traffic.json"), "w"), indent=1)
 
