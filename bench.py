@@ -184,9 +184,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    ops.KERNEL_TIMER = []                     # per-launch HIP events around the hand-written trunk convolutions
     for _ in range(args.steps):
         out = step(True)
     torch.cuda.synchronize()
+    trunk_timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -198,6 +200,10 @@ def main():
 
     gemm_ms = sum(a.elapsed_time(b) for a, b in gemm_ev) / len(gemm_ev)
     gap_ms = sum(a.elapsed_time(b) for a, b in gap_ev) / len(gap_ev)
+    trunk = {}
+    for name, flop, nbytes, ea, eb in trunk_timer:
+        t = trunk.setdefault(name, [0, 0.0, 0.0, 0.0])
+        t[0] += 1; t[1] += flop; t[2] += nbytes; t[3] += ea.elapsed_time(eb)
     gemm_flop = 2.0 * M * Ng * D
     gap_bytes = B * D * 49 * 4 + B * D * 4
 
@@ -275,6 +281,13 @@ def main():
                                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gap_bytes / (gap_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "launch_ms": gap_ms, "algorithmic_bytes_per_launch": gap_bytes},
         }
+        for name, (cnt, flop, nbytes, ms_) in sorted(trunk.items()):
+            # all launches of one hand-written trunk kernel over the timed steps: algorithmic FLOP (and bytes) / summed HIP-event time
+            line["roofline_" + name] = {"kernel": name + (" = cosine_gemm_kernel<EPI=2>" if "1x1" in name else " = conv3x3_nhwc_kernel") +
+                                        " (v_mfma_f32_32x32x2_f32, bias/residual/ReLU fused)", "bound": "mfma",
+                                        "achieved": flop / (ms_ * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": flop / (ms_ * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "launches_per_step": cnt // args.steps,
+                                        "ms_per_step": ms_ / args.steps, "algorithmic_GBps": nbytes / (ms_ * 1e-3) / 1e9}
         if shard_result is not None:
             line["retrieval_shard"] = shard_result
         if world == 1 and not args.no_cpu_baseline:

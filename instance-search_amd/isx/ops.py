@@ -90,6 +90,22 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
+# Optional per-launch timing of the trunk kernels (bench.py): a list that receives
+# (kernel, algorithmic FLOP, algorithmic bytes, start event, end event) per call; None = off.
+KERNEL_TIMER = None
+
+
+def _timed(name, flop, nbytes, fn):
+    if KERNEL_TIMER is None:
+        return fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    out = fn()
+    b.record()
+    KERNEL_TIMER.append((name, flop, nbytes, a, b))
+    return out
+
+
 def bias_relu_maxpool(y, bias):
     """relu(y + bias[c]) -> MaxPool2d(3, 2, 1) of a channels-last (B,C,H,W) fp32 tensor in one pass."""
     if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous(memory_format=torch.channels_last)):
@@ -118,8 +134,10 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True):
         if residual.shape != y.shape or residual.dtype != torch.float32 or not residual.is_contiguous(memory_format=torch.channels_last):
             raise _lib.IsxError("residual must be a channels-last float32 tensor of the output's shape")
         rp = residual.data_ptr()
-    check(lib().isx_conv1x1_nhwc(x.data_ptr(), B * H * W, Cin, w.data_ptr(), Cout, _f32(bias, "bias").data_ptr(), rp,
-                                 1 if relu else 0, y.data_ptr(), _stream()), "isx_conv1x1_nhwc")
+    bp, px = _f32(bias, "bias").data_ptr(), B * H * W
+    _timed("isx_conv1x1_nhwc", 2.0 * px * Cin * Cout, 4.0 * (px * Cin + px * Cout * (2 if rp else 1) + Cin * Cout),
+           lambda: check(lib().isx_conv1x1_nhwc(x.data_ptr(), px, Cin, w.data_ptr(), Cout, bp, rp, 1 if relu else 0, y.data_ptr(), _stream()),
+                         "isx_conv1x1_nhwc"))
     return y
 
 
@@ -140,8 +158,10 @@ def conv3x3_nhwc(x, w_ohwi, bias, stride=1, residual=None, relu=True):
         if residual.shape != y.shape or residual.dtype != torch.float32 or not residual.is_contiguous(memory_format=torch.channels_last):
             raise _lib.IsxError("residual must be a channels-last float32 tensor of the output's shape")
         rp = residual.data_ptr()
-    check(lib().isx_conv3x3_nhwc(x.data_ptr(), B, H, W, Cin, w.data_ptr(), Cout, stride, _f32(bias, "bias").data_ptr(), rp,
-                                 1 if relu else 0, y.data_ptr(), _stream()), "isx_conv3x3_nhwc")
+    bp = _f32(bias, "bias").data_ptr()
+    _timed("isx_conv3x3_nhwc", 18.0 * B * Ho * Wo * Cin * Cout, 4.0 * (B * H * W * Cin + B * Ho * Wo * Cout * (2 if rp else 1) + 9 * Cin * Cout),
+           lambda: check(lib().isx_conv3x3_nhwc(x.data_ptr(), B, H, W, Cin, w.data_ptr(), Cout, stride, bp, rp, 1 if relu else 0, y.data_ptr(),
+                                                _stream()), "isx_conv3x3_nhwc"))
     return y
 
 
