@@ -202,33 +202,35 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int64_t ng = n0 + wn * (32 * TN) + j * 32;        // first column of this 32-column group
-            const int64_t n = ng + l31;
+            // wave-uniform row pointers + 32-bit lane offsets (64-bit per-element addresses cost ~35 VGPRs and a wave per SIMD)
+            const int64_t ng = n0 + wn_u * (32 * TN) + j * 32;      // first column of this 32-column group (uniform)
+            const int ncol = (int)ng + l31;
+            const bool n_ok = ncol < N;
+            const int lane_off = 4 * half * (int)ldc + ncol;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                const int64_t mu = m0 + wm_u * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2);     // uniform; this lane's row = mu + 4 * half
+                const bool row_ok = (mu + 4 * half < M);
                 const float v = acc[i][j][e];
                 if (EPI == 1) {
                     // fused top-k filter: a 32-column group of row m is stored only if one of its scores
                     // can still enter the row's top-k (score >= thr[m], a lower bound of the final k-th
                     // score); one flag byte per (row, group) tells the select kernel which groups exist.
                     // The test is a compare + wave ballot (no cross-lane data movement).
-                    const bool row_ok = (m < M);
-                    const float t = row_ok ? thr[m] : INFINITY;
-                    const unsigned long long qm = __ballot(n < N && v >= t);
+                    const float t = row_ok ? (thr + mu)[4 * half] : INFINITY;
+                    const unsigned long long qm = __ballot(n_ok && v >= t);
                     const bool q = ((half ? (qm >> 32) : qm) & 0xFFFFFFFFull) != 0ull;
                     if (row_ok && ng < N) {
-                        if (l31 == 0) gflag[m * ngrp + (ng >> 5)] = q ? 1 : 0;
-                        if (q && n < N) C[m * ldc + n] = v;
+                        if (l31 == 0) (gflag + mu * ngrp + (ng >> 5))[4 * half * ngrp] = q ? 1 : 0;
+                        if (q && n_ok) (C + mu * ldc)[lane_off] = v;
                     }
                 } else {
-                    if (m < M && n < N) C[m * ldc + n] = v;
+                    if (row_ok && n_ok) (C + mu * ldc)[lane_off] = v;
                 }
             }
         }
     }
 }
-
 
 // ---- 3x3 convolution (padding 1, stride 1 or 2) on NHWC activations as an IMPLICIT GEMM ----------------------
 // Same tile machinery as cosine_gemm_kernel: M = B*Ho*Wo output pixels, N = Cout, K = 9*Cin ordered (kh, kw, ci),
