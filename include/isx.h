@@ -70,6 +70,13 @@ int isx_gap_l2_nhwc(const float* fmap, int64_t B, int C, int H, int W, float eps
 int isx_bias_act_inplace(float* y, const float* bias, const float* residual, int64_t n, int C, int64_t inner, int relu,
                          isx_stream_t stream);
 
+/* Image ingest (next-scope row f4): transforms.ToTensor() + transforms.Normalize(m, s) of the test mains
+ * (test/classif_finetune_test.py:62-73, classif_regions_test.py:55-65, siamese_*_test.py) from decoded RGB bytes:
+ * out[b][c][h][w] = (img[b][h][w][c] / 255 - mean[c]) / std[c], fp32, same operation order as torch.
+ * img: (B,H,W,3) uint8 RGB; out: (B,3,H,W) fp32 in NCHW memory, or channels-last memory ((B,H,W,3)) when channels_last != 0. */
+int isx_images_u8_to_f32(const uint8_t* img, int64_t B, int H, int W, float mean0, float mean1, float mean2, float std0, float std1,
+                         float std2, int channels_last, float* out, isx_stream_t stream);
+
 /* Stem of the same trunk: relu(conv7x7 + bias) -> MaxPool2d(3, stride 2, padding 1) (torchvision ResNet stem as split
  * by model/nn_utils.py:56-71), epilogue and pooling in ONE pass over the channels-last convolution output:
  * out[b][ho][wo][c] = relu(max_{3x3 window, in bounds} y[b][2ho-1+kh][2wo-1+kw][c] + bias[c]).

@@ -439,7 +439,55 @@ __global__ __launch_bounds__(256) void bias_relu_maxpool_nhwc_kernel(const float
     }
 }
 
+// Image ingest: transforms.ToTensor() + Normalize(mean, std) of the reference's test mains
+// (test/classif_finetune_test.py:62-73) on the GPU, from the decoded uint8 RGB pixels: 3 B read and 12 B written
+// per pixel, and only the uint8 batch crosses PCIe (a quarter of the fp32 tensor).  Same fp32 operations in the same
+// order as torch: x = u8 / 255, (x - mean[c]) / std[c].  One thread per 4 pixels (12 bytes = three aligned dwords).
+__global__ __launch_bounds__(256) void images_u8_to_f32_kernel(const uint8_t* __restrict__ img, int64_t B, int HW, float m0, float m1,
+                                                               float m2, float s0, float s1, float s2, int nhwc, float* __restrict__ out) {
+    const int64_t quads = ((int64_t)B * HW + 3) / 4;
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (int64_t)gridDim.x * 256) {
+        const int64_t p0 = q * 4;
+        const int64_t total = (int64_t)B * HW;
+        uint8_t u[12];
+        if (p0 + 3 < total && (((uintptr_t)img) & 3) == 0) {
+            const uint32_t* w = reinterpret_cast<const uint32_t*>(img + p0 * 3);
+            const uint32_t a = w[0], b = w[1], c = w[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { u[i] = (a >> (8 * i)) & 255; u[4 + i] = (b >> (8 * i)) & 255; u[8 + i] = (c >> (8 * i)) & 255; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 12; ++i) u[i] = (p0 * 3 + i < total * 3) ? img[p0 * 3 + i] : 0;
+        }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const int64_t p = p0 + px;
+            if (p >= total) break;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = ((float)u[px * 3 + c] / 255.0f - mean[c]) / sd[c];
+                if (nhwc) out[p * 3 + c] = v;
+                else { const int64_t b = p / HW; out[(b * 3 + c) * (int64_t)HW + (p - b * HW)] = v; }
+            }
+        }
+    }
+}
+
 }  // namespace isx
+
+ISX_API int isx_images_u8_to_f32(const uint8_t* img, int64_t B, int H, int W, float mean0, float mean1, float mean2, float std0, float std1,
+                                 float std2, int channels_last, float* out, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && (int64_t)H * W < (1ll << 31), "isx_images_u8_to_f32: bad shape B=%lld H=%d W=%d", (long long)B, H, W);
+    ISX_REQUIRE(std0 != 0.0f && std1 != 0.0f && std2 != 0.0f, "isx_images_u8_to_f32: zero std");
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(img && out, "isx_images_u8_to_f32: null pointer");
+    const int64_t quads = (B * H * W + 3) / 4, blocks = (quads + 255) / 256;
+    hipLaunchKernelGGL(isx::images_u8_to_f32_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, (hipStream_t)stream, img, B,
+                       H * W, mean0, mean1, mean2, std0, std1, std2, channels_last ? 1 : 0, out);
+    ISX_CHECK_LAUNCH("isx_images_u8_to_f32");
+    return ISX_OK;
+}
 
 ISX_API int isx_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int H, int W, int C, float* out, isx_stream_t stream) {
     ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "isx_bias_relu_maxpool_nhwc: bad shape B=%lld H=%d W=%d C=%d (C %% 4 == 0)", (long long)B, H, W, C);

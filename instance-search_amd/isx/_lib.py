@@ -23,6 +23,7 @@ _SIGNATURES = {
     "isx_gap_l2": (C.c_int, [VP, I64, I32, I32, I32, F32, VP, VP]),
     "isx_gap_l2_nhwc": (C.c_int, [VP, I64, I32, I32, I32, F32, VP, VP]),
     "isx_bias_act_inplace": (C.c_int, [VP, VP, VP, I64, I32, I64, I32, VP]),
+    "isx_images_u8_to_f32": (C.c_int, [VP, I64, I32, I32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, I32, VP, VP]),
     "isx_bias_relu_maxpool_nhwc": (C.c_int, [VP, VP, I64, I32, I32, I32, VP, VP]),
     "isx_conv1x1_nhwc": (C.c_int, [VP, I64, I32, VP, I32, VP, VP, I32, VP, VP]),
     "isx_conv3x3_nhwc": (C.c_int, [VP, I64, I32, I32, I32, VP, I32, I32, VP, VP, I32, VP, VP]),

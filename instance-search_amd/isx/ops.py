@@ -90,6 +90,19 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
+def images_u8_to_f32(img_u8, mean, std, channels_last=True):
+    """ToTensor + Normalize on the GPU: (B,H,W,3) uint8 RGB -> (B,3,H,W) fp32 (channels-last memory by default)."""
+    if not (img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[3] == 3 and img_u8.is_contiguous()):
+        raise _lib.IsxError("img_u8 must be a contiguous (B,H,W,3) uint8 CUDA tensor")
+    B, H, W, _ = img_u8.shape
+    out = torch.empty((B, 3, H, W), device=img_u8.device, dtype=torch.float32,
+                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
+    m, s_ = [float(v) for v in mean], [float(v) for v in std]
+    check(lib().isx_images_u8_to_f32(img_u8.data_ptr(), B, H, W, m[0], m[1], m[2], s_[0], s_[1], s_[2], 1 if channels_last else 0,
+                                     out.data_ptr(), _stream()), "isx_images_u8_to_f32")
+    return out
+
+
 # Optional per-launch timing of the trunk kernels (bench.py): a list that receives
 # (kernel, algorithmic FLOP, algorithmic bytes, start event, end event) per call; None = off.
 KERNEL_TIMER = None

@@ -49,10 +49,17 @@ def dataset_id_of(dataset_full):
     return synthetic_spec(dataset_full)[0] if is_synthetic(dataset_full) else parse_dataset_id(dataset_full)
 
 
-def load_sets(dataset_full, labels):
+def to_raw_tensor(img):
+    """Decoded image as an (H,W,3) uint8 tensor: normalised later, on the GPU, by train._common.stage_batch."""
+    import numpy as np
+    return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
+
+
+def load_sets(dataset_full, labels, raw=False):
     """(test_set, test_train_set) as lists of (normalised tensor, label, path); fills `labels`
     with the sorted label set of the reference (gallery) images; queries whose label is
-    unknown are dropped (reference test/classif_finetune_test.py:62-73)."""
+    unknown are dropped (reference test/classif_finetune_test.py:62-73).  raw=True keeps folder images
+    as uint8 (H,W,3) tensors and registers mean/std for the GPU-side ToTensor + Normalize."""
     if is_synthetic(dataset_full):
         _, o = synthetic_spec(dataset_full)
         size = (3, o['size'], o['size'])
@@ -66,7 +73,12 @@ def load_sets(dataset_full, labels):
     qry_files = get_images_labels(dataset_full + '/test', match)
     labels.extend(sorted(set(lab for _, lab in ref_files)))
     mean, std = read_mean_std(mean_std_files[dataset_id])
-    load = lambda f: to_normalised_tensor(imread_rgb(f), mean, std)
+    if raw:
+        from train import _common as TC
+        TC.RAW_INGEST["mean"], TC.RAW_INGEST["std"] = list(mean), list(std)
+        load = lambda f: to_raw_tensor(imread_rgb(f))
+    else:
+        load = lambda f: to_normalised_tensor(imread_rgb(f), mean, std)
     ref = [(load(f), lab, f) for f, lab in ref_files]
     qry = [(load(f), lab, f) for f, lab in qry_files if lab in labels]
     return qry, ref

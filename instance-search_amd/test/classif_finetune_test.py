@@ -28,7 +28,7 @@ def main(dataset_full, model, weights, device, classify, batch_size, dba):
     dataset_id = C.dataset_id_of(dataset_full)
     del labels[:]
     print('Loading and transforming train/test sets.')
-    test_set, test_train_set = C.load_sets(dataset_full, labels)
+    test_set, test_train_set = C.load_sets(dataset_full, labels, raw=(device >= 0))   # GPU runs ingest uint8 pixels and normalise on the device
     # the globals the retrieval functions read (reference :44-56)
     P.test_pre_proc = True
     P.cuda_device = device

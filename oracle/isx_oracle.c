@@ -205,6 +205,17 @@ ISXO_API void isxo_cosine_sim(const float* Q, int64_t M, const float* G, int64_t
         for (int64_t j = 0; j < N; ++j) sim[i * N + j] = dot_fma(Q + i * D, G + j * D, D);
 }
 
+/* transforms.ToTensor() + transforms.Normalize(m, s) (test/classif_finetune_test.py:62-73): (B,H,W,3) uint8 -> (B,3,H,W) fp32. */
+ISXO_API void isxo_images_u8_to_f32(const uint8_t* img, int64_t B, int H, int W, const float* mean, const float* sd, float* out) {
+    const int64_t HW = (int64_t)H * W;
+    for (int64_t b = 0; b < B; ++b)
+        for (int64_t p = 0; p < HW; ++p)
+            for (int c = 0; c < 3; ++c) {
+                const float x = (float)img[(b * HW + p) * 3 + c] / 255.0f;
+                out[(b * 3 + c) * HW + p] = (x - mean[c]) / sd[c];
+            }
+}
+
 /* relu(y + bias) -> MaxPool2d(3, stride 2, padding 1) on an NHWC map (torchvision ResNet stem after the folded BN). */
 ISXO_API void isxo_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int H, int W, int C, float* out) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;

@@ -105,6 +105,14 @@ def cosine_sim(Q, G):
     return sim
 
 
+def images_u8_to_f32(img, mean, std):
+    img = np.ascontiguousarray(img, np.uint8); B, H, W, _ = img.shape
+    out = np.empty((B, 3, H, W), np.float32)
+    m = np.asarray(mean, np.float32); s_ = np.asarray(std, np.float32)
+    lib().isxo_images_u8_to_f32(img.ctypes.data_as(C.c_void_p), C.c_int64(B), H, W, _p(m, F32P), _p(s_, F32P), _p(out, F32P))
+    return out
+
+
 def bias_relu_maxpool_nhwc(y, bias):
     y = _f32(y); bias = _f32(bias); B, H, W, Cc = y.shape
     out = np.empty((B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc), np.float32)

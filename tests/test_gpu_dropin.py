@@ -171,3 +171,48 @@ def test_bias_act_and_folded_trunk():
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_folder_dataset_raw_ingest_end_to_end(tmp_path, capsys, monkeypatch):
+    """A real folder of image files through the reference's CLI surface on the GPU: images are decoded to uint8,
+    shipped as bytes and normalised by isx_images_u8_to_f32.  The descriptors must equal those of the
+    reference's own ingest (ToTensor + Normalize on the host, fp32 tensors in the dataset) bit for bit."""
+    from PIL import Image
+    from test import _common as C
+    from test import classif_finetune_test
+    rng = np.random.default_rng(11)
+    root = tmp_path / "CLICIDE_video_224sq"
+    (root / "test").mkdir(parents=True)
+    (tmp_path / "data").mkdir()
+    (tmp_path / "data" / "CLICIDE_224sq_train_ms.txt").write_text("0.485 0.456 0.406\n0.229 0.224 0.225\n")
+    for lab in ("a", "b", "c"):
+        for i in range(3):
+            Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(root / ("%s-%d.png" % (lab, i)))
+        Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(root / "test" / ("%s-9.png" % lab))
+    monkeypatch.chdir(tmp_path)
+    seen = []
+    real_eval, real_load = C.evaluate_retrieval, C.load_sets
+
+    def spy(test_embeddings, ref_embeddings, *a, **k):
+        seen.append((test_embeddings.clone(), ref_embeddings.clone()))
+        return real_eval(test_embeddings, ref_embeddings, *a, **k)
+
+    monkeypatch.setattr(C, "evaluate_retrieval", spy)
+    kinds = []
+
+    def load_raw(dataset_full, labels, raw=False):
+        out = real_load(dataset_full, labels, raw=raw)
+        kinds.append(out[1][0][0].dtype)
+        return out
+
+    monkeypatch.setattr(C, "load_sets", load_raw)
+    classif_finetune_test.main(str(root), "resnet50", "", 0, False, 4, 0)
+    monkeypatch.setattr(C, "load_sets", lambda d, l, raw=False: load_raw(d, l, raw=False))
+    classif_finetune_test.main(str(root), "resnet50", "", 0, False, 4, 0)
+    capsys.readouterr()
+    assert kinds == [torch.uint8, torch.float32]
+    (q_raw, g_raw), (q_f32, g_f32) = seen
+    assert g_raw.shape == (9, 2048) and q_raw.shape == (3, 2048)
+    # same pixels, same arithmetic -> same network input; MIOpen may pick another kernel between runs, hence a tolerance
+    np.testing.assert_allclose(host(g_raw), host(g_f32), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(q_raw), host(q_f32), rtol=1e-5, atol=1e-6)

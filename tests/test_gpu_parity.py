@@ -456,3 +456,33 @@ def test_bias_relu_maxpool(ops, B, H, W, C):
     np.testing.assert_array_equal(got, O.bias_relu_maxpool_nhwc(y, b))
     ref = torch.nn.functional.max_pool2d(torch.relu(dev(y).permute(0, 3, 1, 2) + dev(b).view(1, -1, 1, 1)), 3, 2, 1)
     np.testing.assert_array_equal(got, host(ref.permute(0, 2, 3, 1)))
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 1, 1), (2, 5, 7), (3, 224, 224), (2, 13, 3)])
+@pytest.mark.parametrize("cl", [True, False])
+def test_images_u8_to_f32(ops, B, H, W, cl):
+    rng = np.random.default_rng(H)
+    img = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    img[0, 0, 0] = (0, 255, 128)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    got = host(ops.images_u8_to_f32(dev(img), mean, std, channels_last=cl))
+    np.testing.assert_array_equal(got, O.images_u8_to_f32(img, mean, std))
+    # torch's ToTensor + Normalize arithmetic
+    x = torch.from_numpy(img).permute(0, 3, 1, 2).float().div(255.0)
+    ref = (x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    np.testing.assert_array_equal(got, ref.numpy())
+
+
+def test_stage_batch_raw_ingest(ops):
+    """uint8 datasets: stage_batch normalises on the GPU exactly like the CPU ToTensor + Normalize path."""
+    from train import _common as TC
+    rng = np.random.default_rng(3)
+    raw = [(torch.from_numpy(rng.integers(0, 256, (32, 48, 3), dtype=np.uint8)), i % 3, "im%d" % i) for i in range(5)]
+    TC.RAW_INGEST["mean"], TC.RAW_INGEST["std"] = [0.4, 0.5, 0.6], [0.2, 0.25, 0.3]
+    try:
+        g = TC.stage_batch(raw, None, 0)
+        c = TC.stage_batch(raw, None, -1)
+    finally:
+        TC.RAW_INGEST["mean"] = TC.RAW_INGEST["std"] = None
+    assert g.is_cuda and g.shape == (5, 3, 32, 48) and g.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_array_equal(host(g), c.numpy())

@@ -190,3 +190,14 @@ def test_trunk_block(golden):
         y = O.conv1x1_nhwc(t.reshape(-1, Cm), f[2][0].reshape(f[2][0].shape[0], -1), bias3, idt.reshape(-1, idt.shape[-1]), True)
         y = y.reshape(Bo, Ho, Wo, -1)
         np.testing.assert_allclose(y.transpose(0, 3, 1, 2), g["y%d" % blk], rtol=2e-5, atol=2e-5)
+
+
+def test_images_u8_to_f32_matches_torch():
+    """ToTensor + Normalize restatement == torch's own arithmetic (bit-exact)."""
+    import torch
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (2, 9, 11, 3), dtype=np.uint8)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    x = torch.from_numpy(img).permute(0, 3, 1, 2).float().div(255.0)
+    ref = (x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
+    np.testing.assert_array_equal(O.images_u8_to_f32(img, mean, std), ref.numpy())
