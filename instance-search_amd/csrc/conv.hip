@@ -1,0 +1,204 @@
+// conv.hip -- convolutions of the inference trunk on channels-last activations (model/nn_utils.py fold_batch_norm).
+//
+//   isx_conv1x1_nhwc   the activation matrix (B*H*W, Cin) IS the row-major A operand of the fp32-MFMA GEMM of
+//                      cosine.hip; this file only adds the entry point (epilogue mode 2 of cosine_gemm_kernel)
+//   isx_conv3x3_nhwc   implicit GEMM below
+//
+// Reference call sites: the torchvision ResNet `features` trunk built by model/ModelDefinition.py, split by
+// model/nn_utils.py:56-71 and run from model/siamese.py:20,107,151.
+#include "gemm_tile.hpp"
+
+namespace isx {
+
+// ---- 3x3 convolution (padding 1, stride 1 or 2) on NHWC activations as an IMPLICIT GEMM ----------------------
+// Same tile machinery as cosine_gemm_kernel: M = B*Ho*Wo output pixels, N = Cout, K = 9*Cin ordered (kh, kw, ci),
+// weights pre-arranged (Cout, 3, 3, Cin).  A k-tile lies inside one filter tap (Cin % BK == 0), so the A rows of a
+// k-tile are the input pixels shifted by that tap: one base pixel per staged row, kept in registers, plus a
+// bounds test per tap (padding rows load zeros -- fma(0, w, acc) leaves acc unchanged, as skipping the tap would).
+// Epilogue: bias (+ residual) + ReLU fused, wave-uniform row pointers.  Replaces conv2 of the torchvision
+// Bottleneck / both convolutions of BasicBlock inside the `features` trunk.
+struct Conv3x3Geom { int H, W, Cin, Ho, Wo, stride; };
+
+template <int TM, int TN, int BK>
+__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
+                                                           Conv3x3Geom g, float* __restrict__ C, TileMap tm,
+                                                           const float* __restrict__ bias, const float* __restrict__ res, int relu) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 1, LDB = BN + 1;
+    constexpr int CH = BK / 4, NA = BM * CH / 256;
+    __shared__ float lds[BK * (LDA + LDB)];
+    float* As = lds;
+    float* Bs = lds + BK * LDA;
+
+    int tile_m, tile_n;
+    tile_of_block(tm, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int D = 9 * g.Cin;
+    const int64_t ldc = N;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // staged A rows of this thread: top-left input pixel of the 3x3 window (may be -1: padding)
+    int pbase[NA], hw0[NA];                       // pixel index of (hi0, wi0); (hi0 + 1) << 16 | (wi0 + 1)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int idx = j * 256 + threadIdx.x;
+        int64_t m = m0 + idx / CH;
+        m = m < M ? m : M - 1;
+        const int hw = g.Ho * g.Wo;
+        const int b = (int)(m / hw), rem = (int)(m - (int64_t)b * hw);
+        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+        const int hi0 = ho * g.stride - 1, wi0 = wo * g.stride - 1;
+        pbase[j] = (b * g.H + hi0) * g.W + wi0;
+        hw0[j] = ((hi0 + 1) << 16) | (wi0 + 1);
+    }
+    const int c4 = (threadIdx.x % CH) << 2;
+    int kh = 0, kw = 0, ci0 = 0;                  // tap / channel offset of the NEXT k-tile to load (uniform)
+    float4 ra[NA], rb[BN * BK / 1024];
+    const float* ap[NA];                          // source of the next k-tile inside the current tap
+    bool aok[NA];                                 // current tap inside the image for this row?
+    auto load_a = [&]() {
+        if (ci0 == 0) {                           // new tap (uniform branch, once per Cin / BK k-tiles)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int hi = (hw0[j] >> 16) - 1 + kh, wi = (hw0[j] & 0xFFFF) - 1 + kw;
+                aok[j] = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+                ap[j] = x + (int64_t)(pbase[j] + kh * g.W + kw) * g.Cin + c4;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            ra[j] = aok[j] ? *reinterpret_cast<const float4*>(ap[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ap[j] += BK;
+        }
+        ci0 += BK;
+        if (ci0 == g.Cin) { ci0 = 0; if (++kw == 3) { kw = 0; ++kh; } }
+    };
+    const int nk = D / BK;
+    load_a();
+    load_tile<true, BN, BK>(Wt, N, D, n0, 0, rb);
+    store_tile<BM, BK>(As, ra);
+    store_tile<BN, BK>(Bs, rb);
+    __syncthreads();
+
+    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
+    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_a();
+            load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = a_base[(2 * kk) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = b_base[(2 * kk) * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tile<BM, BK>(As, ra);
+            store_tile<BN, BK>(Bs, rb);
+            __syncthreads();
+        }
+    }
+
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ncol = (int)(n0 + wn_u * (32 * TN) + j * 32) + l31;
+            const bool n_ok = ncol < N;
+            const float bias_v = n_ok ? bias[ncol] : 0.0f;
+            const int lane_off = 4 * half * (int)ldc + ncol;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t mu = m0 + wm_u * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2);     // uniform
+                if (n_ok && mu + 4 * half < M) {
+                    float y = acc[i][j][e] + bias_v;
+                    if (res) y += (res + mu * ldc)[lane_off];
+                    (C + mu * ldc)[lane_off] = relu ? fmaxf(y, 0.0f) : y;
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int BK>
+static void launch_conv3x3(const float* x, int64_t M, const float* w, int64_t N, const Conv3x3Geom& g, float* y, const float* bias,
+                           const float* res, int relu, hipStream_t st) {
+    TileMap tm;
+    tm.m_active = nullptr;
+    tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
+    tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<TM, TN, BK>), dim3((unsigned)(tm.tiles_m * tm.tiles_n)), dim3(256), 0, st, x, M, w, N, g, y, tm, bias,
+                       res, relu);
+}
+
+static int g_force_conv_cfg = -1;
+
+}  // namespace isx
+
+using namespace isx;
+
+// 1x1 stride-1 convolution on NHWC activations: one GEMM over the pixels with the bias / residual / ReLU epilogue fused
+// (the backbone layers of model/ModelDefinition.py's torchvision ResNets inside `features`, model/siamese.py:20,107,151).
+ISX_API int isx_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float* w, int Cout, const float* bias, const float* residual,
+                             int relu, float* y, isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && Cin > 0 && Cout > 0, "isx_conv1x1_nhwc: bad shape M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout);
+    if (M == 0) return ISX_OK;
+    ISX_REQUIRE(x && w && bias && y, "isx_conv1x1_nhwc: null pointer");
+    ISX_REQUIRE(y != x && y != residual, "isx_conv1x1_nhwc: y must not alias x or residual");
+    return launch_conv1x1_gemm(x, M, w, Cout, Cin, y, bias, residual, relu ? 1 : 0, (hipStream_t)stream);
+}
+
+// 3x3 convolution, padding 1, stride 1 or 2, NHWC activations, weights (Cout,3,3,Cin), bias / residual / ReLU fused.
+ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, const float* w_ohwi, int Cout, int stride,
+                             const float* bias, const float* residual, int relu, float* y, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2),
+                "isx_conv3x3_nhwc: bad shape B=%lld H=%d W=%d Cin=%d Cout=%d stride=%d", (long long)B, H, W, Cin, Cout, stride);
+    ISX_REQUIRE(Cin % 32 == 0, "isx_conv3x3_nhwc: Cin=%d must be a multiple of 32", Cin);
+    ISX_REQUIRE(H < 32767 && W < 32767 && B * H * W < (1ll << 31), "isx_conv3x3_nhwc: input has too many pixels for 32-bit pixel indices");
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(x && w_ohwi && bias && y, "isx_conv3x3_nhwc: null pointer");
+    ISX_REQUIRE((((uintptr_t)x | (uintptr_t)w_ohwi) % 16) == 0, "isx_conv3x3_nhwc: x and w must be 16-B aligned");
+    ISX_REQUIRE(y != x && y != residual, "isx_conv3x3_nhwc: y must not alias x or residual");
+    Conv3x3Geom g;
+    g.H = H; g.W = W; g.Cin = Cin; g.stride = stride;
+    g.Ho = (H - 1) / stride + 1;
+    g.Wo = (W - 1) / stride + 1;
+    const int64_t M = B * g.Ho * g.Wo, N = Cout;
+    ISX_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), "isx_conv3x3_nhwc: too many tiles");
+    // measured on the ResNet-50 shapes (B = 512): 128x64 tiles win while the launch has >= ~2 rounds of them,
+    // 64x64 tiles (6 workgroups per CU) below; 128x128 never does here (79 VGPRs + 64 accumulators: 3 waves/SIMD)
+    int best = (M > 131072 && N >= 64) ? 2 : 3;
+    if (g_force_conv_cfg == 0 || g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
+    hipStream_t st = (hipStream_t)stream;
+    switch (best) {
+        case 0: launch_conv3x3<2, 2, 16>(x, M, w_ohwi, N, g, y, bias, residual, relu ? 1 : 0, st); break;
+        case 2: launch_conv3x3<2, 1, 32>(x, M, w_ohwi, N, g, y, bias, residual, relu ? 1 : 0, st); break;
+        default: launch_conv3x3<1, 1, 32>(x, M, w_ohwi, N, g, y, bias, residual, relu ? 1 : 0, st); break;
+    }
+    ISX_CHECK_LAUNCH("isx_conv3x3_nhwc");
+    return ISX_OK;
+}
+
+// Debug / A-B hook (not declared in include/isx.h): force the conv3x3 tile shape (0, 2, 3), -1 = automatic.
+ISX_API void isx_debug_set_conv_cfg(int c) { g_force_conv_cfg = c; }
+

@@ -1,0 +1,71 @@
+// gemm_tile.hpp -- device helpers shared by the fp32-MFMA GEMM (cosine.hip) and the implicit-GEMM 3x3 convolution
+// (conv.hip): XCD-aware tile mapping and the K-major LDS staging of operand tiles.
+#pragma once
+#include "isx_internal.hpp"
+
+namespace isx {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int GROUP_N = 16;            // n-tiles per scheduling group
+
+struct TileMap {
+    int tiles_m, tiles_n;
+    const int* m_active;       // optional device scalar: only rows < *m_active are live (fast.hip fallback)
+};
+
+__device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int& tile_n) {
+    // bijective XCD remap (blocks b and b+8 share an XCD): XCD x gets a contiguous id range
+    const int nwg = tm.tiles_m * tm.tiles_n;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    // grouped order: GROUP_N n-tiles wide, all m-tiles tall, n fastest inside a group row
+    const int per_group = GROUP_N * tm.tiles_m;
+    const int gid = wg / per_group;
+    const int first_n = gid * GROUP_N;
+    const int gsz = min(GROUP_N, tm.tiles_n - first_n);
+    const int within = wg - gid * per_group;
+    tile_m = within / gsz;
+    tile_n = first_n + within % gsz;
+}
+
+// ROWS x BK k = ROWS*CH float4; thread t takes idx = j*256 + t: row = idx/CH, chunk = idx%CH
+template <bool ALIGNED, int ROWS, int BK>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t rows, int D, int64_t row0, int k0,
+                                          float4 (&reg)[ROWS * BK / 1024]) {
+    constexpr int CH = BK / 4;               // 16-B chunks per staged row
+#pragma unroll
+    for (int j = 0; j < ROWS * CH / 256; ++j) {
+        const int idx = j * 256 + threadIdx.x;
+        int64_t r = row0 + (idx / CH);
+        r = r < rows ? r : rows - 1;                       // clamp: rows past the edge are never stored
+        const int k = k0 + ((idx % CH) << 2);
+        const float* src = P + r * D + k;
+        if (ALIGNED) {
+            reg[j] = (k < D) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            reg[j].x = (k + 0 < D) ? src[0] : 0.f;
+            reg[j].y = (k + 1 < D) ? src[1] : 0.f;
+            reg[j].z = (k + 2 < D) ? src[2] : 0.f;
+            reg[j].w = (k + 3 < D) ? src[3] : 0.f;
+        }
+    }
+}
+
+template <int ROWS, int BK>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&reg)[ROWS * BK / 1024]) {
+    constexpr int CH = BK / 4;
+    constexpr int LD = ROWS + 1;                            // odd K-major stride: conflict-free transposed writes
+#pragma unroll
+    for (int j = 0; j < ROWS * CH / 256; ++j) {
+        const int idx = j * 256 + threadIdx.x;
+        const int r = idx / CH, k = (idx % CH) << 2;
+        T[(k + 0) * LD + r] = reg[j].x;
+        T[(k + 1) * LD + r] = reg[j].y;
+        T[(k + 2) * LD + r] = reg[j].z;
+        T[(k + 3) * LD + r] = reg[j].w;
+    }
+}
+
+}  // namespace isx

@@ -15,6 +15,10 @@ int launch_cosine_gemm(const float* Q, int64_t M, const float* G, int64_t N, int
 int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t N, int D, float* C, int64_t ldc,
                               const float* thr, uint8_t* gflag, hipStream_t st, const int* m_active = nullptr);
 
+// 1x1 convolution over channels-last pixels: the same GEMM, epilogue y = act(. + bias[n] (+ residual)) (used by conv.hip)
+int launch_conv1x1_gemm(const float* x, int64_t M, const float* w, int64_t N, int D, float* y, const float* bias, const float* residual, int relu,
+                        hipStream_t st);
+
 // fp16-operand variant (fast.hip): approximate scores, fp32 accumulate; gflag == nullptr -> plain GEMM.
 int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C, int64_t ldc, const float* thr,
                     uint8_t* gflag, hipStream_t st);
