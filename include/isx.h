@@ -93,6 +93,14 @@ int isx_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int
 int isx_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float* w, int Cout, const float* bias,
                      const float* residual, int relu, float* y, isx_stream_t stream);
 
+/* Last 1x1 convolution of a bottleneck block together with the block's 1x1 projection shortcut (torchvision Bottleneck
+ * conv3 + downsample, same call sites) as ONE GEMM over the output pixels:
+ *   y[m][co] = act( sum_c t[m][c] w_cat[co][c]  +  sum_c x[pix(m)][c] w_cat[co][K1 + c]  +  bias[co] ),
+ * pix(m) = the input pixel (ho*stride, wo*stride) of output pixel m; one fp32 fma chain per output (t's channels first).
+ * t: (B,Ho,Wo,K1); x: (B,H,W,K2); w_cat: (Cout, K1 + K2); y: (B,Ho,Wo,Cout); K1 % 32 == K2 % 32 == 0. */
+int isx_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_t B, int H, int W, int K2, int stride, const float* w_cat,
+                          int Cout, const float* bias, int relu, float* y, isx_stream_t stream);
+
 /* 3x3 convolution (padding 1, stride 1 or 2) of the same trunk, channels-last, as an implicit GEMM on the fp32
  * matrix cores: M = B*Ho*Wo output pixels, K = 9*Cin in (kh, kw, ci) order (one fp32 fma chain per output, bit-exact
  * vs the oracle), epilogue act(. + bias[co] + residual) fused.  Replaces conv2 of the torchvision Bottleneck and the

@@ -151,6 +151,142 @@ static void launch_conv3x3(const float* x, int64_t M, const float* w, int64_t N,
                        res, relu);
 }
 
+
+// ---- last convolution of a bottleneck block WITH its projection shortcut, as ONE GEMM -------------------------
+//   y = relu( W3 . t  +  Wd . x_s  +  (b3 + bd) )  =  relu( [W3 | Wd] . [t ; x_s] + b )
+// t: (M, K1) the block's 3x3 output, x: the block input (B,H,W,K2) sampled with the projection's stride (1x1, no
+// padding), weights concatenated along K.  The shortcut tensor is never written or read back (a (M, Cout) round trip:
+// 6.6 GB in layer 1 at B = 1024) and one launch disappears.  K order: all of t's channels, then all of x's -- one fp32
+// fma chain per output, restated by the oracle.
+struct DualGeom { int H, W, Ho, Wo, stride, K1, K2; };
+
+template <int TM, int TN, int BK>
+__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t M,
+                                                                                      const float* __restrict__ Wt, int64_t N, DualGeom g,
+                                                                                      float* __restrict__ C, TileMap tm,
+                                                                                      const float* __restrict__ bias, int relu) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 1, LDB = BN + 1;
+    constexpr int CH = BK / 4, NA = BM * CH / 256;
+    __shared__ float lds[BK * (LDA + LDB)];
+    float* As = lds;
+    float* Bs = lds + BK * LDA;
+
+    int tile_m, tile_n;
+    tile_of_block(tm, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+    const int D = g.K1 + g.K2;
+    const int64_t ldc = N;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int c4 = (threadIdx.x % CH) << 2;
+    const float* ap[NA];                          // source of the next k-tile of each staged row
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int64_t m = m0 + (j * 256 + threadIdx.x) / CH;
+        m = m < M ? m : M - 1;
+        ap[j] = t + m * g.K1 + c4;
+    }
+    int kdone = 0;                                // channels of the current source already issued (uniform)
+    bool second = false;
+    float4 ra[NA], rb[BN * BK / 1024];
+    auto load_a = [&]() {
+        if (!second && kdone == g.K1) {           // switch to the block input, sampled with the projection's stride
+            second = true;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                int64_t m = m0 + (j * 256 + threadIdx.x) / CH;
+                m = m < M ? m : M - 1;
+                const int hw = g.Ho * g.Wo;
+                const int b = (int)(m / hw), rem = (int)(m - (int64_t)b * hw);
+                const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+                ap[j] = x + ((int64_t)(b * g.H + ho * g.stride) * g.W + wo * g.stride) * g.K2 + c4;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            ra[j] = *reinterpret_cast<const float4*>(ap[j]);
+            ap[j] += BK;
+        }
+        kdone += BK;
+    };
+    const int nk = D / BK;
+    load_a();
+    load_tile<true, BN, BK>(Wt, N, D, n0, 0, rb);
+    store_tile<BM, BK>(As, ra);
+    store_tile<BN, BK>(Bs, rb);
+    __syncthreads();
+
+    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
+    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_a();
+            load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = a_base[(2 * kk) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = b_base[(2 * kk) * LDB + 32 * j];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            store_tile<BM, BK>(As, ra);
+            store_tile<BN, BK>(Bs, rb);
+            __syncthreads();
+        }
+    }
+
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ncol = (int)(n0 + wn_u * (32 * TN) + j * 32) + l31;
+            const bool n_ok = ncol < N;
+            const float bias_v = n_ok ? bias[ncol] : 0.0f;
+            const int lane_off = 4 * half * (int)ldc + ncol;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t mu = m0 + wm_u * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2);     // uniform
+                if (n_ok && mu + 4 * half < M) {
+                    const float y = acc[i][j][e] + bias_v;
+                    (C + mu * ldc)[lane_off] = relu ? fmaxf(y, 0.0f) : y;
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN, int BK>
+static void launch_dual(const float* t, const float* x, int64_t M, const float* w, int64_t N, const DualGeom& g, float* y, const float* bias, int relu,
+                        hipStream_t st) {
+    TileMap tm;
+    tm.m_active = nullptr;
+    tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
+    tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
+    hipLaunchKernelGGL((conv1x1_dual_nhwc_kernel<TM, TN, BK>), dim3((unsigned)(tm.tiles_m * tm.tiles_n)), dim3(256), 0, st, t, x, M, w, N, g, y, tm,
+                       bias, relu);
+}
+
 static int g_force_conv_cfg = -1;
 
 }  // namespace isx
@@ -196,6 +332,32 @@ ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, c
         default: launch_conv3x3<1, 1, 32>(x, M, w_ohwi, N, g, y, bias, residual, relu ? 1 : 0, st); break;
     }
     ISX_CHECK_LAUNCH("isx_conv3x3_nhwc");
+    return ISX_OK;
+}
+
+// Last 1x1 convolution of a bottleneck block fused with its 1x1 projection shortcut (see conv1x1_dual_nhwc_kernel).
+ISX_API int isx_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_t B, int H, int W, int K2, int stride, const float* w_cat,
+                                  int Cout, const float* bias, int relu, float* y, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && K1 > 0 && K2 > 0 && Cout > 0 && (stride == 1 || stride == 2),
+                "isx_conv1x1_dual_nhwc: bad shape B=%lld H=%d W=%d K1=%d K2=%d Cout=%d stride=%d", (long long)B, H, W, K1, K2, Cout, stride);
+    ISX_REQUIRE(K1 % 32 == 0 && K2 % 32 == 0, "isx_conv1x1_dual_nhwc: K1=%d and K2=%d must be multiples of 32", K1, K2);
+    ISX_REQUIRE(B * H * W < (1ll << 31), "isx_conv1x1_dual_nhwc: input has too many pixels for 32-bit pixel indices");
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(t && x && w_cat && bias && y, "isx_conv1x1_dual_nhwc: null pointer");
+    ISX_REQUIRE((((uintptr_t)t | (uintptr_t)x | (uintptr_t)w_cat) % 16) == 0, "isx_conv1x1_dual_nhwc: t, x and w must be 16-B aligned");
+    ISX_REQUIRE(y != t && y != x, "isx_conv1x1_dual_nhwc: y must not alias an input");
+    DualGeom g;
+    g.H = H; g.W = W; g.stride = stride; g.K1 = K1; g.K2 = K2;
+    g.Ho = (H - 1) / stride + 1;
+    g.Wo = (W - 1) / stride + 1;
+    const int64_t M = B * g.Ho * g.Wo, N = Cout;
+    ISX_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), "isx_conv1x1_dual_nhwc: too many tiles");
+    int best = (M > 131072 && N >= 64) ? 2 : 3;
+    if (g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
+    hipStream_t st = (hipStream_t)stream;
+    if (best == 2) launch_dual<2, 1, 32>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);
+    else launch_dual<1, 1, 32>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);
+    ISX_CHECK_LAUNCH("isx_conv1x1_dual_nhwc");
     return ISX_OK;
 }
 

@@ -154,6 +154,29 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True):
     return y
 
 
+def conv1x1_dual_nhwc(t, x, w_cat, bias, stride=1, relu=True):
+    """act(conv1x1(t, w_cat[:, :K1]) + conv1x1(x[:, :, ::stride, ::stride], w_cat[:, K1:]) + bias) in one GEMM: the last
+    convolution of a bottleneck block fused with its projection shortcut.  t: (B,K1,Ho,Wo), x: (B,K2,H,W), both channels-last."""
+    for a, n in ((t, "t"), (x, "x")):
+        if not (a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last)):
+            raise _lib.IsxError(n + " must be a channels-last float32 CUDA tensor (B,C,H,W)")
+    B, K2, H, W = x.shape
+    K1 = t.shape[1]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if tuple(t.shape) != (B, K1, Ho, Wo):
+        raise _lib.IsxError("t must be (B, K1, Ho, Wo) for x's shape and the stride")
+    w = _f32(w_cat, "w_cat")
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, K1 + K2):
+        raise _lib.IsxError("w_cat must be (Cout, K1 + K2)")
+    y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    bp, px = _f32(bias, "bias").data_ptr(), B * Ho * Wo
+    _timed("isx_conv1x1_nhwc", 2.0 * px * (K1 + K2) * Cout, 4.0 * (px * (K1 + K2) + px * Cout + (K1 + K2) * Cout),
+           lambda: check(lib().isx_conv1x1_dual_nhwc(t.data_ptr(), K1, x.data_ptr(), B, H, W, K2, stride, w.data_ptr(), Cout, bp,
+                                                     1 if relu else 0, y.data_ptr(), _stream()), "isx_conv1x1_dual_nhwc"))
+    return y
+
+
 def conv3x3_nhwc(x, w_ohwi, bias, stride=1, residual=None, relu=True):
     """3x3 convolution (padding 1, stride 1|2) of a channels-last (B,Cin,H,W) fp32 tensor, epilogue fused.
     w_ohwi: (Cout,3,3,Cin) contiguous (= conv.weight.permute(0,2,3,1)).  Returns channels-last (B,Cout,Ho,Wo)."""

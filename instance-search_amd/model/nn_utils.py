@@ -80,6 +80,7 @@ def extract_layers(net):
 _CONV3X3_MODE = os.environ.get("ISX_CONV3X3", "auto")
 _IMPLICIT_GEMM_3X3 = _CONV3X3_MODE != "0"
 _GEMM_1X1 = os.environ.get("ISX_CONV1X1", "1") != "0"
+_FUSE_PROJECTION = os.environ.get("ISX_FUSE_PROJECTION", "1") != "0"     # last 1x1 conv + projection shortcut as one GEMM
 
 
 class _ConvBiasAct(nn.Module):
@@ -184,7 +185,30 @@ class _FusedBlock(nn.Module):
             self.convs[-1].bias = nn.Parameter(self.convs[-1].bias + _ConvBiasAct(downsample, relu=False).bias, requires_grad=False)
             self.downsample = d                                             # projection (its bias lives in the last conv's epilogue)
 
+        self._w_cat = None            # [W_last | W_projection] for the fused last-conv + shortcut GEMM, built on first use
+
+    def _fusable_projection(self, x):
+        last, d = self.convs[-1], self.downsample
+        return (_GEMM_1X1 and _FUSE_PROJECTION and d is not None and last._pointwise() and d.conv.kernel_size == (1, 1) and d.conv.padding == (0, 0)
+                and d.conv.groups == 1 and d.conv.stride in ((1, 1), (2, 2)) and last.conv.in_channels % 32 == 0 and d.conv.in_channels % 32 == 0
+                and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.dim() == 4
+                and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
+
     def forward(self, x):
+        if self._fusable_projection(x):
+            # relu(conv_last(t) + projection(x) + bias) as ONE GEMM over [t ; x_strided] (libisx isx_conv1x1_dual_nhwc):
+            # the shortcut tensor is never materialised
+            from isx import ops
+            last, d = self.convs[-1], self.downsample
+            if self._w_cat is None or self._w_cat.device != x.device:
+                co = last.conv.out_channels
+                self._w_cat = torch.cat([last.conv.weight.detach().reshape(co, -1), d.conv.weight.detach().reshape(co, -1)], 1).contiguous()
+            t = x
+            for c in self.convs[:-1]:
+                t = c(t)
+            if not t.is_contiguous(memory_format=torch.channels_last):
+                t = t.contiguous(memory_format=torch.channels_last)
+            return ops.conv1x1_dual_nhwc(t, x, self._w_cat, last.bias, d.conv.stride[0], last.relu)
         idt = x if self.downsample is None else self.downsample(x)
         y = x
         for c in self.convs[:-1]:

@@ -248,6 +248,28 @@ ISXO_API void isxo_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float*
         }
 }
 
+/* conv3 + 1x1 projection shortcut of a bottleneck block as one fma chain per output: t's K1 channels, then the K2 channels
+ * of the strided block input (torchvision Bottleneck: out = conv3(t) + downsample(x), BN folded, then ReLU). */
+ISXO_API void isxo_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_t B, int H, int W, int K2, int stride,
+                                     const float* w, int Cout, const float* bias, int relu, float* y) {
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    for (int64_t b = 0; b < B; ++b)
+        for (int ho = 0; ho < Ho; ++ho)
+            for (int wo = 0; wo < Wo; ++wo) {
+                const int64_t m = (b * Ho + ho) * Wo + wo;
+                const float* tp = t + m * K1;
+                const float* xp = x + ((b * H + (int64_t)ho * stride) * W + (int64_t)wo * stride) * K2;
+                for (int co = 0; co < Cout; ++co) {
+                    const float* wp = w + (int64_t)co * (K1 + K2);
+                    float acc = 0.0f;
+                    for (int c = 0; c < K1; ++c) acc = fmaf(tp[c], wp[c], acc);
+                    for (int c = 0; c < K2; ++c) acc = fmaf(xp[c], wp[K1 + c], acc);
+                    const float v = acc + bias[co];
+                    y[m * Cout + co] = relu ? fmaxf(v, 0.0f) : v;
+                }
+            }
+}
+
 /* 3x3 convolution, padding 1, stride 1|2, NHWC, weights (Cout,3,3,Cin), folded-BN epilogue (conv2 of the torchvision
  * Bottleneck / BasicBlock convolutions inside `features`): fma chain over (kh, kw, ci) in that order; padding taps
  * contribute fma(0, w, acc). */

@@ -130,6 +130,18 @@ def conv1x1_nhwc(x, w, bias, res=None, relu=True):
     return y
 
 
+def conv1x1_dual_nhwc(t, x, w_cat, bias, stride=1, relu=True):
+    """t: (B,Ho,Wo,K1), x: (B,H,W,K2), w_cat: (Cout, K1+K2) -> (B,Ho,Wo,Cout)."""
+    t = _f32(t); x = _f32(x); w = _f32(w_cat); bias = _f32(bias)
+    B, H, W, K2 = x.shape; K1 = t.shape[3]; Cout = w.shape[0]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    assert t.shape == (B, Ho, Wo, K1) and w.shape == (Cout, K1 + K2)
+    y = np.empty((B, Ho, Wo, Cout), np.float32)
+    lib().isxo_conv1x1_dual_nhwc(_p(t, F32P), K1, _p(x, F32P), C.c_int64(B), H, W, K2, stride, _p(w, F32P), Cout, _p(bias, F32P),
+                                 1 if relu else 0, _p(y, F32P))
+    return y
+
+
 def conv3x3_nhwc(x, w_ohwi, bias, stride=1, res=None, relu=True):
     """x: (B,H,W,Cin), w_ohwi: (Cout,3,3,Cin), res: (B,Ho,Wo,Cout) or None -> (B,Ho,Wo,Cout); padding 1."""
     x = _f32(x); w = _f32(w_ohwi); bias = _f32(bias); B, H, W, Cin = x.shape; Cout = w.shape[0]

@@ -486,3 +486,31 @@ def test_stage_batch_raw_ingest(ops):
         TC.RAW_INGEST["mean"] = TC.RAW_INGEST["std"] = None
     assert g.is_cuda and g.shape == (5, 3, 32, 48) and g.is_contiguous(memory_format=torch.channels_last)
     np.testing.assert_array_equal(host(g), c.numpy())
+
+
+@pytest.mark.parametrize("B,H,W,K1,K2,Cout,stride", [(1, 2, 2, 32, 32, 32, 1), (2, 8, 6, 64, 64, 256, 1), (2, 9, 7, 128, 256, 512, 2),
+                                                     (3, 5, 5, 32, 96, 130, 2), (1, 14, 14, 256, 512, 1024, 2), (2, 1, 1, 64, 32, 64, 1)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_conv1x1_dual_nhwc(ops, B, H, W, K1, K2, Cout, stride, relu):
+    from isx._lib import lib
+    rng = np.random.default_rng(H * 10 + K1 + stride)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    t = np.maximum(rng.standard_normal((B, Ho, Wo, K1), dtype=np.float32), 0)
+    x = np.maximum(rng.standard_normal((B, H, W, K2), dtype=np.float32), 0)
+    w = rng.standard_normal((Cout, K1 + K2), dtype=np.float32) * np.float32((K1 + K2) ** -0.5)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    want = O.conv1x1_dual_nhwc(t, x, w, b, stride, relu)
+    tt, xt = dev(t).permute(0, 3, 1, 2), dev(x).permute(0, 3, 1, 2)
+    set_cfg = lib().isx_debug_set_conv_cfg
+    try:
+        for cfg in (-1, 2, 3):
+            set_cfg(cfg)
+            got = host(ops.conv1x1_dual_nhwc(tt, xt, dev(w), dev(b), stride, relu).permute(0, 2, 3, 1))
+            np.testing.assert_array_equal(got, want)
+    finally:
+        set_cfg(-1)
+    F = torch.nn.functional
+    ref = F.conv2d(tt, dev(w[:, :K1]).reshape(Cout, K1, 1, 1)) + F.conv2d(xt, dev(w[:, K1:]).reshape(Cout, K2, 1, 1), stride=stride) + dev(b).view(1, -1, 1, 1)
+    if relu:
+        ref = torch.relu(ref)
+    np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1)), rtol=1e-4, atol=1e-4)

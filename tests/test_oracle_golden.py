@@ -187,9 +187,15 @@ def test_trunk_block(golden):
         t = O.conv1x1_nhwc(y.reshape(-1, C), f[0][0].reshape(f[0][0].shape[0], -1), f[0][1], None, True).reshape(B, H, W, -1)
         t = O.conv3x3_nhwc(t, np.ascontiguousarray(f[1][0].transpose(0, 2, 3, 1)), f[1][1], stride, None, True)
         Bo, Ho, Wo, Cm = t.shape
+        y_in = y
         y = O.conv1x1_nhwc(t.reshape(-1, Cm), f[2][0].reshape(f[2][0].shape[0], -1), bias3, idt.reshape(-1, idt.shape[-1]), True)
         y = y.reshape(Bo, Ho, Wo, -1)
         np.testing.assert_allclose(y.transpose(0, 3, 1, 2), g["y%d" % blk], rtol=2e-5, atol=2e-5)
+        if "b%d_dw" % blk in g:
+            # the fused form (last convolution and projection shortcut as one fma chain over [t ; x_strided])
+            w_cat = np.concatenate([f[2][0].reshape(f[2][0].shape[0], -1), dw.reshape(dw.shape[0], -1)], axis=1)
+            y2 = O.conv1x1_dual_nhwc(t, y_in, w_cat, bias3, stride, True)
+            np.testing.assert_allclose(y2.transpose(0, 3, 1, 2), g["y%d" % blk], rtol=2e-5, atol=2e-5)
 
 
 def test_images_u8_to_f32_matches_torch():
