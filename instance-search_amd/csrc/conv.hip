@@ -352,10 +352,13 @@ ISX_API int isx_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_
     g.Wo = (W - 1) / stride + 1;
     const int64_t M = B * g.Ho * g.Wo, N = Cout;
     ISX_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), "isx_conv1x1_dual_nhwc: too many tiles");
-    int best = (M > 131072 && N >= 64) ? 2 : 3;
-    if (g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
+    // measured at B = 1024 (ms, 128x128 / 128x64 / 64x64): layer 1 2.10 / 2.22 / 2.21, layer 2 2.64 / 2.68 / 2.84,
+    // layer 3 2.54 / 2.54 / 2.75, layer 4 (50 k pixels) 2.55 / 2.48 / 2.72
+    int best = (M > 131072 && N >= 128) ? 0 : 2;
+    if (g_force_conv_cfg == 0 || g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
     hipStream_t st = (hipStream_t)stream;
-    if (best == 2) launch_dual<2, 1, 32>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);
+    if (best == 0) launch_dual<2, 2, 16>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);
+    else if (best == 2) launch_dual<2, 1, 32>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);
     else launch_dual<1, 1, 32>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);
     ISX_CHECK_LAUNCH("isx_conv1x1_dual_nhwc");
     return ISX_OK;

@@ -503,7 +503,7 @@ def test_conv1x1_dual_nhwc(ops, B, H, W, K1, K2, Cout, stride, relu):
     tt, xt = dev(t).permute(0, 3, 1, 2), dev(x).permute(0, 3, 1, 2)
     set_cfg = lib().isx_debug_set_conv_cfg
     try:
-        for cfg in (-1, 2, 3):
+        for cfg in (-1, 0, 2, 3):
             set_cfg(cfg)
             got = host(ops.conv1x1_dual_nhwc(tt, xt, dev(w), dev(b), stride, relu).permute(0, 2, 3, 1))
             np.testing.assert_array_equal(got, want)
