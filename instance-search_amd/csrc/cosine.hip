@@ -297,12 +297,14 @@ int run_topk_chunks(const TopkJob& j) {
     while (nc > min_nc && topk_chunk_bytes(M, nc) > j.ws_bytes - fixed_b) nc -= (nc > 4096 ? 1024 : 128);
     if (nc < N) nc = nc >= 128 ? nc / 128 * 128 : nc;
     if (nc < N && nc >= 4096) {
-        // a chunk launch runs ceil(tiles / 512) lock-step rounds of 128x128 tiles: trim the width (by at
-        // most 16 tiles) so that the last round is >= 90 % full
-        const int64_t tm_ = (M + 127) / 128;
-        for (int64_t tn = nc / 128, tries = 0; tries < 16 && tn > 16; --tn, ++tries) {
-            const int64_t rem = (tm_ * tn) % 512;
-            if (rem == 0 || rem >= 460) { nc = tn * 128; break; }
+        // a chunk launch runs ceil(tiles / slots) lock-step rounds of tiles (fp32: 128x128, 512 resident at the
+        // filter kernel's 2 workgroups per CU ... measured best with 512; fp16: 256x256, one per CU): trim the width
+        // (by at most 16 tiles) so that the last round is >= 90 % full
+        const int64_t tile = j.Qh ? 256 : 128, slots = j.Qh ? 256 : 512;
+        const int64_t tm_ = (M + tile - 1) / tile;
+        for (int64_t tn = nc / tile, tries = 0; tries < 16 && tn > 16; --tn, ++tries) {
+            const int64_t rem = (tm_ * tn) % slots;
+            if (rem == 0 || rem >= slots * 9 / 10) { nc = tn * tile; break; }
         }
     }
     uint64_t* carry = (uint64_t*)j.ws;
