@@ -19,9 +19,14 @@ from .custom_modules import NormalizeL2, Shift
 from .nn_utils import convolutionalize, extract_layers, get_feature_size, set_untrained_blocks
 
 
-def _fast(x):
-    """HIP path: GPU tensor, inference."""
-    return x.is_cuda and not (torch.is_grad_enabled() and x.requires_grad)
+def _fast(x, trainable=None):
+    """HIP path: GPU tensor and no autograd graph needed -- neither through x nor (while gradients are being recorded)
+    into the parameters of `trainable`, the module about to consume x (its fast path reads them detached)."""
+    if not x.is_cuda:
+        return False
+    if not torch.is_grad_enabled():
+        return True
+    return not x.requires_grad and not (trainable is not None and any(p.requires_grad for p in trainable.parameters()))
 
 
 class BoxPool(nn.AvgPool2d):
@@ -94,13 +99,51 @@ class TuneClassifSub(TuneClassif):
         return [self.forward_single(x) for x in scales]
 
 
+def _frozen(module):
+    return not any(p.requires_grad for p in module.parameters())
+
+
+class _FrozenTrunk(object):
+    """Siamese training with a fully frozen backbone (untrained = -1, the reference's default): the trunk needs no
+    autograd graph, so it runs as the BN-folded inference trunk with the hand-written convolution kernels
+    (model/nn_utils.fold_batch_norm), built once -- frozen weights cannot change under it."""
+
+    def __init__(self):
+        self.folded = None
+        self.key = None
+
+    def __call__(self, features, x):
+        if not (x.is_cuda and x.dtype == torch.float32 and _frozen(features)):
+            return features(x)
+        if any(isinstance(m, nn.BatchNorm2d) and m.training for m in features.modules()):
+            return features(x)                      # BN statistics are being updated: keep the plain trunk
+        key = (id(features), str(x.device))
+        if self.folded is None or self.key != key:
+            from .nn_utils import fold_batch_norm
+            self.folded = fold_batch_norm(features).to(x.device).to(memory_format=torch.channels_last)
+            self.key = key
+        with torch.no_grad():
+            return self.folded(x.contiguous(memory_format=torch.channels_last))
+
+
+def _many(forward_single, xs):
+    """forward_single over several same-shaped batches in ONE pass (eval-mode BN: samples are independent), split back."""
+    if len(set(tuple(x.shape) for x in xs)) != 1:
+        return tuple(forward_single(x) for x in xs)
+    n = xs[0].size(0)
+    out = forward_single(torch.cat(xs, 0))
+    if isinstance(out, tuple):
+        return tuple(tuple(o[i * n:(i + 1) * n] for o in out) for i in range(len(xs)))
+    return tuple(out[i * n:(i + 1) * n] for i in range(len(xs)))
+
+
 def _descriptor_head(in_features, out_features):
     return nn.Sequential(NormalizeL2(), Shift(in_features), nn.Linear(in_features, out_features))
 
 
 def _apply_head(head, rows):
     """feature_reduc1 on (R, F) rows: NormalizeL2 -> Shift -> Linear; fused prologue on the GPU."""
-    if _fast(rows):
+    if _fast(rows, head):
         from isx import ops
         lin = head[2]
         return F.linear(ops.l2norm_shift_rows(rows.float(), head[1].param.detach()), lin.weight, lin.bias)
@@ -116,17 +159,20 @@ class DescriptorNet(nn.Module):
         self.feature_size = feature_dim if feature_dim > 0 else get_feature_size(classifier)
         self.feature_reduc1 = _descriptor_head(in_features, self.feature_size)
         self.feature_reduc2 = NormalizeL2()
+        self._trunk = _FrozenTrunk()
 
     def forward_single(self, x):
-        x = self.features(x)
+        x = self._trunk(self.features, x) if self.training else self.features(x)
         x = x.reshape(x.size(0), -1)
         return self.feature_reduc2(_apply_head(self.feature_reduc1, x))
 
     def forward(self, x1, x2=None, x3=None):
+        # the reference runs one trunk pass per branch (model/siamese.py:124-130); the branches share the weights and
+        # BN is in eval mode, so they go through together here
         if self.training and x3 is not None:
-            return self.forward_single(x1), self.forward_single(x2), self.forward_single(x3)
+            return _many(self.forward_single, [x1, x2, x3])
         if self.training:
-            return self.forward_single(x1), self.forward_single(x2)
+            return _many(self.forward_single, [x1, x2])
         return self.forward_single(x1)
 
 
@@ -153,7 +199,7 @@ class RegionDescriptorNet(nn.Module):
         kh, kw = self.feature_size2d
         n_loc = c.size(2) * c.size(3)
         k = min(n_loc, self.k)
-        if _fast(x):
+        if _fast(x, self.feature_reduc1):
             from isx import ops
             flat_idx, _ = ops.region_topk(c[0].float(), k)
             rows = ops.region_gather_l2(x[0].float(), kh, kw, flat_idx, c.size(3), self.feature_reduc1[1].param.detach())
@@ -193,7 +239,7 @@ class RegionDescriptorNet(nn.Module):
         # images goes through together on the GPU, and image by image on the autograd / CPU path
         x = self.features(x)
         c = self.classifier(self.feature_reduc(x))
-        if _fast(x):
+        if _fast(x, self.feature_reduc1) and not c.requires_grad:
             return self._batched_gpu(x, c)
         outs = [self._single_image(x[b:b + 1], c[b:b + 1]) for b in range(x.size(0))]
         return torch.cat([o[0] for o in outs], 0), torch.cat([o[1] for o in outs], 0)

@@ -7,7 +7,7 @@ import torch.nn as nn
 from model.custom_modules import l2_normalize_rows
 from model.siamese import TuneClassif
 from utils import fold_batches, move_device, tensor
-from ._common import base_model, load_weights, stage_batch, test_transform
+from ._common import base_model, load_weights, make_resident, stage_batch, test_transform
 from .classif_finetune_p import P
 
 labels = []   # filled by the entry point once the reference set is listed, then constant
@@ -43,6 +43,8 @@ def get_embeddings(net, dataset, device, out_size):
     pass, restored afterwards); True: the class scores.  On the GPU the pool + L2 of a batch is
     one fused kernel (`isx_gap_l2`) writing straight into the slab rows."""
     trans = test_transform(P)
+    if trans is None:
+        make_resident(dataset, P.cuda_device)           # the set goes to HBM once; batches are device-side row gathers
     stripped = not P.embeddings_classify
     if stripped:
         classifier, net.classifier = net.classifier, nn.Sequential()

@@ -13,7 +13,7 @@ from model.siamese import DescriptorNet, TuneClassif
 from model.custom_modules import TripletLoss
 from utils import (choose_rand_neg, embeddings_device_dim, fold_batches, get_pos_couples, get_similarities, log, move_device,
                    tensor, test_print_descriptor, train_gen)
-from ._common import base_model, load_weights, stage_batch, test_transform
+from ._common import base_model, load_weights, make_resident, stage_batch, stage_images, test_transform
 from .siamese_descriptor_p import P
 
 labels = []
@@ -22,6 +22,8 @@ labels = []
 def get_embeddings(net, dataset, device, out_size):
     trans = test_transform(P)
     slab = tensor(device, len(dataset), out_size)
+    if trans is None:
+        make_resident(dataset, P.cuda_device)
 
     def run(slab, i, is_final, batch):
         with torch.no_grad():
@@ -74,6 +76,8 @@ def mine_epoch_negatives(similarities, dataset, couples_list, semi_hard):
 
 def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, optimizer, best_score=0):
     trans = None if P.train_pre_proc else P.train_trans
+    if trans is None:
+        make_resident(train_set, P.cuda_device)          # batches become row gathers on the device
     couples = get_pos_couples(train_set)
     log(P, '#pos (without order, with duplicates):{0}'.format(sum(len(c) for c in couples.values())))
 
@@ -89,12 +93,11 @@ def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, op
 
     def create_batch(batch, n, epoch):
         prep = (lambda im: im) if trans is None else trans
-        a = torch.stack([prep(im1) for _, _, (im1, _), _ in batch])
-        p = torch.stack([prep(im2) for _, _, (_, im2), _ in batch])
-        ng = torch.stack([prep(train_set[k][0] if k >= 0 else choose_rand_neg(train_set, lab)) for lab, _, _, k in batch])
+        a = stage_images([prep(im1) for _, _, (im1, _), _ in batch], P.cuda_device)
+        p = stage_images([prep(im2) for _, _, (_, im2), _ in batch], P.cuda_device)
+        ng = stage_images([prep(train_set[k][0] if k >= 0 else choose_rand_neg(train_set, lab)) for lab, _, _, k in batch], P.cuda_device)
         lab_ids = torch.tensor([labels.index(lab) for lab, _, _, _ in batch], dtype=torch.int64)
-        mv = lambda t: move_device(t, P.cuda_device)
-        return [mv(a), mv(p), mv(ng)], [mv(lab_ids)]
+        return [a, p, ng], [move_device(lab_ids, P.cuda_device)]
 
     def create_loss(out, labels_list):
         return criterion(*out), None
