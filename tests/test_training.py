@@ -246,3 +246,62 @@ def test_training_epoch_on_gpu_reduces_loss():
     te = synthetic_image_set(8, 4, seed=2)
     net, score = sd.main(tr, tr, te)
     assert next(net.parameters()).is_cuda and score >= 0
+
+
+def test_siamese_branches_share_one_trunk_pass():
+    """forward(x1, x2, x3) in training mode == three forward_single calls (eval-mode BN: samples are independent)."""
+    from isx import backbones
+    from model.siamese import DescriptorNet, TuneClassif
+    torch.manual_seed(0)
+    net = DescriptorNet(TuneClassif(backbones.alexnet(pretrained=True, seed=0), 5), 16, (6, 6), untrained=-1)
+    net.train()
+    xs = [torch.randn(2, 3, 224, 224) for _ in range(3)]
+    a, p, n = net(*xs)
+    for got, x in zip((a, p, n), xs):
+        torch.testing.assert_close(got, net.forward_single(x), rtol=1e-5, atol=1e-6)
+    a2, p2 = net(xs[0], xs[1])
+    torch.testing.assert_close(a2, a, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_resident_images_and_frozen_trunk_training_step():
+    """Device-resident datasets gather exactly the staged batch; behind a frozen trunk the head's Shift parameter and
+    Linear both receive gradients (the fused inference head must not be used while they train)."""
+    from isx import backbones
+    from model.custom_modules import TripletLoss
+    from model.siamese import DescriptorNet, TuneClassif
+    from train import _common as TC
+    g = torch.Generator().manual_seed(4)
+    ds = [(torch.randn(3, 224, 224, generator=g), "l%d" % (i % 3), "p%d" % i) for i in range(12)]
+    raw = [(torch.randint(0, 256, (40, 30, 3), generator=g, dtype=torch.uint8), "a", "r%d" % i) for i in range(6)]
+    TC.drop_resident()
+    try:
+        batch = [ds[i] for i in (5, 0, 7, 7, 2)]
+        want = TC.stage_batch(batch, None, 0)                       # stack + H2D
+        assert TC.make_resident(ds, 0) is not None
+        got = TC.stage_batch(batch, None, 0)                        # device-side row gather
+        assert torch.equal(got, want)
+        TC.RAW_INGEST["mean"], TC.RAW_INGEST["std"] = [0.4, 0.5, 0.6], [0.2, 0.25, 0.3]
+        want_raw = TC.stage_batch(raw[:4], None, 0)
+        TC.make_resident(raw, 0)
+        assert torch.equal(TC.stage_batch(raw[:4], None, 0), want_raw)
+    finally:
+        TC.drop_resident()
+        TC.RAW_INGEST["mean"] = TC.RAW_INGEST["std"] = None
+    torch.manual_seed(0)
+    net = DescriptorNet(TuneClassif(backbones.resnet18(pretrained=True, seed=0), 5), 32, (7, 7), untrained=-1).cuda()
+    net.train()
+    for m in net.features.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    xs = [torch.randn(4, 3, 224, 224, device="cuda") for _ in range(3)]
+    a, p, n = net(*xs)
+    TripletLoss(0.1, False, True)(a, p, n).backward()
+    shift, lin = net.feature_reduc1[1], net.feature_reduc1[2]
+    assert shift.param.grad is not None and float(shift.param.grad.abs().sum()) > 0
+    assert lin.weight.grad is not None and float(lin.weight.grad.abs().sum()) > 0
+    # the frozen trunk went through the folded inference kernels: same descriptors as the plain trunk within fp32 noise
+    net._trunk.folded = None
+    ref = net.forward_single(xs[0])
+    plain = net.feature_reduc2(net.feature_reduc1(net.features(xs[0]).reshape(4, -1)))
+    torch.testing.assert_close(ref, plain, rtol=1e-4, atol=1e-5)
