@@ -6,7 +6,7 @@ import torch
 from model.custom_modules import l2_normalize_rows
 from model.siamese import TuneClassif, TuneClassifSub
 from utils import fold_batches, move_device, tensor
-from ._common import base_model, load_weights, stage_batch, test_transform
+from ._common import base_model, load_weights, make_resident, stage_batch, test_transform
 from .classif_regions_p import P
 
 labels = []
@@ -46,6 +46,8 @@ def test_classif_net(net, test_set):
 
 def get_embeddings(net, dataset, device, out_size):
     trans = test_transform(P)
+    if trans is None:
+        make_resident(dataset, P.cuda_device)
     slab = tensor(device, len(dataset), out_size)
 
     def run(slab, i, is_final, batch):

@@ -10,7 +10,7 @@ from model.siamese import RegionDescriptorNet, TuneClassifSub
 from model.custom_modules import TripletLoss
 from utils import (choose_rand_neg, fold_batches, get_pos_couples, get_similarities, log, move_device, tensor,
                    test_print_descriptor, train_gen)
-from ._common import base_model, load_weights, stage_batch, test_transform
+from ._common import base_model, load_weights, make_resident, stage_batch, test_transform
 from .siamese_descriptor import mine_epoch_negatives, shuffle_couples
 from .siamese_regions_p import P
 
@@ -19,6 +19,8 @@ labels = []
 
 def get_embeddings(net, dataset, device, out_size):
     trans = test_transform(P)
+    if trans is None:
+        make_resident(dataset, P.cuda_device)
     slab = tensor(device, len(dataset), out_size)
 
     def run(slab, i, is_final, batch):
