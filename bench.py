@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
 
@@ -244,6 +245,8 @@ def main():
         flop = 2.0 * Ms * Ns * world * D
         shard_result = {"shape": [Ms, Ns * world, D], "gallery_rows_per_gpu": Ns, "k": k, "ms": ms,
                         "dist_per_s": Ms * Ns * world / (ms * 1e-3),
+                        "tflops_end_to_end": flop / (ms * 1e-3) / 1e12,
+                        "frac_of_f16_mfma_peak": flop / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS * world),
                         "path": "isx_cosine_topk_fast (fp16-MFMA filter + exact fp32 re-scoring, bit-identical results)",
                         "fp32_path": {"ms": ms32, "dist_per_s": Ms * Ns * world / (ms32 * 1e-3),
                                       "tflops_end_to_end": flop / (ms32 * 1e-3) / 1e12,
