@@ -208,3 +208,36 @@ def test_sharded_gallery_fast_equals_fp32(ops):
     a = ShardedGallery(G, 1000, fast=False).search(Q, 20)
     b = ShardedGallery(G, 1000, fast=True).search(Q, 20)
     assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32))
+
+
+def test_randomised_shapes_fast_equals_fp32(ops):
+    """40 random (M, N, D, k, workspace, clustering) configurations: the fast path and the all-fp32 path return the same bits."""
+    rng = np.random.default_rng(2026)
+    g = torch.Generator(device="cuda").manual_seed(77)
+    for trial in range(40):
+        M = int(rng.integers(1, 700))
+        N = int(rng.integers(300, 60000))
+        D = int(rng.choice([8, 24, 64, 128, 200, 512, 1000]))
+        k = int(rng.integers(1, 129))
+        Q = torch.randn(M, D, device="cuda", generator=g)
+        G = torch.randn(N, D, device="cuda", generator=g)
+        mode = trial % 4
+        if mode == 1:                                   # near-duplicate gallery rows: dense score clusters
+            G = G[torch.randint(0, max(2, N // 50), (N,), device="cuda", generator=g)] + 1e-4 * torch.randn(N, D, device="cuda", generator=g)
+        elif mode == 2:                                 # non-negative descriptors
+            Q, G = Q.relu(), G.relu() + 1e-3
+        elif mode == 3:                                 # exact duplicates
+            G[N // 2:] = G[:N - N // 2].clone()
+        Q, G = ops.l2norm_rows(Q), ops.l2norm_rows(G)
+        idx_base = int(rng.integers(0, 1000))
+        ref = ops.cosine_topk(Q, G, k, idx_base=idx_base)
+        need = ops.cosine_topk_fast_workspace(M, N, D, k, trial % 2 == 0)
+        ws = torch.empty((need if trial % 3 else max(need // 2, 1 << 20),), dtype=torch.uint8, device="cuda")
+        gh = ops.gallery_to_f16(G) if trial % 2 == 0 else None
+        try:
+            got = ops.cosine_topk_fast(Q, G, k, idx_base=idx_base, gallery_f16=gh, ws=ws)
+        except Exception as e:                          # a halved workspace may be below the documented minimum: that must be an error, not a wrong answer
+            assert "workspace" in str(e) and trial % 3 == 0
+            continue
+        assert torch.equal(ref[1], got[1]), (trial, M, N, D, k, mode)
+        assert torch.equal(ref[0].view(torch.int32), got[0].view(torch.int32)), (trial, M, N, D, k, mode)
