@@ -338,12 +338,12 @@ int run_topk_chunks(const TopkJob& j) {
                 isx_set_error("%s: hipMemsetAsync failed", j.who);
                 return ISX_ERR_HIP;
             }
-            rc = launch_select_groups(chunk, nullptr /* all groups present */, M, w, w, c0, k, carry, thr, emit, j.idx_base, j.top_score,
+            rc = launch_select_groups(chunk, nullptr /* all groups present */, M, w, w, c0, k, carry, thr, emit ? 1 : (last ? 2 : 0), j.idx_base, j.top_score,
                                       j.top_idx, st, j.m_active, j.row_map);
         } else {
             rc = gemm(c0, w, thr, gflag);
             if (rc) return rc;
-            rc = launch_select_groups(chunk, gflag, M, w, w, c0, k, carry, thr, emit, j.idx_base, j.top_score, j.top_idx, st, j.m_active,
+            rc = launch_select_groups(chunk, gflag, M, w, w, c0, k, carry, thr, emit ? 1 : (last ? 2 : 0), j.idx_base, j.top_score, j.top_idx, st, j.m_active,
                                       j.row_map);
         }
         if (rc) return rc;

@@ -34,8 +34,9 @@ int launch_select(const float* sim, int64_t M, int64_t Nc, int64_t ld, int64_t c
 // Running top-k update from a FILTERED chunk: only the flagged 32-column groups are read from sim.  k <= kGroupSelectMaxK.  Updates carry and thr
 // (thr[row] = score of the k-th key, -inf while fewer than k).
 int launch_select_groups(const float* sim, const uint8_t* gflag, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
-                         uint64_t* carry, float* thr, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx,
+                         uint64_t* carry, float* thr, int mode, int64_t idx_base, float* top_score, int64_t* top_idx,
                          hipStream_t st, const int* m_active = nullptr, const int* row_map = nullptr);
+// mode 0: intermediate chunk (carry unsorted, k-th largest key in slot k-1), 1: last chunk, emit sorted lists, 2: last chunk, sorted carry.
 // m_active / row_map (optional, device): only rows < *m_active are processed and row r emits to output row row_map[r].
 
 constexpr int kGroupSelectMaxK = 256;

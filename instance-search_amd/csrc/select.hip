@@ -119,67 +119,125 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
 constexpr int GS_NEW = 512;                        // capacity of the unsorted run
 constexpr int GS_BUF = kGroupSelectMaxK + GS_NEW;  // 768 keys = 6 KB
 
-// count of entries greater than key in run[0, n) (n a power of two or 0; sorted descending; zeros last)
-__device__ __forceinline__ int count_greater(const uint64_t* run, int n, uint64_t key) {
-    int lo = 0;
-    for (int step = n >> 1; step > 0; step >>= 1)
-        if (run[lo + step - 1] > key) lo += step;
-    if (n > 0 && lo < n && run[lo] > key) ++lo;
-    return lo;
+// ---- flush: keep the k largest of the n = cnt keys in buf, by RADIX SELECT (no sort) -----------------------
+// The list is kept UNSORTED between flushes; only its k-th largest key T (the admission threshold) is needed.
+// T is found most-significant byte first: a 256-bin LDS histogram of the current byte over the keys that still match
+// the prefix, a suffix scan for the bin that holds the rank-k key, repeat on the next byte; bytes on which all keys
+// agree are skipped (wave AND / OR), and the search stops as soon as the bin holds one key.  Survivors (key >= T) are
+// compacted to buf[0, k) with ballot prefix sums.  ~1 k wave instructions per flush, where sorting the new run and
+// rank-merging it cost ~3.4 k: the bitonic networks were instruction-bound.  One sort of the k keys remains,
+// at the end of the kernel.
+constexpr int GS_R = GS_BUF / 64;                  // keys per lane held in registers during a flush (12)
+
+__device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, s, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), s, 64);
+        v |= ((uint64_t)hi << 32) | lo;
+    }
+    return v;
 }
 
-// Returns with cnt == k, buf[0,k) sorted.  Uniform control flow; all 64 lanes call it.
-__device__ __forceinline__ void gs_flush(uint64_t* buf, int k, int kp2, int cnt, int lane) {
-    const int m = cnt - k;
-    if (m <= 0) return;
-    int P = 64;
-    while (P < m) P <<= 1;
-    uint64_t* B = buf + k;
-    for (int i = m + lane; i < P; i += 64) B[i] = 0ull;
-    bitonic_sort_desc<64>(B, P);                   // starts and ends with a barrier
-    // ranks: list entry i moves down by the number of new keys above it, new key t by the number of
-    // list entries above it (all keys are distinct: a column is scored once)
-    uint64_t ka[kGroupSelectMaxK / 64], kb[GS_NEW / 64];
-    int pa[kGroupSelectMaxK / 64], pb[GS_NEW / 64];
+// Returns the new threshold key (k-th largest; 0 while the list holds fewer than k keys).  cnt > k on entry; on exit
+// buf[0, k) holds the survivors (unsorted, zero padded).  Uniform control flow; all 64 lanes call it.
+__device__ __forceinline__ uint64_t gs_flush(uint64_t* buf, uint32_t* hist, int k, int cnt, int lane) {
+    __syncthreads();                               // appended keys visible
+    uint64_t v[GS_R];
+    uint64_t all_and = ~0ull, all_or = 0ull;
 #pragma unroll
-    for (int r = 0; r < kGroupSelectMaxK / 64; ++r) {
-        const int i = lane + 64 * r;
-        ka[r] = (i < k) ? buf[i] : 0ull;
-        pa[r] = ka[r] ? i + count_greater(B, P, ka[r]) : GS_BUF;
+    for (int r = 0; r < GS_R; ++r) {
+        const int i = r * 64 + lane;
+        v[r] = (i < cnt) ? buf[i] : 0ull;          // slots beyond cnt behave like empty (zero) entries
+        if (r * 64 < cnt) { all_or |= v[r]; all_and &= (i < cnt) ? v[r] : ~0ull; }
     }
+    all_or = wave_or_u64(all_or);
+    all_and = ~wave_or_u64(~all_and);
+    const uint64_t diff = all_and ^ all_or;        // bits on which the keys differ (uniform)
+    uint64_t prefix = 0ull, mask = 0ull, T = 0ull;
+    int want = k;                                  // rank (from the top) still to be located inside the prefix class
+    bool done = false;
+#pragma unroll 1
+    for (int shift = 56; shift >= 0 && !done; shift -= 8) {
+        if (((diff >> shift) & 255ull) == 0ull) {  // every key has the same byte here
+            prefix |= ((all_and >> shift) & 255ull) << shift;
+            mask |= 255ull << shift;
+            continue;
+        }
+        for (int i = lane; i < 256; i += 64) hist[i] = 0u;
+        __syncthreads();
 #pragma unroll
-    for (int r = 0; r < GS_NEW / 64; ++r) {
-        const int t = lane + 64 * r;
-        kb[r] = (t < m) ? B[t] : 0ull;
-        pb[r] = GS_BUF;
-        if (r * 64 < m && kb[r]) {
-            // list run: kp2 = next_pow2(k) entries are addressable (entries in [k, kp2) belong to B: mask them)
-            int lo = 0;
-            for (int step = kp2 >> 1; step > 0; step >>= 1) {
-                const int j = lo + step - 1;
-                if (j < k && buf[j] > kb[r]) lo += step;
-            }
-            if (lo < k && buf[lo] > kb[r]) ++lo;
-            pb[r] = t + lo;
+        for (int r = 0; r < GS_R; ++r)
+            if (r * 64 + lane < cnt && (v[r] & mask) == prefix) atomicAdd(&hist[(unsigned)(v[r] >> shift) & 255u], 1u);
+        __syncthreads();
+        // lane l owns bins 4l .. 4l+3; suffix sums from bin 255 downwards
+        const uint4 c = reinterpret_cast<const uint4*>(hist)[lane];
+        const int lane_sum = (int)(c.x + c.y + c.z + c.w);
+        int total;
+        const int below_incl = wave_excl_prefix(lane_sum, lane, total) + lane_sum;     // bins of lanes <= lane
+        int cum = total - below_incl;                                                  // keys in bins of higher lanes
+        const int cj[4] = {(int)c.x, (int)c.y, (int)c.z, (int)c.w};
+        int digit = -1, above = 0, inbin = 0;
+#pragma unroll
+        for (int j = 3; j >= 0; --j) {
+            if (digit < 0 && cum < want && cum + cj[j] >= want) { digit = 4 * lane + j; above = cum; inbin = cj[j]; }
+            cum += cj[j];
+        }
+        const unsigned long long who = __ballot(digit >= 0);
+        if (who == 0ull) {                         // want > number of keys in the class: cannot happen (cnt > k)
+            T = 0ull;
+            done = true;
+            break;
+        }
+        const int src = __ffsll((long long)who) - 1;
+        digit = __shfl(digit, src, 64);
+        above = __shfl(above, src, 64);
+        inbin = __shfl(inbin, src, 64);
+        want -= above;
+        prefix |= (uint64_t)digit << shift;
+        mask |= 255ull << shift;
+        if (inbin == 1) {                          // a single key left in the class: it is T
+            uint64_t f = 0ull;
+#pragma unroll
+            for (int r = 0; r < GS_R; ++r)
+                if (r * 64 + lane < cnt && (v[r] & mask) == prefix) f |= v[r];
+            T = wave_or_u64(f);
+            done = true;
+        }
+    }
+    if (!done) T = prefix;                         // all eight bytes fixed
+    // compaction: the non-empty keys >= T (distinct keys: exactly k of them when T != 0)
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < GS_R; ++r) {
+        if (r * 64 < cnt) {                        // uniform
+            const bool keep = (v[r] != 0ull) && (v[r] >= T);
+            const unsigned long long km = __ballot(keep);
+            if (keep) buf[base + __popcll(km & ((1ull << lane) - 1ull))] = v[r];
+            base += __popcll(km);
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int r = 0; r < kGroupSelectMaxK / 64; ++r)
-        if (pa[r] < k) buf[pa[r]] = ka[r];
-#pragma unroll
-    for (int r = 0; r < GS_NEW / 64; ++r)
-        if (pb[r] < k) buf[pb[r]] = kb[r];
+    for (int i = base + lane; i < k; i += 64) buf[i] = 0ull;
     __syncthreads();
+    if (base < k) return 0ull;                     // list not full yet: slot k-1 is empty (0), everything is admitted
+    // keep the threshold key in slot k-1 (the unsorted carry format: buf[k-1] is always the k-th largest)
+    for (int i = lane; i < k; i += 64)
+        if (buf[i] == T) { buf[i] = buf[k - 1]; buf[k - 1] = T; }      // exactly one lane matches (distinct keys)
+    __syncthreads();
+    return T;
 }
 
 __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restrict__ sim, const uint8_t* __restrict__ gflag,
                                                            int64_t Nc, int64_t ld, int ngrp, uint32_t col_base, int k,
-                                                           uint64_t* __restrict__ carry, float* __restrict__ thr, int emit,
+                                                           uint64_t* __restrict__ carry, float* __restrict__ thr, int mode,
                                                            int64_t idx_base, float* __restrict__ top_score,
                                                            int64_t* __restrict__ top_idx, const int* __restrict__ m_active,
                                                            const int* __restrict__ row_map) {
+    // mode 0: intermediate chunk, the carry stays UNSORTED with the k-th largest key in slot k-1; 1: last chunk, emit the sorted
+    // lists; 2: last chunk, leave the sorted keys in the carry (fast.hip re-scores them)
     __shared__ __attribute__((aligned(16))) uint64_t buf[GS_BUF];
+    __shared__ __attribute__((aligned(16))) uint32_t hist[256];
     const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
     const int64_t row = blockIdx.x;
     if (m_active && row >= *m_active) return;
@@ -198,9 +256,8 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
         const bool vec = ((((uintptr_t)r) & 15) == 0);
         for (int64_t j0 = 0; j0 < Nc; j0 += 256) {
             if (cnt - k > GS_NEW - 256) {              // room for a full step
-                gs_flush(buf, k, kp2, cnt, lane);
+                thr_key = gs_flush(buf, hist, k, cnt, lane);
                 cnt = k;
-                thr_key = buf[k - 1];
             }
             const int64_t j = j0 + (int64_t)lane * 4;
             float vv[4];
@@ -233,9 +290,8 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
         unsigned long long mask = __ballot(q);
         while (mask) {
             if (cnt - k > GS_NEW - 256) {          // this step can add up to 4 x 64 keys
-                gs_flush(buf, k, kp2, cnt, lane);
+                thr_key = gs_flush(buf, hist, k, cnt, lane);
                 cnt = k;
-                thr_key = buf[k - 1];
             }
             // up to eight qualifying groups per step: sub-step u gives one to each half-wave
             int64_t col[4];
@@ -265,8 +321,13 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
             }
         }
     }
+    if (cnt > k) gs_flush(buf, hist, k, cnt, lane);
     __syncthreads();
-    gs_flush(buf, k, kp2, cnt, lane);
+    if (mode != 0) {                               // the list leaves the search sorted (canonical order)
+        for (int i = k + lane; i < kp2; i += 64) buf[i] = 0ull;
+        bitonic_sort_desc<64>(buf, kp2);
+    }
+    const int emit = (mode == 1);
     if (emit) {
         const int64_t orow = row_map ? (int64_t)row_map[row] : row;
         for (int i = lane; i < k; i += 64) {
@@ -281,13 +342,13 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
 }
 
 int launch_select_groups(const float* sim, const uint8_t* gflag, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
-                         uint64_t* carry, float* thr, bool emit, int64_t idx_base, float* top_score, int64_t* top_idx,
+                         uint64_t* carry, float* thr, int mode, int64_t idx_base, float* top_score, int64_t* top_idx,
                          hipStream_t st, const int* m_active, const int* row_map) {
     if (M == 0) return ISX_OK;
     if (M >= (1ll << 31) || k > kGroupSelectMaxK) { isx_set_error("select_groups: unsupported M=%lld k=%d", (long long)M, k); return ISX_ERR_ARG; }
     const int ngrp = (int)((Nc + 31) / 32);
     hipLaunchKernelGGL(select_groups_kernel, dim3((unsigned)M), dim3(64), 0, st, sim, gflag, Nc, ld, ngrp, (uint32_t)col_base, k, carry, thr,
-                       emit ? 1 : 0, idx_base, top_score, top_idx, m_active, row_map);
+                       mode, idx_base, top_score, top_idx, m_active, row_map);
     ISX_CHECK_LAUNCH("select_groups");
     return ISX_OK;
 }
@@ -342,7 +403,7 @@ ISX_API int isx_topk_rows(const float* sim, int64_t M, int64_t N, int k, int64_t
     ISX_REQUIRE(idx_base >= 0 && idx_base + N <= 0xFFFFFFFFll, "isx_topk_rows: gallery indices must stay below 2^32");
     ISX_REQUIRE((top_score && top_idx && (sim || N == 0)) || M == 0, "isx_topk_rows: null pointer");
     if (k <= kGroupSelectMaxK && M > 0)     // wave-per-row kernel: all groups present, empty carry
-        return launch_select_groups(sim, nullptr, M, N, N, 0, k, nullptr, nullptr, true, idx_base, top_score, top_idx, (hipStream_t)stream);
+        return launch_select_groups(sim, nullptr, M, N, N, 0, k, nullptr, nullptr, 1, idx_base, top_score, top_idx, (hipStream_t)stream);
     return launch_select(sim, M, N, N, 0, k, nullptr, true, true, idx_base, top_score, top_idx, (hipStream_t)stream);
 }
 
