@@ -241,3 +241,24 @@ def test_randomised_shapes_fast_equals_fp32(ops):
             continue
         assert torch.equal(ref[1], got[1]), (trial, M, N, D, k, mode)
         assert torch.equal(ref[0].view(torch.int32), got[0].view(torch.int32)), (trial, M, N, D, k, mode)
+
+
+def test_non_finite_inputs_take_the_exact_path(ops):
+    """NaN / Inf anywhere in Q or G makes the error bound meaningless: every row must run the exact fp32 search, so the
+    two entry points still agree bit for bit (whatever order the canonical key gives non-finite scores)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    Q = ops.l2norm_rows(torch.randn(64, 128, device="cuda", generator=g))
+    G = ops.l2norm_rows(torch.randn(6000, 128, device="cuda", generator=g))
+    for where in ("q_nan", "g_inf"):
+        Q2, G2 = Q.clone(), G.clone()
+        if where == "q_nan":
+            Q2[3, 7] = float("nan")
+        else:
+            G2[100, 5] = float("inf")
+        ref = ops.cosine_topk(Q2, G2, 10)
+        need = ops.cosine_topk_fast_workspace(64, 6000, 128, 10, False)
+        ws = torch.empty((need,), dtype=torch.uint8, device="cuda")
+        got = ops.cosine_topk_fast(Q2, G2, 10, ws=ws)
+        assert fallback_rows(ws, 64, 6000, 128, 10, False) == 64
+        assert torch.equal(ref[1], got[1])
+        assert torch.equal(ref[0].view(torch.int32), got[0].view(torch.int32))
