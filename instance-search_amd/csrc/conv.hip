@@ -72,12 +72,16 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel
             for (int j = 0; j < NA; ++j) {
                 const int hi = (hw0[j] >> 16) - 1 + kh, wi = (hw0[j] & 0xFFFF) - 1 + kw;
                 aok[j] = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-                ap[j] = x + (int64_t)(pbase[j] + kh * g.W + kw) * g.Cin + c4;
+                // padding taps read the window's centre pixel (always inside the image) and discard it: the load
+                // itself stays unconditional (no exec-masked branch in the k loop)
+                const int pix = aok[j] ? pbase[j] + kh * g.W + kw : pbase[j] + g.W + 1;
+                ap[j] = x + (int64_t)pix * g.Cin + c4;
             }
         }
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            ra[j] = aok[j] ? *reinterpret_cast<const float4*>(ap[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 v = *reinterpret_cast<const float4*>(ap[j]);
+            ra[j] = make_float4(aok[j] ? v.x : 0.f, aok[j] ? v.y : 0.f, aok[j] ? v.z : 0.f, aok[j] ? v.w : 0.f);
             ap[j] += BK;
         }
         ci0 += BK;

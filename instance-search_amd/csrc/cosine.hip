@@ -205,7 +205,7 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     if (epi < 0) epi = gmax ? 1 : 0;
     if (M == 0 || N == 0) return ISX_OK;
     if (((M + 63) / 64) * ((N + 63) / 64) >= (1ll << 31)) { isx_set_error("cosine gemm: too many tiles for one grid"); return ISX_ERR_ARG; }
-    const bool aligned = (D % 4 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);
+    const bool aligned = (D % 32 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);     // no k tail for BK = 16 or 32
     int best = 0;
     double best_t = 1e300;
     for (int c = 0; c < 4; ++c) {

@@ -30,7 +30,8 @@ __device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int
     tile_n = first_n + within % gsz;
 }
 
-// ROWS x BK k = ROWS*CH float4; thread t takes idx = j*256 + t: row = idx/CH, chunk = idx%CH
+// ROWS x BK k = ROWS*CH float4; thread t takes idx = j*256 + t: row = idx/CH, chunk = idx%CH.
+// ALIGNED: 16-B aligned rows AND D a multiple of BK (unconditional 16-B loads); otherwise scalar loads with a zero-filled k tail.
 template <bool ALIGNED, int ROWS, int BK>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t rows, int D, int64_t row0, int k0,
                                           float4 (&reg)[ROWS * BK / 1024]) {
@@ -43,7 +44,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t r
         const int k = k0 + ((idx % CH) << 2);
         const float* src = P + r * D + k;
         if (ALIGNED) {
-            reg[j] = (k < D) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            reg[j] = *reinterpret_cast<const float4*>(src);     // ALIGNED: D % BK == 0, no k tail, no exec-masked branch around the load
         } else {
             reg[j].x = (k + 0 < D) ? src[0] : 0.f;
             reg[j].y = (k + 1 < D) ? src[1] : 0.f;
