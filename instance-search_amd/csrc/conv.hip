@@ -325,9 +325,9 @@ ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, c
     g.Wo = (W - 1) / stride + 1;
     const int64_t M = B * g.Ho * g.Wo, N = Cout;
     ISX_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), "isx_conv3x3_nhwc: too many tiles");
-    // measured on the ResNet-50 shapes (B = 512): 128x64 tiles win while the launch has >= ~2 rounds of them,
-    // 64x64 tiles (6 workgroups per CU) below; 128x128 never does here (79 VGPRs + 64 accumulators: 3 waves/SIMD)
-    int best = (M > 131072 && N >= 64) ? 2 : 3;
+    // measured on the ResNet-50 shapes at B = 1024 (ms, 128x128 / 128x64 / 64x64): 64->64 @56 3.70 / 2.10 / 2.04,
+    // 128->128 @28 1.89 / 1.98 / 1.97, 256->256 @14 1.93 / 1.98 / 1.91, 512->512 @7 2.08 / 2.04 / 1.94
+    int best = (N >= 128 && N <= 256 && M > 131072) ? 0 : 3;
     if (g_force_conv_cfg == 0 || g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
     hipStream_t st = (hipStream_t)stream;
     switch (best) {
