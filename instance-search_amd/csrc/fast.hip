@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_f16_kernel(const _Float16* __
 constexpr int GBM = 256, GBN = 256;
 constexpr int GSTAGE_B = (GBM + GBN) * HBK * 2;          // 64 KB
 
-template <bool FILTER>
+template <bool FILTER, bool FULLK>
 __global__ __launch_bounds__(512) void cosine_gemm_f16_big_kernel(const _Float16* __restrict__ Q, int64_t M,
                                                                   const _Float16* __restrict__ G, int64_t N, int D,
                                                                   float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n,
@@ -301,7 +301,8 @@ __global__ __launch_bounds__(512) void cosine_gemm_f16_big_kernel(const _Float16
     float4 reg[8];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) reg[j] = (k0 + sc * 8 < D) ? *reinterpret_cast<const float4*>(gsrc[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < 8; ++j)      // FULLK (D % 64 == 0): unconditional loads, no exec-masked branch in the k loop
+            reg[j] = (FULLK || k0 + sc * 8 < D) ? *reinterpret_cast<const float4*>(gsrc[j] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto lstore = [&](char* st) {
 #pragma unroll
@@ -403,8 +404,11 @@ int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, 
     const bool big = g_force_f16_tile >= 0 ? g_force_f16_tile == 1 : (btm * btn >= 512);
     if (big) {
         const dim3 grid((unsigned)(btm * btn)), block(512);
-        if (gflag) hipLaunchKernelGGL(cosine_gemm_f16_big_kernel<true>, grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
-        else hipLaunchKernelGGL(cosine_gemm_f16_big_kernel<false>, grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
+        const bool fullk = (D % HBK == 0);
+        if (gflag && fullk) hipLaunchKernelGGL((cosine_gemm_f16_big_kernel<true, true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
+        else if (gflag) hipLaunchKernelGGL((cosine_gemm_f16_big_kernel<true, false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
+        else if (fullk) hipLaunchKernelGGL((cosine_gemm_f16_big_kernel<false, true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
+        else hipLaunchKernelGGL((cosine_gemm_f16_big_kernel<false, false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
         ISX_CHECK_LAUNCH("cosine_gemm_f16_big");
         return ISX_OK;
     }
