@@ -102,18 +102,7 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel
             load_a();
             load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
         }
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = a_base[(2 * kk) * LDA + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = b_base[(2 * kk) * LDB + 32 * j];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+        mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
         __syncthreads();
         if (more) {
             store_tile<BM, BK>(As, ra);
@@ -239,18 +228,7 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_k
             load_a();
             load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
         }
-#pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = a_base[(2 * kk) * LDA + 32 * i];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = b_base[(2 * kk) * LDB + 32 * j];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
+        mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
         __syncthreads();
         if (more) {
             store_tile<BM, BK>(As, ra);
