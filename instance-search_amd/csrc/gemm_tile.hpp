@@ -1,6 +1,9 @@
 // gemm_tile.hpp -- device helpers shared by the fp32-MFMA GEMM (cosine.hip) and the implicit-GEMM 3x3 convolution
 // (conv.hip): XCD-aware tile mapping and the K-major LDS staging of operand tiles.
 #pragma once
+#ifndef ISX_SIMPLE_KLOOP
+#define ISX_SIMPLE_KLOOP 0      // A/B: 1 = the plain per-step k loop on every tile shape
+#endif
 #include "isx_internal.hpp"
 
 namespace isx {
@@ -74,7 +77,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 // of a drain per step; +4 % on the trunk's 1x1 convolutions).  a_base / b_base: this lane's first operand element.
 template <int TM, int TN, int BK, int LDA, int LDB>
 __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, const float* __restrict__ b_base, f32x16 (&acc)[TM][TN]) {
-    if (TM * TN <= 2) {
+    if (TM * TN <= 2 && !ISX_SIMPLE_KLOOP) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float af[BK / 4][TM], bf[BK / 4][TN];

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libisx.so")
+LIB_PATH = os.environ.get("ISX_LIB") or os.path.join(_CSRC, "libisx.so")      # ISX_LIB: A/B builds of the same ABI
 
 _lib = None
 
