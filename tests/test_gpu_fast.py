@@ -262,3 +262,25 @@ def test_non_finite_inputs_take_the_exact_path(ops):
         assert fallback_rows(ws, 64, 6000, 128, 10, False) == 64
         assert torch.equal(ref[1], got[1])
         assert torch.equal(ref[0].view(torch.int32), got[0].view(torch.int32))
+
+
+def test_full_size_shard_invariance(ops):
+    """Config-3/5 scale (2 k queries x 400 k rows x 2048, top-100): the fast search on the whole gallery, on 8 row shards +
+    merge, and the all-fp32 search give the same bits; sampled rows against the CPU oracle."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, N, D, k, P = 2000, 400000, 2048, 100, 8
+    Q = ops.l2norm_rows(torch.randn(M, D, device="cuda", generator=g))
+    G = torch.empty(N, D, device="cuda")
+    for i in range(0, N, 100000):
+        G[i:i + 100000] = ops.l2norm_rows(torch.randn(100000, D, device="cuda", generator=g))
+    ts, ti = ops.cosine_topk_fast(Q, G, k, gallery_f16=ops.gallery_to_f16(G))
+    assert bool((ts[:, :-1] >= ts[:, 1:]).all()) and int(ti.min()) >= 0 and int(ti.max()) < N
+    parts = [ops.cosine_topk_fast(Q, G[p * N // P:(p + 1) * N // P], k, idx_base=p * N // P) for p in range(P)]
+    ms, mi = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(mi, ti) and torch.equal(ms.view(torch.int32), ts.view(torch.int32))
+    ref = ops.cosine_topk(Q, G, k)
+    assert torch.equal(ref[1], ti) and torch.equal(ref[0].view(torch.int32), ts.view(torch.int32))
+    rows = [0, 777, 1999]
+    os_, oi = O.cosine_topk(host(Q[rows]), host(G), k)
+    np.testing.assert_array_equal(host(ti[rows]), oi)
+    np.testing.assert_array_equal(host(ts[rows]), os_)
