@@ -39,7 +39,9 @@ def _worker(rank, world, port, out_dir):
     # k larger than a shard row count exercises the (-inf,-1) padding
     tiny = R.ShardedGallery(G[lo:lo + 2], lo)
     s2, i2 = tiny.search(Q, 5)
-    torch.save({"s": s, "i": i, "s2": s2, "i2": i2, "G": G, "Q": Qall, "lo": lo}, os.path.join(out_dir, "r%d.pt" % rank))
+    # replicated gallery, queries split across ranks (7 queries over 2 ranks: uneven blocks)
+    rs, ri = R.ReplicatedGallery(G).search(torch.cat([Qall, Qall[:1]]), k)
+    torch.save({"s": s, "i": i, "s2": s2, "i2": i2, "G": G, "Q": Qall, "lo": lo, "rs": rs, "ri": ri}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -56,6 +58,11 @@ def test_sharded_search_matches_unsharded(tmp_path):
     assert torch.equal(r[0]["s"], want.values[:, :10])
     # the canonical order also agrees with the oracle's ranking of the same score matrix
     np.testing.assert_array_equal(r[0]["i"].numpy(), O.rank_full(sim.numpy())[:, :10])
+    # replicated-gallery mode: the same lists (7 queries: 6 + the first one again), on every rank
+    Q7 = torch.cat([Q, Q[:1]])
+    want7 = (Q7 @ G.t()).sort(dim=1, descending=True, stable=True)
+    for k_ in range(world):
+        assert torch.equal(r[k_]["ri"], want7.indices[:, :10]) and torch.equal(r[k_]["rs"], want7.values[:, :10])
     # tiny shards: 2 rows each -> 4 real candidates + padding
     rows = torch.cat([G[r[0]["lo"]:r[0]["lo"] + 2], G[r[1]["lo"]:r[1]["lo"] + 2]])
     ids = torch.tensor([r[0]["lo"], r[0]["lo"] + 1, r[1]["lo"], r[1]["lo"] + 1])

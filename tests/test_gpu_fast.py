@@ -284,3 +284,13 @@ def test_full_size_shard_invariance(ops):
     os_, oi = O.cosine_topk(host(Q[rows]), host(G), k)
     np.testing.assert_array_equal(host(ti[rows]), oi)
     np.testing.assert_array_equal(host(ts[rows]), os_)
+
+
+def test_replicated_gallery_single_process(ops):
+    from isx.retrieval import ReplicatedGallery, ShardedGallery
+    g = torch.Generator(device="cuda").manual_seed(6)
+    Q = ops.l2norm_rows(torch.randn(300, 64, device="cuda", generator=g))
+    G = ops.l2norm_rows(torch.randn(20000, 64, device="cuda", generator=g))
+    a = ReplicatedGallery(G).search(Q, 10)
+    b = ShardedGallery(G, 0, fast=False).search(Q, 10)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
