@@ -172,6 +172,10 @@ int isx_gallery_to_f16(const float* G, int64_t N, int D, void* Gh, float* gstats
  * rows whose candidate window cannot be proven complete, k > 128, D % 8 != 0, unaligned or tiny galleries
  * and out-of-range magnitudes all run the exact fp32 search. */
 size_t isx_cosine_topk_fast_workspace(int64_t M, int64_t N, int D, int k, int have_gallery_f16);
+/* Byte offset in that workspace of an int32 holding, after the search has completed, how many query rows took the exact
+ * fp32 fallback ((size_t)-1: the whole call runs the fp32 search).  A caller whose data keeps falling back (dense clusters
+ * of near-equal scores) should switch to isx_cosine_topk. */
+size_t isx_cosine_topk_fast_fallback_offset(int64_t M, int64_t N, int D, int k, int have_gallery_f16);
 int isx_cosine_topk_fast(const float* Q, int64_t M, const float* G, int64_t N, int D, int k, int64_t idx_base,
                          const void* Gh, const float* gstats, float* top_score, int64_t* top_idx, void* ws,
                          size_t ws_bytes, isx_stream_t stream);

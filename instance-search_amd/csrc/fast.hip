@@ -731,6 +731,14 @@ ISX_API int isx_cosine_topk_fast(const float* Q, int64_t M, const float* G, int6
 // Debug / A-B hook (not declared in include/isx.h): force the fp16 GEMM tile (0 = 128x128, 1 = 256x256, -1 = automatic).
 ISX_API void isx_debug_set_f16_tile(int t) { g_force_f16_tile = t; }
 
+// Byte offset, inside the workspace of isx_cosine_topk_fast called with the same arguments, of an int32 that holds -- once
+// that call has completed on its stream -- the number of query rows that needed the exact fp32 fallback.  (size_t)-1 when such a
+// call runs the fp32 search as a whole.  Lets a caller watch the fallback rate without a host synchronisation inside libisx.
+ISX_API size_t isx_cosine_topk_fast_fallback_offset(int64_t M, int64_t N, int D, int k, int have_gallery_f16) {
+    if (!fast_applicable(M, N, D, k)) return (size_t)-1;
+    return fast_layout(M, N, D, k, !have_gallery_f16).count;
+}
+
 // Debug / test hook (not declared in include/isx.h): number of query rows of the LAST isx_cosine_topk_fast
 // call on this workspace that took the exact fp32 fallback (-1: the call ran the fp32 path as a whole).
 // Synchronises the device.

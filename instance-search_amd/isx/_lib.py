@@ -39,6 +39,7 @@ _SIGNATURES = {
     "isx_cosine_sim_f16": (C.c_int, [VP, I64, VP, I64, I32, VP, VP]),
     "isx_gallery_to_f16": (C.c_int, [VP, I64, I32, VP, VP, VP]),
     "isx_cosine_topk_fast_workspace": (SZ, [I64, I64, I32, I32, I32]),
+    "isx_cosine_topk_fast_fallback_offset": (SZ, [I64, I64, I32, I32, I32]),
     "isx_cosine_topk_fast": (C.c_int, [VP, I64, VP, I64, I32, I32, I64, VP, VP, VP, VP, VP, SZ, VP]),
     "isx_topk_rows": (C.c_int, [VP, I64, I64, I32, I64, VP, VP, VP]),
     "isx_rank_full_workspace": (SZ, [I64, I64]),

@@ -301,6 +301,15 @@ def cosine_topk_fast_workspace(M, N, D, k, have_gallery_f16=False):
     return lib().isx_cosine_topk_fast_workspace(M, N, D, k, 1 if have_gallery_f16 else 0)
 
 
+def cosine_topk_fast_fallback_counter(ws, M, N, D, k, have_gallery_f16=False):
+    """int32 view (1 element, on the device) of the fallback-row counter inside a cosine_topk_fast workspace, or None when a
+    call of this shape runs the fp32 search as a whole.  Valid once the search has completed on its stream."""
+    off = lib().isx_cosine_topk_fast_fallback_offset(M, N, D, k, 1 if have_gallery_f16 else 0)
+    if off == (1 << 64) - 1 or off + 4 > ws.numel():
+        return None
+    return ws[off:off + 4].view(torch.int32)
+
+
 def cosine_topk_fast(Q, G, k, idx_base=0, gallery_f16=None, ws=None, out=None):
     """Same result as cosine_topk, bit for bit; fp16-MFMA filter + exact fp32 re-scoring.
     gallery_f16: optional (Gh, gstats) from gallery_to_f16(G)."""

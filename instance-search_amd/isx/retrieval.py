@@ -103,6 +103,12 @@ class ShardedGallery(object):
         self.fast = bool(fast) and self.shard.is_cuda
         self._ws = None
         self._f16 = None                      # (Gh, gstats), built on first search
+        # fallback watch: rows of the previous fast search that needed the exact fp32 pass (read back asynchronously).
+        # Data with dense clusters of near-equal scores makes the filter pay without saving anything: above
+        # FALLBACK_LIMIT of the rows the gallery switches itself to the all-fp32 search (same results).
+        self._fb_host = None
+        self._fb_event = None
+        self._fb_rows = 0
 
     @classmethod
     def from_full(cls, gallery, group=None):
@@ -124,12 +130,34 @@ class ShardedGallery(object):
             self._ws = torch.empty((need,), dtype=torch.uint8, device=self.shard.device)
         return self._ws
 
+    FALLBACK_LIMIT = 0.25
+
+    def _check_fallback(self):
+        if self._fb_event is not None and self._fb_event.query():
+            if self._fb_rows and int(self._fb_host[0]) > self.FALLBACK_LIMIT * self._fb_rows:
+                self.fast = False                      # this data defeats the filter: stay on the fp32 search
+            self._fb_event = None
+
     def local_search(self, Q, k):
         """This rank's shard only (no collective): canonical top-k with global indices."""
+        if self.fast:
+            self._check_fallback()
         if self.fast and self._f16 is None and self.shard.size(0) > 0:
             from . import ops
             self._f16 = ops.gallery_to_f16(self.shard)
-        return local_topk(Q, self.shard, k, self.idx_base, self._workspace(Q.size(0), k), self._f16 if self.fast else None)
+        ws = self._workspace(Q.size(0), k)
+        out = local_topk(Q, self.shard, k, self.idx_base, ws, self._f16 if self.fast else None)
+        if self.fast and self._f16 is not None and self._fb_event is None:
+            from . import ops
+            cnt = ops.cosine_topk_fast_fallback_counter(ws, Q.size(0), self.shard.size(0), self.shard.size(1), k, True)
+            if cnt is not None:
+                if self._fb_host is None:
+                    self._fb_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._fb_host.copy_(cnt, non_blocking=True)
+                self._fb_rows = Q.size(0)
+                self._fb_event = torch.cuda.Event()
+                self._fb_event.record()
+        return out
 
     def search(self, Q, k):
         """Global canonical top-k for the (replicated) query block Q: (scores (M,k), idx (M,k))."""

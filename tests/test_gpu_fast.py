@@ -294,3 +294,25 @@ def test_replicated_gallery_single_process(ops):
     a = ReplicatedGallery(G).search(Q, 10)
     b = ShardedGallery(G, 0, fast=False).search(Q, 10)
     assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+
+
+def test_sharded_gallery_leaves_the_fast_path_when_the_data_defeats_it(ops):
+    """Every row falls back on a gallery of tight clusters: after the first search the gallery switches itself to the fp32
+    search; results are the same before and after.  A well-separated gallery stays on the fast path."""
+    from isx.retrieval import ShardedGallery
+    g = torch.Generator(device="cuda").manual_seed(8)
+    Q = ops.l2norm_rows(torch.randn(200, 128, device="cuda", generator=g))
+    c = ops.l2norm_rows(torch.randn(8, 128, device="cuda", generator=g))
+    G = ops.l2norm_rows(c[torch.randint(0, 8, (20000,), device="cuda", generator=g)] + 1e-4 * torch.randn(20000, 128, device="cuda", generator=g))
+    gal = ShardedGallery(G, 0)
+    a = gal.search(Q, 20)
+    torch.cuda.synchronize()
+    b = gal.search(Q, 20)                          # reads the counter of the first search
+    assert gal.fast is False
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+    ok = ShardedGallery(ops.l2norm_rows(torch.randn(20000, 128, device="cuda", generator=g)), 0)
+    ok.search(Q, 20); torch.cuda.synchronize(); ok.search(Q, 20)
+    assert ok.fast is True
+    counter = ops.cosine_topk_fast_fallback_counter(ok._ws, 200, 20000, 128, 20, True)
+    torch.cuda.synchronize()
+    assert int(counter.item()) == 0
