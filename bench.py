@@ -123,9 +123,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the HIP path)")
+    # debugging aid for boxes with ONE GPU: ISX_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and uses gloo, so the N > 1 code path
+    # (query all-gather, per-shard search, result all-gather, merge) can be exercised; the numbers it prints mean nothing
+    one_device = world > 1 and os.environ.get("ISX_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 and one_device:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 

@@ -216,3 +216,26 @@ def test_folder_dataset_raw_ingest_end_to_end(tmp_path, capsys, monkeypatch):
     # same pixels, same arithmetic -> same network input; MIOpen may pick another kernel between runs, hence a tolerance
     np.testing.assert_allclose(host(g_raw), host(g_f32), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(host(q_raw), host(q_f32), rtol=1e-5, atol=1e-6)
+
+
+def test_bench_multi_rank_code_path_on_one_gpu():
+    """bench.py's N > 1 path (query all-gather, per-shard search, result all-gather, canonical merge, one JSON line from rank 0)
+    with two ranks sharing cuda:0 over gloo (ISX_BENCH_ONE_DEVICE=1): functional check only, the 8-GPU RCCL run is the driver's."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, ISX_BENCH_ONE_DEVICE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
+           "--gallery", "2000", "--no-cpu-baseline", "--no-shard-bench"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 2
+    assert d["config"]["gallery_rows_per_gpu"] == 2000 and "roofline" in d
