@@ -4,19 +4,23 @@
 // by the 157 TFLOP/s fp32 matrix peak.  The fp16 matrix cores are 16x faster, and a top-k search does
 // not need every score exactly -- only the scores of the candidates that can make the list:
 //
-//   1. operands rounded to fp16 (RNE), row norms kept                         rows_to_f16_kernel
+//   1. operands scaled by a power of two (exact) and rounded to fp16 (RNE), row norms kept
+//                                                                   amax_kernel, rows_to_f16_kernel
 //   2. approximate scores  S' = Qh . Gh^T  on v_mfma_f32_32x32x16_f16 (fp32 accumulate) with the
-//      same fused filter epilogue / group select as the fp32 path -> the KL best APPROXIMATE
-//      candidates of every query (KL = 256 >= k)                             cosine_gemm_f16_kernel
+//      same fused filter epilogue / group select as the fp32 path (run_topk_chunks, cosine.hip) ->
+//      the KL = min(256, 2k + 32) best APPROXIMATE candidates of every query
+//                                                 cosine_gemm_f16_big_kernel / cosine_gemm_f16_kernel
 //   3. |S' - S| <= eps_i for every pair (eps_i = c * |q_i| * max_j |g_j|, bound below), hence every
 //      member of the exact top-k has S' >= a_k - 2 eps_i where a_k is the k-th best approximate
 //      score.  Candidates inside that window are re-scored EXACTLY (the k-ordered fp32 fma chain of
 //      the oracle) and sorted by the canonical key                            rescore_kernel
-//   4. a row whose window is not fully covered by its KL candidates (dense clusters of near-equal
-//      scores) is recomputed by exhaustive exact search                      exhaustive_rows_kernel
+//   4. rows whose window is not fully covered by their KL candidates (dense clusters of near-equal
+//      scores) are compacted on the device and searched exactly by the fp32 pipeline (the same
+//      run_topk_chunks with m_active / row_map: launch sizes fixed, idle tiles exit at once)
+//                                                          compact_rows_kernel, gather_rows_kernel
 //
-// The result is bit-identical to isx_cosine_topk for ANY input (tests: random, clustered galleries
-// that force step 4, adversarial orderings).  Reference call sites: the same as isx_cosine_topk
+// The result is bit-identical to isx_cosine_topk for ANY input (tests/test_gpu_fast.py: random, clustered
+// galleries that force step 4, adversarial orderings, magnitudes, non-finite values, 40 random shapes).  Reference call sites: the same as isx_cosine_topk
 // (test/classif_finetune_test.py:82 + utils/metrics.py:10-13,33).
 //
 // Error bound.  u16 = 2^-11 (fp16 RNE), u32 = 2^-24.  Operands are first multiplied by a power of two
