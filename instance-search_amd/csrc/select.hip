@@ -5,10 +5,13 @@
 // (score desc, index asc).  Every candidate is a single u64 key
 // (orderable(score) << 32 | ~index), so "k best" = "k largest keys" and ties cannot occur.
 //
-// One 256-thread workgroup per query row.  Scores stream from HBM/L2 in 16-B loads;
-// candidates beating the current k-th key are appended to a 2048-entry LDS buffer
-// (wave prefix by shuffles + one LDS atomic per wave); when the buffer could
-// overflow it is bitonic-sorted and cut back to k, which also tightens the threshold.
+// Two kernels:
+//   select_groups_kernel (k <= 256, the usual case): ONE WAVE per query row over a materialised or FILTERED score chunk;
+//     running list unsorted in LDS, threshold updates by radix select, one sort at the end of the search (see below).
+//   select_kernel (k up to 1024): one 256-thread workgroup per row.  Scores stream from HBM/L2 in 16-B loads; candidates
+//     beating the current k-th key are appended to a 2048-entry LDS buffer (wave prefix by shuffles + one LDS atomic per
+//     wave); when the buffer could overflow it is bitonic-sorted and cut back to k, which also tightens the threshold.
+//   topk_merge_kernel: canonical merge of P per-shard lists.
 #include "isx_internal.hpp"
 
 namespace isx {
