@@ -2,7 +2,9 @@
 //
 //   isx_conv1x1_nhwc   the activation matrix (B*H*W, Cin) IS the row-major A operand of the fp32-MFMA GEMM of
 //                      cosine.hip; this file only adds the entry point (epilogue mode 2 of cosine_gemm_kernel)
-//   isx_conv3x3_nhwc   implicit GEMM below
+//   isx_conv3x3_nhwc        implicit GEMM below (conv3x3_nhwc_kernel)
+//   isx_conv1x1_dual_nhwc   last 1x1 convolution of a bottleneck block + its projection shortcut as ONE GEMM over the
+//                           concatenated K = [t ; x_strided] (conv1x1_dual_nhwc_kernel)
 //
 // Reference call sites: the torchvision ResNet `features` trunk built by model/ModelDefinition.py, split by
 // model/nn_utils.py:56-71 and run from model/siamese.py:20,107,151.

@@ -20,6 +20,9 @@
 // tile t+1 are issued before the MFMAs of tile t (register prefetch).  Workgroups are
 // remapped XCD-aware: each XCD walks a contiguous range of tiles, ordered so that
 // concurrently resident tiles share Q / G panels in that XCD's L2.
+//
+// The same kernel, epilogue mode 2, is the 1x1 convolution of the inference trunk (entry point in conv.hip); the chunked
+// running-top-k driver at the end of this file (run_topk_chunks) serves isx_cosine_topk and both phases of fast.hip.
 #include "gemm_tile.hpp"
 
 namespace isx {
