@@ -1,0 +1,62 @@
+"""Randomised soak test (not part of the suite): many random shapes through the kernels with bit-exact comparisons.
+    python scratch/soak.py [seconds]"""
+import sys, time, numpy as np, torch
+sys.path.insert(0, "/root/repo/instance-search_amd"); sys.path.insert(0, "/root/repo/oracle")
+from isx import ops
+import oracle as O
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rng = np.random.default_rng(int(time.time()))
+g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+t0 = time.time(); n = {"fast": 0, "conv1": 0, "conv3": 0, "dual": 0, "topk": 0, "sel": 0}
+def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+while time.time() - t0 < budget:
+    kind = rng.integers(0, 6)
+    if kind == 0:      # fast vs fp32 search
+        M = int(rng.integers(1, 3000)); N = int(rng.integers(300, 200000)); D = int(rng.choice([8, 16, 64, 96, 256, 512, 1024, 2048])); k = int(rng.integers(1, 129))
+        if M * N * D > 4e11: continue
+        Q = torch.randn(M, D, device="cuda", generator=g); G = torch.randn(N, D, device="cuda", generator=g)
+        mode = int(rng.integers(0, 4))
+        if mode == 1: G = G[torch.randint(0, max(2, N // int(rng.integers(2, 200))), (N,), device="cuda", generator=g)] + float(10 ** rng.uniform(-6, -2)) * torch.randn(N, D, device="cuda", generator=g)
+        if mode == 2: Q, G = Q.relu() + 1e-4, G.relu() + 1e-4
+        if mode == 3: G[N // 2:] = G[:N - N // 2].clone()
+        Q, G = ops.l2norm_rows(Q) * float(10 ** rng.uniform(-3, 3)), ops.l2norm_rows(G) * float(10 ** rng.uniform(-3, 3))
+        ib = int(rng.integers(0, 10 ** 6))
+        a = ops.cosine_topk(Q, G, k, idx_base=ib); b = ops.cosine_topk_fast(Q, G, k, idx_base=ib, gallery_f16=ops.gallery_to_f16(G) if rng.integers(2) else None)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), ("fast", M, N, D, k, mode)
+        n["fast"] += 1
+    elif kind == 1:    # conv1x1 vs oracle
+        M = int(rng.integers(1, 3000)); Cin = int(rng.choice([4, 32, 64, 100, 256, 512])); Cout = int(rng.choice([4, 36, 64, 128, 130, 512]))
+        x = np.maximum(rng.standard_normal((M, Cin), dtype=np.float32), 0); w = rng.standard_normal((Cout, Cin), dtype=np.float32) * 0.1
+        b = rng.standard_normal(Cout, dtype=np.float32); res = rng.integers(2); relu = bool(rng.integers(2))
+        r = rng.standard_normal((M, Cout), dtype=np.float32) if res else None
+        y = ops.conv1x1_nhwc(dev(x).view(1, M, 1, Cin).permute(0, 3, 1, 2), dev(w), dev(b), dev(r).view(1, M, 1, Cout).permute(0, 3, 1, 2) if res else None, relu)
+        assert np.array_equal(y.permute(0, 2, 3, 1).reshape(M, Cout).cpu().numpy(), O.conv1x1_nhwc(x, w, b, r, relu)), ("conv1", M, Cin, Cout)
+        n["conv1"] += 1
+    elif kind == 2:    # conv3x3 vs oracle
+        B = int(rng.integers(1, 4)); H = int(rng.integers(1, 20)); W = int(rng.integers(1, 20)); Cin = int(rng.choice([32, 64, 96, 128])); Cout = int(rng.choice([32, 64, 100, 256])); s = int(rng.integers(1, 3))
+        x = np.maximum(rng.standard_normal((B, H, W, Cin), dtype=np.float32), 0); w = rng.standard_normal((Cout, 3, 3, Cin), dtype=np.float32) * 0.05; b = rng.standard_normal(Cout, dtype=np.float32)
+        y = ops.conv3x3_nhwc(dev(x).permute(0, 3, 1, 2), dev(w), dev(b), s, None, True)
+        assert np.array_equal(y.permute(0, 2, 3, 1).cpu().numpy(), O.conv3x3_nhwc(x, w, b, s, None, True)), ("conv3", B, H, W, Cin, Cout, s)
+        n["conv3"] += 1
+    elif kind == 3:    # dual
+        B = int(rng.integers(1, 4)); H = int(rng.integers(1, 16)); W = int(rng.integers(1, 16)); K1 = int(rng.choice([32, 64, 128])); K2 = int(rng.choice([32, 64, 256])); Cout = int(rng.choice([32, 100, 256])); s = int(rng.integers(1, 3))
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        t = np.maximum(rng.standard_normal((B, Ho, Wo, K1), dtype=np.float32), 0); x = np.maximum(rng.standard_normal((B, H, W, K2), dtype=np.float32), 0)
+        w = rng.standard_normal((Cout, K1 + K2), dtype=np.float32) * 0.1; b = rng.standard_normal(Cout, dtype=np.float32)
+        y = ops.conv1x1_dual_nhwc(dev(t).permute(0, 3, 1, 2), dev(x).permute(0, 3, 1, 2), dev(w), dev(b), s, True)
+        assert np.array_equal(y.permute(0, 2, 3, 1).cpu().numpy(), O.conv1x1_dual_nhwc(t, x, w, b, s, True)), ("dual", B, H, W, K1, K2, Cout, s)
+        n["dual"] += 1
+    elif kind == 4:    # fp32 fused topk vs materialised topk_rows
+        M = int(rng.integers(1, 500)); N = int(rng.integers(1, 120000)); D = int(rng.choice([8, 20, 64, 256])); k = int(rng.integers(1, 400))
+        Q = torch.randn(M, D, device="cuda", generator=g); G = torch.randn(N, D, device="cuda", generator=g)
+        a = ops.cosine_topk(Q, G, k); sim = ops.cosine_sim(Q, G); b = ops.topk_rows(sim, k)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), ("topk", M, N, D, k)
+        n["topk"] += 1
+    else:              # topk_rows vs torch (values; ties only by equal scores)
+        M = int(rng.integers(1, 300)); N = int(rng.integers(1, 50000)); k = int(rng.integers(1, min(N, 256) + 1))
+        sim = torch.randn(M, N, device="cuda", generator=g)
+        s_, i_ = ops.topk_rows(sim, k); ts = torch.topk(sim, k, dim=1).values
+        assert torch.equal(s_, ts) and torch.equal(sim.gather(1, i_), s_), ("sel", M, N, k)
+        n["sel"] += 1
+torch.cuda.synchronize()
+print("soak OK", n, "in %.0f s" % (time.time() - t0))
