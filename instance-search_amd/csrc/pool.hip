@@ -460,15 +460,32 @@ __global__ __launch_bounds__(256) void images_u8_to_f32_kernel(const uint8_t* __
 #pragma unroll
             for (int i = 0; i < 12; ++i) u[i] = (p0 * 3 + i < total * 3) ? img[p0 * 3 + i] : 0;
         }
+        float v[12];
 #pragma unroll
-        for (int px = 0; px < 4; ++px) {
-            const int64_t p = p0 + px;
-            if (p >= total) break;
+        for (int i = 0; i < 12; ++i) v[i] = ((float)u[i] / 255.0f - mean[i % 3]) / sd[i % 3];
+        if (p0 + 3 < total && nhwc) {
+            // 4 pixels x 3 channels = 48 contiguous bytes, 16-B aligned (p0 is a multiple of 4)
+            float4* o = reinterpret_cast<float4*>(out + p0 * 3);
+            o[0] = make_float4(v[0], v[1], v[2], v[3]);
+            o[1] = make_float4(v[4], v[5], v[6], v[7]);
+            o[2] = make_float4(v[8], v[9], v[10], v[11]);
+        } else if (p0 + 3 < total && (HW & 3) == 0) {
+            // NCHW with HW % 4 == 0: the 4 pixels are in one image, one 16-B store per channel plane
+            const int64_t b = p0 / HW, hw = p0 - b * HW;
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float v = ((float)u[px * 3 + c] / 255.0f - mean[c]) / sd[c];
-                if (nhwc) out[p * 3 + c] = v;
-                else { const int64_t b = p / HW; out[(b * 3 + c) * (int64_t)HW + (p - b * HW)] = v; }
+            for (int c = 0; c < 3; ++c)
+                *reinterpret_cast<float4*>(out + (b * 3 + c) * (int64_t)HW + hw) = make_float4(v[c], v[3 + c], v[6 + c], v[9 + c]);
+        } else {
+#pragma unroll
+            for (int px = 0; px < 4; ++px) {
+                const int64_t p = p0 + px;
+                if (p < total) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if (nhwc) out[p * 3 + c] = v[px * 3 + c];
+                        else { const int64_t b = p / HW; out[(b * 3 + c) * (int64_t)HW + (p - b * HW)] = v[px * 3 + c]; }
+                    }
+                }
             }
         }
     }
