@@ -79,51 +79,50 @@ __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restric
                                                           float* __restrict__ norm2, float* __restrict__ amax,
                                                           unsigned* __restrict__ stats, int want_norm_max) {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     __shared__ float wn2[4];
-    if (lane == 0) wn2[threadIdx.x >> 6] = 0.0f;
-    if (row >= B) {
-        if (want_norm_max) __syncthreads();
-        return;
-    }
     const float scale = stats ? f16_scale(__uint_as_float(stats[1])) : 1.0f;
-    const float* r = x + row * D;
-    _Float16* o = h + row * D;
-    float ss = 0.0f, mx = 0.0f;
-    if ((D & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)h)) & 15) == 0) {
-        // 8 elements per lane and step: two 16-B loads, one 16-B store
-        for (int j = lane * 8; j < D; j += 512) {
-            const float4 v0 = *reinterpret_cast<const float4*>(r + j), v1 = *reinterpret_cast<const float4*>(r + j + 4);
-            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            half8 hv;
+    float run_max = 0.0f;                                // this wave's largest row norm (grid-stride over row groups:
+    const bool vec = (D & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)h)) & 15) == 0;      // one atomic per workgroup at the end)
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < B; row += (int64_t)gridDim.x * 4) {
+        const float* r = x + row * D;
+        _Float16* o = h + row * D;
+        float ss = 0.0f, mx = 0.0f;
+        if (vec) {
+            // 8 elements per lane and step: two 16-B loads, one 16-B store
+            for (int j = lane * 8; j < D; j += 512) {
+                const float4 v0 = *reinterpret_cast<const float4*>(r + j), v1 = *reinterpret_cast<const float4*>(r + j + 4);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                half8 hv;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                hv[q] = (_Float16)(v[q] * scale);    // power-of-two scaling is exact; conversion RNE
-                ss += v[q] * v[q];
-                mx = nanmax(mx, fabsf(v[q]));
+                for (int q = 0; q < 8; ++q) {
+                    hv[q] = (_Float16)(v[q] * scale);    // power-of-two scaling is exact; conversion RNE
+                    ss += v[q] * v[q];
+                    mx = nanmax(mx, fabsf(v[q]));
+                }
+                *reinterpret_cast<half8*>(o + j) = hv;
             }
-            *reinterpret_cast<half8*>(o + j) = hv;
+        } else {
+            for (int j = lane; j < D; j += 64) {
+                const float v = r[j];
+                o[j] = (_Float16)(v * scale);
+                ss += v * v;
+                mx = nanmax(mx, fabsf(v));
+            }
         }
-    } else {
-        for (int j = lane; j < D; j += 64) {
-            const float v = r[j];
-            o[j] = (_Float16)(v * scale);
-            ss += v * v;
-            mx = nanmax(mx, fabsf(v));
-        }
-    }
-    ss = wave_sum(ss);
+        ss = wave_sum(ss);
 #pragma unroll
-    for (int s = 32; s > 0; s >>= 1) mx = nanmax(mx, __shfl_xor(mx, s, 64));
-    ss *= 1.000001f;                                                    // slight inflation: norm2 is an upper bound
-    if (!(ss >= 0.0f)) ss = INFINITY;
-    if (!(mx >= 0.0f)) mx = INFINITY;
-    if (lane == 0) {
-        if (norm2) norm2[row] = ss;
-        if (amax) amax[row] = mx;
-        wn2[threadIdx.x >> 6] = ss;
+        for (int s = 32; s > 0; s >>= 1) mx = nanmax(mx, __shfl_xor(mx, s, 64));
+        ss *= 1.000001f;                                                    // slight inflation: norm2 is an upper bound
+        if (!(ss >= 0.0f)) ss = INFINITY;
+        if (!(mx >= 0.0f)) mx = INFINITY;
+        if (lane == 0) {
+            if (norm2) norm2[row] = ss;
+            if (amax) amax[row] = mx;
+        }
+        run_max = fmaxf(run_max, ss);
     }
-    if (want_norm_max) {                                   // uniform per launch; one atomic per workgroup
+    if (want_norm_max) {                                   // uniform per launch
+        if (lane == 0) wn2[threadIdx.x >> 6] = run_max;
         __syncthreads();
         if (threadIdx.x == 0) atomicMax(&stats[0], __float_as_uint(fmaxf(fmaxf(wn2[0], wn2[1]), fmaxf(wn2[2], wn2[3]))));
     }
@@ -627,7 +626,8 @@ static int convert_scaled(const float* x, int64_t B, int D, _Float16* h, float* 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, stats);
     ISX_CHECK_LAUNCH("amax");
-    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x, B, D, h, norm2, (float*)nullptr, stats, want_norm_max);
+    hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4 < 4096 ? (B + 3) / 4 : 4096)), dim3(256), 0, st, x, B, D, h, norm2, (float*)nullptr, stats,
+                       want_norm_max);
     ISX_CHECK_LAUNCH("rows_to_f16");
     return ISX_OK;
 }
