@@ -25,7 +25,7 @@ template <int TM, int TN, int BK>
 __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
                                                            Conv3x3Geom g, float* __restrict__ C, TileMap tm,
                                                            const float* __restrict__ bias, const float* __restrict__ res, int relu) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 1, LDB = BN + 1;
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
     constexpr int CH = BK / 4, NA = BM * CH / 256;
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_k
                                                                                       const float* __restrict__ Wt, int64_t N, DualGeom g,
                                                                                       float* __restrict__ C, TileMap tm,
                                                                                       const float* __restrict__ bias, int relu) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 1, LDB = BN + 1;
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
     constexpr int CH = BK / 4, NA = BM * CH / 256;
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;

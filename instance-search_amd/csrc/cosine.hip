@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
                                                           float* __restrict__ C, int64_t ldc, TileMap tm,
                                                           const float* __restrict__ thr, uint8_t* __restrict__ gflag,
                                                           int ngrp) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + 1, LDB = BN + 1;
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
     float* Bs = lds + BK * LDA;

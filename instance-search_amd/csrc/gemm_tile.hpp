@@ -57,10 +57,17 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t r
     }
 }
 
+// K-major LDS image [k][row] with row stride ROWS + pad.  A staging lane (chunk c = idx % CH, row r = idx / CH) writes
+// element (4c + i, r): bank = ((4c + i) * stride + r) mod 32.  BK = 32 (CH = 8, 4 rows per 32-lane group): stride = 1 mod 32 gives
+// 4c + r, all distinct.  BK = 16 (CH = 4, 8 rows per group): stride = 1 would give 4c + r with 4-way collisions (measured:
+// SQ_LDS_BANK_CONFLICT = 25 % of the LDS cycles of the 128x128 kernel); stride = 2 mod 32 gives 8c + r, all distinct.  Operand
+// reads are 32 consecutive floats per half-wave for either stride.
+__host__ __device__ constexpr int lds_pad(int BK) { return BK == 16 ? 2 : 1; }
+
 template <int ROWS, int BK>
 __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&reg)[ROWS * BK / 1024]) {
     constexpr int CH = BK / 4;
-    constexpr int LD = ROWS + 1;                            // odd K-major stride: conflict-free transposed writes
+    constexpr int LD = ROWS + lds_pad(BK);                  // K-major stride chosen for conflict-free transposed writes
 #pragma unroll
     for (int j = 0; j < ROWS * CH / 256; ++j) {
         const int idx = j * 256 + threadIdx.x;
