@@ -76,7 +76,7 @@ def extract_layers(net):
 # A/B switches (environment).  ISX_CONV1X1=0 sends the 1x1 trunk convolutions back to MIOpen.  ISX_CONV3X3: "auto"
 # (default) runs the implicit-GEMM kernel where it wins on MI355X -- Cin <= 128, the wide-image layers whose separate
 # epilogue pass costs as much as a fifth of the convolution (measured at B = 1024: 64->64 @56 2.08 vs 2.55 ms,
-# 128->128 @56/2 2.01 vs 2.23; from Cin = 256 on MIOpen's igemm + epilogue is 3-5 % faster) -- "1" everywhere, "0" never.
+# 128->128 @56/2 2.01 vs 2.23; from Cin = 256 on MIOpen's igemm + epilogue is 3-5 % faster) -- "1" everywhere, "0" never, an integer N > 1: Cin <= N.
 _CONV3X3_MODE = os.environ.get("ISX_CONV3X3", "auto")
 _IMPLICIT_GEMM_3X3 = _CONV3X3_MODE != "0"
 _GEMM_1X1 = os.environ.get("ISX_CONV1X1", "1") != "0"
@@ -106,7 +106,7 @@ class _ConvBiasAct(nn.Module):
         c = self.conv
         return (_IMPLICIT_GEMM_3X3 and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.groups == 1 and c.dilation == (1, 1)
                 and c.stride in ((1, 1), (2, 2)) and c.in_channels % 32 == 0
-                and (_CONV3X3_MODE == "1" or c.in_channels <= 128))
+                and (_CONV3X3_MODE == "1" or c.in_channels <= (int(_CONV3X3_MODE) if _CONV3X3_MODE.isdigit() and int(_CONV3X3_MODE) > 1 else 128)))
 
     def forward(self, x, residual=None):
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self._three_by_three()
