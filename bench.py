@@ -3,8 +3,8 @@
 
 Workload (BASELINE configs[1], "ResNet-50 fully-conv global descriptors, 10k-image synthetic
 gallery"): one STEP = one batch of synthetic 224x224 images through the whole path
-    images --ResNet-50 convs (PyTorch-ROCm / MIOpen)--> (B,2048,7,7) feature map
-           --isx_gap_l2 (HIP)--> L2-normalised 2048-d descriptors
+    images --ResNet-50 trunk (fp32; 1x1 / wide 3x3 convolutions + every epilogue: libisx, rest: MIOpen)-->
+           (B,2048,7,7) feature map --isx_gap_l2 (HIP)--> L2-normalised 2048-d descriptors
            --[N>1: RCCL all-gather of the query descriptors]--
            --isx_cosine_sim (fp32 MFMA) + isx_topk_rows (HIP) against this rank's gallery shard-->
            --[N>1: RCCL all-gather of per-shard top-k + isx_topk_merge]--> ranked top-100 lists
@@ -12,26 +12,29 @@ Inputs (images, gallery slab) are resident in HBM before the timed region.  Weak
 rank extracts B images and holds a 10k-row gallery shard.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8                      # self-launching: starts torch.distributed.run itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
            --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
 
-Rank 0 prints ONE JSON line (metric / value / roofline / cpu_baseline ...).
+Rank 0 prints ONE JSON line (metric / value / roofline / cpu_baseline ...).  The K timed steps carry no
+per-kernel instrumentation; the per-kernel HIP-event timings behind the `roofline*` objects come from a
+separate instrumented pass over the same step.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-PEAK_F16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md)
+PEAK_F16_MFMA_TFLOPS = 2500.0    # dense fp16/bf16 MFMA peak of one MI355X (MI355X_MICROARCH.md)
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_GBS = 8000.0            # HBM3E spec
+RESNET50_GFLOP_PER_IMAGE = 8.17  # 2 x 4.087 GMAC, convolutions of the 224x224 trunk (SURVEY 8d: ~8.2)
 
 
 def parse():
@@ -46,17 +49,32 @@ def parse():
     ap.add_argument("--backbone-dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = the reference's precision (default); bf16 is reported separately, never as `value`")
     ap.add_argument("--memory-format", default="channels_last", choices=["channels_last", "contiguous"],
-                    help="layout of the backbone activations (same fp32 math; MIOpen's NHWC kernels are ~9%% faster); "
-                         "isx_gap_l2 consumes either layout in place")
+                    help="layout of the backbone activations (same fp32 math); isx_gap_l2 consumes either layout in place")
     ap.add_argument("--no-fold-bn", action="store_true",
                     help="keep BatchNorm as separate kernels (default: folded into the convolutions for inference)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard-bench", action="store_true", help="skip the 10k x 125k retrieval-shard side measurement")
+    ap.add_argument("--no-kernel-pass", action="store_true", help="skip the instrumented per-kernel pass (roofline objects of the trunk)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare command line: start the N ranks as CHILD processes of a parent that has
+    not touched the GPU (no torch import yet), relay their output and exit with their code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required for RCCL across processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def build_net(name, dtype, device, channels_last=False, fold_bn=False):
+    import torch
     from isx import backbones
     from model.nn_utils import set_net_train
     from model.siamese import TuneClassif
@@ -84,23 +102,34 @@ def usable_cpus():
     return max(1, n)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, gallery_cpu, images_cpu):
-    """The reference's CPU path (torch CPU backbone, then the oracle's pooling / cosine / top-k)
-    on a bounded sample of the same workload; images/s on this box's host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
-    import oracle as O
+    """The reference's PyTorch-CPU path in modern torch on a bounded sample of the same workload:
+    fp32 eval-mode trunk -> mean over (H,W) -> x / sqrt(sum x^2 + 1e-10) -> torch.mm(q, G.t()) -> topk, every usable host
+    core.  The oracle is NOT in the timed region; it only checks the sample's ranked lists afterwards."""
+    import torch
     net = build_net(args.backbone, "f32", "cpu")
-    threads = min(usable_cpus(), 32)           # torch's conv scaling flattens out beyond a few dozen threads at this batch
+    threads = usable_cpus()
     torch.set_num_threads(threads)
-    G = gallery_cpu.numpy()
+    G = gallery_cpu
 
     def run(n):
         x = images_cpu[:n]
         with torch.no_grad():
             fmap = net.features(x)
-        q = O.gap_l2(fmap.numpy())
-        O.cosine_topk(q, G, args.k)
+            pooled = fmap.mean((2, 3))
+            q = pooled / (pooled.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()
+            sim = torch.mm(q, G.t())
+            return q, sim.topk(min(args.k, G.size(0)), dim=1)
 
     run(2)                                                  # warm caches / thread pool
     t0 = time.time(); run(4); per = (time.time() - t0) / 4
@@ -108,19 +137,48 @@ def cpu_baseline(args, gallery_cpu, images_cpu):
     passes = int(max(1, min(16, round((args.cpu_seconds - 6 * per) / max(per * nb, 1e-3)))))   # ~cpu_seconds of work
     t0 = time.time()
     for _ in range(passes):
-        run(nb)
+        q, (ts, ti) = run(nb)
     dt = time.time() - t0
     n = passes * nb
-    return {"value": n / dt, "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "%d images: torch-CPU fp32 %s features + oracle gap_l2 + oracle cosine_topk vs the %d-row gallery, %.1f s"
-                      % (n, args.backbone, G.shape[0], dt)}
+    checked = None
+    try:                                                    # checker only, outside the timing
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import numpy as np
+        import oracle as O
+        _, oi = O.cosine_topk(q[:4].numpy(), G.numpy(), min(10, G.size(0)))
+        checked = bool(np.array_equal(oi[:, 0], ti[:4, 0].numpy()))
+    except Exception:
+        pass
+    return {"value": n / dt, "unit": "images/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(),
+            "host_cpus_visible": os.cpu_count(),
+            "sample": "%d images (%d passes over %d): torch-CPU fp32 %s trunk + mean-pool + L2 + torch.mm vs the %d-row gallery + topk(%d), "
+                      "%d threads, %.1f s" % (n, passes, nb, args.backbone, G.size(0), args.k, threads, dt),
+            "top1_matches_oracle_on_sample": checked}
+
+
+def load_traffic():
+    """HBM bytes measured with rocprofv3 PMC passes on an EARLIER run of this command (profiles/roofline_traffic.json, written
+    by profiles/summarize_prof.py): a property of that profiled run, stamped with its source -- never of the run printing it."""
+    path = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import torch
+    import torch.distributed as dist
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the HIP path)")
     # debugging aid for boxes with ONE GPU: ISX_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 and uses gloo, so the N > 1 code path
@@ -128,13 +186,17 @@ def main():
     one_device = world > 1 and os.environ.get("ISX_BENCH_ONE_DEVICE", "0") == "1"
     if one_device:
         local = 0
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs cuda:%d but only %d device(s) are visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 and one_device:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    elif world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    backend = None
+    if world > 1:
+        backend = "gloo" if one_device else "nccl"
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from isx import ops, retrieval
     from utils.dataset import synthetic_descriptors, synthetic_images
@@ -157,8 +219,8 @@ def main():
     gemm_ev, gap_ev = [], []
 
     def step(timed):
-        if timed:
-            a, b = ev(), ev()
+        """One step.  `timed`: the instrumented pass (HIP events around the pool and the GEMM on torch's current stream, which
+        is the stream every libisx launch goes to)."""
         with torch.no_grad():
             if args.backbone_dtype == "bf16":
                 with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -167,7 +229,7 @@ def main():
             else:
                 fmap = net.features(images)
         if timed:
-            a.record()
+            a, b = ev(), ev(); a.record()
         ops.gap_l2(fmap, out=q_local)
         if timed:
             b.record(); gap_ev.append((a, b))
@@ -192,11 +254,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ops.KERNEL_TIMER = []                     # per-launch HIP events around the hand-written trunk convolutions
     for _ in range(args.steps):
-        out = step(True)
+        out = step(False)
     torch.cuda.synchronize()
-    trunk_timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -206,12 +266,26 @@ def main():
         dt = float(tmax.item())
     assert out[1].shape == (M, k) and int(out[1].min()) >= 0
 
-    gemm_ms = sum(a.elapsed_time(b) for a, b in gemm_ev) / len(gemm_ev)
-    gap_ms = sum(a.elapsed_time(b) for a, b in gap_ev) / len(gap_ev)
-    trunk = {}
-    for name, flop, nbytes, ea, eb in trunk_timer:
-        t = trunk.setdefault(name, [0, 0.0, 0.0, 0.0])
-        t[0] += 1; t[1] += flop; t[2] += nbytes; t[3] += ea.elapsed_time(eb)
+    # ---- instrumented pass (outside the timed region): per-launch HIP events of the hand-written kernels ----------
+    trunk, ksteps = {}, 0
+    gemm_ms = gap_ms = None
+    if not args.no_kernel_pass:
+        ksteps = max(1, min(args.steps, 5))
+        ops.KERNEL_TIMER = []
+        for _ in range(ksteps):
+            step(True)
+        torch.cuda.synchronize()
+        timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+        gemm_ms = sum(a.elapsed_time(b) for a, b in gemm_ev) / len(gemm_ev)
+        gap_ms = sum(a.elapsed_time(b) for a, b in gap_ev) / len(gap_ev)
+        for name, flop, nbytes, ea, eb in timer:
+            t = trunk.setdefault(name, {"n": 0, "flop": 0.0, "bytes": 0.0, "ms": 0.0, "floor_ms": 0.0})
+            ms_ = ea.elapsed_time(eb)
+            t["n"] += 1; t["flop"] += flop; t["bytes"] += nbytes; t["ms"] += ms_
+            # per-launch roofline floor: the slower of the MFMA time and the HBM time of that launch's algorithmic work
+            t["floor_ms"] += max(flop / (PEAK_F32_MFMA_TFLOPS * 1e9), nbytes / (PEAK_HBM_GBS * 1e6))
+        if world > 1:
+            dist.barrier()
     gemm_flop = 2.0 * M * Ng * D
     gap_bytes = B * D * 49 * 4 + B * D * 4
 
@@ -253,16 +327,15 @@ def main():
         assert ri.shape == (Ms, k) and int(ri.min()) >= 0 and int(ri.max()) < Ns * world
         flop = 2.0 * Ms * Ns * world * D
         return {"shape": [Ms, Ns * world, D], "gallery_rows_per_gpu": Ns, "k": k, "ms": ms,
-                        "dist_per_s": Ms * Ns * world / (ms * 1e-3),
-                        "tflops_end_to_end": flop / (ms * 1e-3) / 1e12,
-                        "frac_of_f16_mfma_peak": flop / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS * world),
-                        "path": "isx_cosine_topk_fast (fp16-MFMA filter + exact fp32 re-scoring, bit-identical results)",
-                        "fp32_path": {"ms": ms32, "dist_per_s": Ms * Ns * world / (ms32 * 1e-3),
-                                      "tflops_end_to_end": flop / (ms32 * 1e-3) / 1e12,
-                                      "frac_of_f32_mfma_peak": flop / (ms32 * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
-                        "identical_to_fp32_path": identical,
-                        "includes": "local top-k" + (" + RCCL all-gather of per-shard top-k + isx_topk_merge" if world > 1 else "")}
-
+                "dist_per_s": Ms * Ns * world / (ms * 1e-3),
+                "tflops_end_to_end": flop / (ms * 1e-3) / 1e12,
+                "frac_of_f16_mfma_peak": flop / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS * world),
+                "path": "isx_cosine_topk_fast (fp16-MFMA filter + exact fp32 re-scoring, bit-identical results)",
+                "fp32_path": {"ms": ms32, "dist_per_s": Ms * Ns * world / (ms32 * 1e-3),
+                              "tflops_end_to_end": flop / (ms32 * 1e-3) / 1e12,
+                              "frac_of_f32_mfma_peak": flop / (ms32 * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
+                "identical_to_fp32_path": identical,
+                "includes": "local top-k" + (" + %s all-gather of per-shard top-k + isx_topk_merge" % ("RCCL" if backend == "nccl" else backend) if world > 1 else "")}
 
     if not args.no_shard_bench:
         if world > 1:
@@ -276,38 +349,80 @@ def main():
 
     if rank == 0:
         images_per_s = world * B * args.steps / dt
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(prof):
-            try:
-                traffic = json.load(open(prof)).get("cosine_gemm_kernel", {}).get("%dx%dx%d" % (M, Ng, D))
-            except Exception:
-                traffic = None
+        ms_per_step = 1000.0 * dt / args.steps
+        traffic = load_traffic()
+        tsrc = traffic.get("source")
+
+        def traffic_of(key, sub=None):
+            e = traffic.get("kernels", {}).get(key)
+            if isinstance(e, dict) and sub is not None:
+                e = e.get(sub)
+            return e
+
         line = {
             "metric": "images/sec descriptor extract + query x gallery search",
             "value": images_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: ResNet-50 fully-conv global descriptors + top-%d cosine search, "
                                    "%d-row gallery shard per GPU, 224x224 synthetic images" % (k, Ng),
                        "images_per_gpu_per_step": B, "gallery_rows_per_gpu": Ng, "descriptor_dim": D, "k": k,
-                       "backbone": args.backbone, "backbone_dtype": args.backbone_dtype, "activation_layout": "NHWC" if cl else "NCHW", "bn_folded": not args.no_fold_bn, "parallelism": "gallery-row shards x%d + DP extraction" % world},
+                       "backbone": args.backbone, "backbone_dtype": args.backbone_dtype, "activation_layout": "NHWC" if cl else "NCHW",
+                       "bn_folded": not args.no_fold_bn, "parallelism": "gallery-row shards x%d + DP extraction" % world,
+                       "collective_backend": backend, "ranks": world},
             "dist_per_s": images_per_s * Ng * world,
-            "roofline": {"kernel": "cosine_gemm_kernel (isx_cosine_sim, v_mfma_f32_32x32x2_f32)", "bound": "mfma",
-                         "achieved": gemm_flop / (gemm_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": gemm_flop / (gemm_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                         "launch_ms": gemm_ms, "algorithmic_flop_per_launch": gemm_flop, "shape": [M, Ng, D]},
-            "roofline_gap_l2": {"kernel": "gap_l2_nhwc_kernel (isx_gap_l2_nhwc)" if cl else "gap_l2_kernel (isx_gap_l2)", "bound": "hbm", "achieved": gap_bytes / (gap_ms * 1e-3) / 1e9,
-                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gap_bytes / (gap_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                "launch_ms": gap_ms, "algorithmic_bytes_per_launch": gap_bytes},
         }
-        for name, (cnt, flop, nbytes, ms_) in sorted(trunk.items()):
-            # all launches of one hand-written trunk kernel over the timed steps: algorithmic FLOP (and bytes) / summed HIP-event time
-            line["roofline_" + name] = {"kernel": name + (" = cosine_gemm_kernel<EPI=2>" if "1x1" in name else " = conv3x3_nhwc_kernel") +
-                                        " (v_mfma_f32_32x32x2_f32, bias/residual/ReLU fused)", "bound": "mfma",
-                                        "achieved": flop / (ms_ * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": flop / (ms_ * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "launches_per_step": cnt // args.steps,
-                                        "ms_per_step": ms_ / args.steps, "algorithmic_GBps": nbytes / (ms_ * 1e-3) / 1e9}
+        # whole step against the fp32 matrix-core peak (ResNet-50 convolutions + the distance GEMM; pooling / top-k are bytes, not FLOP)
+        step_flop = RESNET50_GFLOP_PER_IMAGE * 1e9 * B + gemm_flop if args.backbone == "resnet50" else None
+        if step_flop:
+            line["roofline_step"] = {"bound": "mfma", "achieved": step_flop / (ms_per_step * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                                     "unit": "TFLOP/s", "frac": step_flop / (ms_per_step * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                     "algorithmic_flop_per_step_per_gpu": step_flop,
+                                     "note": "%.2f GFLOP per image (ResNet-50 convolutions) x %d images + 2*M*N*D of the search" % (RESNET50_GFLOP_PER_IMAGE, B)}
+        fam = {}
+        kernel_names = {
+            "isx_conv1x1_nhwc": "gemm_nt_kernel<EPI_CONV> (isx_conv1x1_nhwc: 1x1 convolutions as one fp32-MFMA GEMM over the pixels, bias/residual/ReLU fused)",
+            "isx_conv1x1_dual_nhwc": "conv1x1_dual_nhwc_kernel (isx_conv1x1_dual_nhwc: last 1x1 conv + projection shortcut as one GEMM)",
+            "isx_conv3x3_nhwc": "conv3x3_nhwc_kernel (isx_conv3x3_nhwc: implicit GEMM, bias/residual/ReLU fused)",
+        }
+        for name, t in sorted(trunk.items()):
+            mf = t["flop"] / (t["ms"] * 1e-3) / 1e12
+            hb = t["bytes"] / (t["ms"] * 1e-3) / 1e9
+            mfma_bound = t["flop"] / (PEAK_F32_MFMA_TFLOPS * 1e12) >= t["bytes"] / (PEAK_HBM_GBS * 1e9)
+            o = {"kernel": kernel_names.get(name, name), "bound": "mfma" if mfma_bound else "hbm",
+                 "achieved": mf if mfma_bound else hb, "peak": PEAK_F32_MFMA_TFLOPS if mfma_bound else PEAK_HBM_GBS,
+                 "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                 "frac": (mf / PEAK_F32_MFMA_TFLOPS) if mfma_bound else (hb / PEAK_HBM_GBS),
+                 "traffic": traffic_of(name), "traffic_source": tsrc if traffic_of(name) is not None else None,
+                 "launches_per_step": t["n"] // ksteps, "ms_per_step": t["ms"] / ksteps,
+                 "algorithmic_flop_per_step": t["flop"] / ksteps, "algorithmic_bytes_per_step": t["bytes"] / ksteps,
+                 "achieved_tflops": mf, "algorithmic_GBps": hb,
+                 # sum over launches of max(MFMA time, HBM time) / measured time: counts the HBM-bound layers of the family honestly
+                 "frac_of_per_launch_rooflines": t["floor_ms"] / t["ms"],
+                 "timing": "HIP events on the launch stream, %d instrumented steps after the timed region" % ksteps}
+            fam[name] = o
+        if gemm_ms is not None:
+            tr = traffic_of("cosine_gemm", "%dx%dx%d" % (M, Ng, D))
+            fam["cosine_gemm"] = {"kernel": "gemm_nt_kernel<EPI_STORE> (isx_cosine_sim)", "bound": "mfma",
+                                  "achieved": gemm_flop / (gemm_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": gemm_flop / (gemm_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                  "traffic": tr, "traffic_source": tsrc if tr is not None else None,
+                                  "launch_ms": gemm_ms, "algorithmic_flop_per_launch": gemm_flop, "shape": [M, Ng, D]}
+            tr = traffic_of("gap_l2", str(B))
+            fam["gap_l2"] = {"kernel": "gap_l2_nhwc_kernel (isx_gap_l2_nhwc)" if cl else "gap_l2_kernel (isx_gap_l2)", "bound": "hbm",
+                             "achieved": gap_bytes / (gap_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": gap_bytes / (gap_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": tr,
+                             "traffic_source": tsrc if tr is not None else None,
+                             "launch_ms": gap_ms, "algorithmic_bytes_per_launch": gap_bytes}
+        # `roofline` = the hand-written kernel family with the largest share of the step
+        share = lambda o: o.get("ms_per_step", o.get("launch_ms", 0.0))
+        if fam:
+            dom = max(fam, key=lambda n: share(fam[n]))
+            line["roofline"] = dict(fam[dom], share_of_step=share(fam[dom]) / ms_per_step, family=dom)
+            for n, o in fam.items():
+                line["roofline_" + n] = o
+        else:
+            line["roofline"] = None
         if shard_result is not None:
             line["retrieval_shard"] = shard_result
         if world == 1 and not args.no_cpu_baseline:
@@ -315,7 +430,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args, shard.cpu(), images_cpu)
             except Exception as e:
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -244,6 +244,12 @@ int isx_shard_topk_allgather(void* comm, const float* s_local, const int64_t* i_
 int isx_mine_negatives(const float* sim, int64_t N, const int32_t* labels, const int64_t* i1, const int64_t* i2,
                        int64_t n_couples, int semi_hard, int64_t* neg, isx_stream_t stream);
 
+/* The same mining when the N x N matrix is never built whole (it exceeds the memory budget the reference answers with a CPU
+ * fallback, utils/train_siamese.py:30-43): sim_rows = rows [row_base, row_base + rows) of the matrix, row-major with
+ * stride N; every anchor i1[c] lies inside that range; i1 / i2 / neg are absolute gallery indices. */
+int isx_mine_negatives_rows(const float* sim_rows, int64_t N, int64_t row_base, int64_t rows, const int32_t* labels,
+                            const int64_t* i1, const int64_t* i2, int64_t n_couples, int semi_hard, int64_t* neg, isx_stream_t stream);
+
 /* model/custom_modules.py:153-171 TripletLossFun.forward, per-row part: loss_rows[b] = max(0, l_b) with
  * l_b = a.n - a.p + margin (normalized) or (|a-p|^2 - |a-n|^2 + 2 margin)/2.  The caller sums the rows
  * (and divides by B for size_average).  anchor, pos, neg: (B,D). */

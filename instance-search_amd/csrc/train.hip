@@ -11,13 +11,14 @@ namespace isx {
 // similar than the positive.  Excluded entries are treated as -2 exactly like the reference
 // (`sims[ind_exl] = -2; sims.max(0)`), ties go to the smallest index; -1 = every item excluded
 // (the caller falls back to a random negative, reference :100-107,129-131).
-__global__ __launch_bounds__(256) void mine_negatives_kernel(const float* __restrict__ sim, int64_t N,
+// sim holds rows [row_base, row_base + rows) of the N x N matrix (row_base = 0, rows = N: the whole matrix).
+__global__ __launch_bounds__(256) void mine_negatives_kernel(const float* __restrict__ sim, int64_t N, int64_t row_base,
                                                              const int32_t* __restrict__ lab, const int64_t* __restrict__ i1,
                                                              const int64_t* __restrict__ i2, int semi_hard,
                                                              int64_t* __restrict__ neg) {
     __shared__ uint64_t red[4];
     const int64_t a = i1[blockIdx.x], p = i2[blockIdx.x];
-    const float* row = sim + a * N;
+    const float* row = sim + (a - row_base) * N;
     const float sim_pos = row[p];
     const int32_t la = lab[a];
     uint64_t best = 0;
@@ -85,8 +86,21 @@ ISX_API int isx_mine_negatives(const float* sim, int64_t N, const int32_t* label
     ISX_REQUIRE(N > 0 && N <= 0xFFFFFFFFll && n_couples >= 0 && n_couples < (1ll << 31), "isx_mine_negatives: bad shape N=%lld couples=%lld", (long long)N, (long long)n_couples);
     if (n_couples == 0) return ISX_OK;
     ISX_REQUIRE(sim && labels && i1 && i2 && neg, "isx_mine_negatives: null pointer");
-    hipLaunchKernelGGL(mine_negatives_kernel, dim3((unsigned)n_couples), dim3(256), 0, (hipStream_t)stream, sim, N, labels, i1, i2, semi_hard, neg);
+    hipLaunchKernelGGL(mine_negatives_kernel, dim3((unsigned)n_couples), dim3(256), 0, (hipStream_t)stream, sim, N, (int64_t)0, labels, i1, i2, semi_hard, neg);
     ISX_CHECK_LAUNCH("isx_mine_negatives");
+    return ISX_OK;
+}
+
+// The same mining on a BLOCK of anchor rows: sim_rows = rows [row_base, row_base + rows) of the N x N matrix, every i1[c] inside
+// that range (the caller's contract; i1 / i2 stay absolute indices).  For similarity matrices that are never built whole.
+ISX_API int isx_mine_negatives_rows(const float* sim_rows, int64_t N, int64_t row_base, int64_t rows, const int32_t* labels, const int64_t* i1,
+                                    const int64_t* i2, int64_t n_couples, int semi_hard, int64_t* neg, isx_stream_t stream) {
+    ISX_REQUIRE(N > 0 && N <= 0xFFFFFFFFll && n_couples >= 0 && n_couples < (1ll << 31) && row_base >= 0 && rows >= 0 && row_base + rows <= N,
+                "isx_mine_negatives_rows: bad shape N=%lld row_base=%lld rows=%lld couples=%lld", (long long)N, (long long)row_base, (long long)rows, (long long)n_couples);
+    if (n_couples == 0) return ISX_OK;
+    ISX_REQUIRE(sim_rows && labels && i1 && i2 && neg && rows > 0, "isx_mine_negatives_rows: null pointer or empty block");
+    hipLaunchKernelGGL(mine_negatives_kernel, dim3((unsigned)n_couples), dim3(256), 0, (hipStream_t)stream, sim_rows, N, row_base, labels, i1, i2, semi_hard, neg);
+    ISX_CHECK_LAUNCH("isx_mine_negatives_rows");
     return ISX_OK;
 }
 

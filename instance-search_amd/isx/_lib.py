@@ -49,6 +49,7 @@ _SIGNATURES = {
     "isx_masked_sums": (C.c_int, [VP, I64, I64, VP, VP, VP, VP]),
     "isx_topk_merge": (C.c_int, [VP, VP, I32, I64, I32, VP, VP, VP]),
     "isx_mine_negatives": (C.c_int, [VP, I64, VP, VP, VP, I64, I32, VP, VP]),
+    "isx_mine_negatives_rows": (C.c_int, [VP, I64, I64, I64, VP, VP, VP, I64, I32, VP, VP]),
     "isx_triplet_loss_fwd": (C.c_int, [VP, VP, VP, I64, I32, F32, I32, VP, VP]),
     "isx_triplet_loss_bwd": (C.c_int, [VP, VP, VP, VP, I64, I32, F32, I32, VP, VP, VP, VP]),
     "isx_comm_unique_id_bytes": (C.c_int, []),

@@ -10,9 +10,25 @@ buckets of `bucket_mb`; a bucket's all-reduce is launched asynchronously from th
 last of its parameters on the FINAL micro-batch, so the exchange of early buckets overlaps the rest of
 the backward pass.  xGMI is point-to-point (7 links x ~153 GB/s per GPU): ~0.9 GB of ResNet-50 +
 Linear(100352, 2048) gradients is ~10 ms on one ring, so few, large buckets are used (default 256 MB).
+
+Collective discipline: every rank issues exactly one all-reduce per bucket per step, ALWAYS in bucket order
+0, 1, 2, ... -- whether a bucket was launched early from a hook (armed ranks) or from finish() (a rank whose
+slice of the mini-batch was empty never arms; parameters no backward touched never fire a hook).  RCCL matches
+collectives by issue order, so the order must not depend on what a rank happened to compute.
 """
 import torch
 import torch.distributed as dist
+
+
+def broadcast_module_state(module, src=0, group=None):
+    """Make every replica start from rank `src`'s parameters AND buffers (BatchNorm statistics, counters).
+    Without this each process keeps its own random initialisation of the layers that are not loaded from a file
+    (the descriptor head) and the summed gradient is applied to different weights."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in module.state_dict().values():          # state_dict tensors share storage with the module
+            dist.broadcast(t, src=src, group=group)
 
 
 class GradAllReducer(object):
@@ -29,9 +45,9 @@ class GradAllReducer(object):
         self.slices = {}
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
             self.slices[p] = (off, off + n)
             off += n
+        self._attach_all()
         cap = max(1, int(bucket_mb * (1 << 20) // 4))
         self.buckets, cur, size = [], [], 0
         for p in reversed(self.params):
@@ -43,44 +59,75 @@ class GradAllReducer(object):
         if cur:
             self.buckets.append(cur)
         self.bucket_of = {p: b for b, ps in enumerate(self.buckets) for p in ps}
+        self.ranges = [(min(self.slices[q][0] for q in ps), max(self.slices[q][1] for q in ps)) for ps in self.buckets]
         self.pending = [0] * len(self.buckets)
+        self.next_bucket = 0              # buckets [0, next_bucket) of this step have been issued
         self.handles = []
         self.armed = False
         if self.world > 1:
             for p in self.params:
                 p.register_post_accumulate_grad_hook(self._hook)
 
+    # -- the gradients must stay views of the flat buffer ------------------------------------------------------
+    def _view(self, p):
+        lo, hi = self.slices[p]
+        return self.flat[lo:hi].view_as(p)
+
+    def _is_view(self, p):
+        lo, _ = self.slices[p]
+        return p.grad is not None and p.grad.data_ptr() == self.flat.data_ptr() + 4 * lo and p.grad.dtype == torch.float32
+
+    def _reattach(self, p):
+        """`optimizer.zero_grad(set_to_none=True)` or `p.grad = None` elsewhere detaches a gradient from the flat buffer;
+        autograd then accumulates into a fresh tensor the exchange would never see.  Fold it back in."""
+        if self._is_view(p):
+            return
+        v = self._view(p)
+        if p.grad is not None:
+            v.copy_(p.grad)                 # this step's gradient so far lives in the stray tensor
+        p.grad = v
+
+    def _attach_all(self):
+        for p in self.params:
+            self._reattach(p)
+
     def zero_grad(self):
+        self._attach_all()
         self.flat.zero_()
 
+    # -- exchange ---------------------------------------------------------------------------------------------
     def arm(self):
         """Call before the backward of the LAST micro-batch of a step: buckets are exchanged as they fill."""
         self.pending = [len(ps) for ps in self.buckets]
-        self.handles = []
         self.armed = self.world > 1
+
+    def _issue_ready(self, upto_complete_only):
+        """Issue the all-reduce of every not-yet-issued bucket, in bucket order; with `upto_complete_only` stop at the
+        first bucket that still waits for gradients."""
+        while self.next_bucket < len(self.buckets):
+            b = self.next_bucket
+            if upto_complete_only and self.pending[b] > 0:
+                break
+            lo, hi = self.ranges[b]
+            self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.next_bucket += 1
 
     def _hook(self, p):
         if not self.armed:
             return
+        self._reattach(p)
         b = self.bucket_of[p]
         self.pending[b] -= 1
         if self.pending[b] == 0:
-            lo = min(self.slices[q][0] for q in self.buckets[b])
-            hi = max(self.slices[q][1] for q in self.buckets[b])
-            self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._issue_ready(True)
 
     def finish(self):
-        """Wait for the exchange (and exchange whatever the hooks did not cover, e.g. unused parameters)."""
+        """Issue whatever the hooks did not (unarmed rank, unused parameters), wait for the exchange."""
         if self.world > 1:
-            if self.armed:
-                for b, left in enumerate(self.pending):
-                    if left > 0:
-                        lo = min(self.slices[q][0] for q in self.buckets[b])
-                        hi = max(self.slices[q][1] for q in self.buckets[b])
-                        self.handles.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            else:
-                self.handles.append(dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._attach_all()
+            self._issue_ready(False)
             for h in self.handles:
                 h.wait()
         self.armed = False
         self.handles = []
+        self.next_bucket = 0

@@ -14,17 +14,27 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _on_current_device(t, name):
+    """Launches go to the CURRENT device's current stream: a tensor of another GPU would be touched from the wrong
+    device / stream, so it is refused (select the device with torch.cuda.device(...) around the call)."""
+    if t.device.index != torch.cuda.current_device():
+        raise _lib.IsxError("%s lives on %s but the current device is cuda:%d -- wrap the call in torch.cuda.device(%s)"
+                            % (name, t.device, torch.cuda.current_device(), t.device.index))
+
+
 def _f32(t, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise _lib.IsxError("%s must be a CUDA tensor (libisx has no CPU path)" % name)
     if t.dtype != torch.float32:
         raise _lib.IsxError("%s must be float32, got %s" % (name, t.dtype))
+    _on_current_device(t, name)
     return t.contiguous()
 
 
 def _typed(t, dtype, name):
     if not (isinstance(t, torch.Tensor) and t.is_cuda):
         raise _lib.IsxError("%s must be a CUDA tensor" % name)
+    _on_current_device(t, name)
     return t.to(dtype).contiguous()
 
 
@@ -56,6 +66,7 @@ def gap_l2(fmap, eps=EPS, out=None):
         raise _lib.IsxError("fmap must be a CUDA tensor (libisx has no CPU path)")
     if fmap.dtype != torch.float32:
         raise _lib.IsxError("fmap must be float32, got %s" % (fmap.dtype,))
+    _on_current_device(fmap, "fmap")
     B, Cc, H, W = fmap.shape
     y = torch.empty((B, Cc), device=fmap.device, dtype=torch.float32) if out is None else out
     assert y.is_contiguous() and y.shape == (B, Cc)
@@ -73,6 +84,7 @@ def bias_act_(y, bias, residual=None, relu=True):
     memory (the residual must share y's memory format)."""
     if not (y.is_cuda and y.dtype == torch.float32):
         raise _lib.IsxError("y must be a float32 CUDA tensor")
+    _on_current_device(y, "y")
     B, Cc, H, W = y.shape
     if y.is_contiguous():
         inner = H * W
@@ -94,6 +106,7 @@ def images_u8_to_f32(img_u8, mean, std, channels_last=True):
     """ToTensor + Normalize on the GPU: (B,H,W,3) uint8 RGB -> (B,3,H,W) fp32 (channels-last memory by default)."""
     if not (img_u8.is_cuda and img_u8.dtype == torch.uint8 and img_u8.dim() == 4 and img_u8.shape[3] == 3 and img_u8.is_contiguous()):
         raise _lib.IsxError("img_u8 must be a contiguous (B,H,W,3) uint8 CUDA tensor")
+    _on_current_device(img_u8, "img_u8")
     B, H, W, _ = img_u8.shape
     out = torch.empty((B, 3, H, W), device=img_u8.device, dtype=torch.float32,
                       memory_format=torch.channels_last if channels_last else torch.contiguous_format)
@@ -123,6 +136,7 @@ def bias_relu_maxpool(y, bias):
     """relu(y + bias[c]) -> MaxPool2d(3, 2, 1) of a channels-last (B,C,H,W) fp32 tensor in one pass."""
     if not (y.is_cuda and y.dtype == torch.float32 and y.dim() == 4 and y.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.IsxError("y must be a channels-last float32 CUDA tensor (B,C,H,W)")
+    _on_current_device(y, "y")
     B, Cc, H, W = y.shape
     out = torch.empty((B, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=y.device, dtype=torch.float32, memory_format=torch.channels_last)
     check(lib().isx_bias_relu_maxpool_nhwc(y.data_ptr(), _f32(bias, "bias").data_ptr(), B, H, W, Cc, out.data_ptr(), _stream()),
@@ -136,6 +150,7 @@ def conv1x1_nhwc(x, weight, bias, residual=None, relu=True):
     Returns a channels-last (B,Cout,H,W) tensor."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.IsxError("x must be a channels-last float32 CUDA tensor (B,C,H,W)")
+    _on_current_device(x, "x")
     B, Cin, H, W = x.shape
     w = _f32(weight.reshape(weight.shape[0], -1), "weight")
     Cout = w.shape[0]
@@ -160,6 +175,7 @@ def conv1x1_dual_nhwc(t, x, w_cat, bias, stride=1, relu=True):
     for a, n in ((t, "t"), (x, "x")):
         if not (a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last)):
             raise _lib.IsxError(n + " must be a channels-last float32 CUDA tensor (B,C,H,W)")
+        _on_current_device(a, n)
     B, K2, H, W = x.shape
     K1 = t.shape[1]
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
@@ -171,7 +187,7 @@ def conv1x1_dual_nhwc(t, x, w_cat, bias, stride=1, relu=True):
         raise _lib.IsxError("w_cat must be (Cout, K1 + K2)")
     y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     bp, px = _f32(bias, "bias").data_ptr(), B * Ho * Wo
-    _timed("isx_conv1x1_nhwc", 2.0 * px * (K1 + K2) * Cout, 4.0 * (px * (K1 + K2) + px * Cout + (K1 + K2) * Cout),
+    _timed("isx_conv1x1_dual_nhwc", 2.0 * px * (K1 + K2) * Cout, 4.0 * (px * (K1 + K2) + px * Cout + (K1 + K2) * Cout),
            lambda: check(lib().isx_conv1x1_dual_nhwc(t.data_ptr(), K1, x.data_ptr(), B, H, W, K2, stride, w.data_ptr(), Cout, bp,
                                                      1 if relu else 0, y.data_ptr(), _stream()), "isx_conv1x1_dual_nhwc"))
     return y
@@ -182,6 +198,7 @@ def conv3x3_nhwc(x, w_ohwi, bias, stride=1, residual=None, relu=True):
     w_ohwi: (Cout,3,3,Cin) contiguous (= conv.weight.permute(0,2,3,1)).  Returns channels-last (B,Cout,Ho,Wo)."""
     if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
         raise _lib.IsxError("x must be a channels-last float32 CUDA tensor (B,C,H,W)")
+    _on_current_device(x, "x")
     B, Cin, H, W = x.shape
     w = _f32(w_ohwi, "w_ohwi")
     Cout = w.shape[0]
@@ -438,17 +455,23 @@ def shard_topk_allgather(comm, nranks, s_local, i_local):
 
 
 # ---- training step -----------------------------------------------------------------------
-def mine_negatives(sim, labels, i1, i2, semi_hard):
-    """neg index per positive couple (int64, -1 = none available)."""
+def mine_negatives(sim, labels, i1, i2, semi_hard, row_base=0):
+    """neg index per positive couple (int64, -1 = none available).  sim: the N x N matrix, or rows
+    [row_base, row_base + sim.size(0)) of it (every anchor i1 inside that range; i1 / i2 are absolute indices)."""
     sim = _f32(sim, "sim")
-    N = sim.size(0)
-    assert sim.shape == (N, N)
+    rows, N = sim.shape
     labels = _typed(labels, torch.int32, "labels")
     i1 = _typed(i1, torch.int64, "i1")
     i2 = _typed(i2, torch.int64, "i2")
     neg = torch.empty_like(i1)
-    check(lib().isx_mine_negatives(sim.data_ptr(), N, labels.data_ptr(), i1.data_ptr(), i2.data_ptr(), i1.numel(),
-                                   1 if semi_hard else 0, neg.data_ptr(), _stream()), "isx_mine_negatives")
+    if rows == N and row_base == 0:
+        check(lib().isx_mine_negatives(sim.data_ptr(), N, labels.data_ptr(), i1.data_ptr(), i2.data_ptr(), i1.numel(),
+                                       1 if semi_hard else 0, neg.data_ptr(), _stream()), "isx_mine_negatives")
+        return neg
+    if i1.numel() and not (int(i1.min()) >= row_base and int(i1.max()) < row_base + rows):
+        raise _lib.IsxError("mine_negatives: anchors outside the row block [%d, %d)" % (row_base, row_base + rows))
+    check(lib().isx_mine_negatives_rows(sim.data_ptr(), N, row_base, rows, labels.data_ptr(), i1.data_ptr(), i2.data_ptr(), i1.numel(),
+                                        1 if semi_hard else 0, neg.data_ptr(), _stream()), "isx_mine_negatives_rows")
     return neg
 
 

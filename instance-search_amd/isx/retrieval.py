@@ -156,7 +156,7 @@ class ShardedGallery(object):
                 self._fb_host.copy_(cnt, non_blocking=True)
                 self._fb_rows = Q.size(0)
                 self._fb_event = torch.cuda.Event()
-                self._fb_event.record()
+                self._fb_event.record(torch.cuda.current_stream(self.shard.device))
         return out
 
     def search(self, Q, k):

@@ -72,19 +72,21 @@ def load_slab(path, device="cpu", rows=None):
     if dev.type == "cpu":
         out = torch.from_numpy(np.array(mm))
     else:
-        out = torch.empty((n, D), dtype=torch.float32, device=dev)
-        stage = [torch.empty((min(CHUNK_ROWS, max(n, 1)), D), dtype=torch.float32).pin_memory() for _ in range(2)]
-        events = [None, None]
-        for c, r0 in enumerate(range(0, n, CHUNK_ROWS)):
-            r1 = min(r0 + CHUNK_ROWS, n)
-            b = c & 1
-            if events[b] is not None:
-                events[b].synchronize()                     # the previous copy out of this buffer is done
-            stage[b][: r1 - r0].copy_(torch.from_numpy(np.ascontiguousarray(mm[r0:r1])))
-            out[r0:r1].copy_(stage[b][: r1 - r0], non_blocking=True)
-            events[b] = torch.cuda.Event()
-            events[b].record()
-        torch.cuda.synchronize(dev)
+        with torch.cuda.device(dev):                        # copies, events and the final sync all on the TARGET device's stream
+            out = torch.empty((n, D), dtype=torch.float32, device=dev)
+            stage = [torch.empty((min(CHUNK_ROWS, max(n, 1)), D), dtype=torch.float32).pin_memory() for _ in range(2)]
+            events = [None, None]
+            copy_stream = torch.cuda.current_stream(dev)
+            for c, r0 in enumerate(range(0, n, CHUNK_ROWS)):
+                r1 = min(r0 + CHUNK_ROWS, n)
+                b = c & 1
+                if events[b] is not None:
+                    events[b].synchronize()                 # the previous copy out of this buffer is done
+                stage[b][: r1 - r0].copy_(torch.from_numpy(np.ascontiguousarray(mm[r0:r1])))
+                out[r0:r1].copy_(stage[b][: r1 - r0], non_blocking=True)
+                events[b] = torch.cuda.Event()
+                events[b].record(copy_stream)
+            torch.cuda.synchronize(dev)
     labels = None
     if info["has_labels"]:
         lm = np.memmap(path, dtype=np.int32, mode="r", offset=info["label_offset"] + lo * 4, shape=(n,)) if n else np.zeros((0,), np.int32)

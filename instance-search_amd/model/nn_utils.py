@@ -216,6 +216,17 @@ class _FusedBlock(nn.Module):
         return self.convs[-1](y, idt)
 
 
+class _ChannelsLastEntry(nn.Module):
+    """First module of a folded trunk: a GPU fp32 image batch enters in channels-last memory, so that every activation
+    behind it is the row-major (pixels, channels) matrix the hand-written convolution kernels (and MIOpen's NHWC kernels)
+    consume.  Same values, another memory format; the 3-channel input is the only tensor ever converted."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and not torch.is_grad_enabled():
+            return x.contiguous(memory_format=torch.channels_last)
+        return x
+
+
 def fold_batch_norm(features, fuse_epilogues=True):
     """Inference-only copy of a `features` trunk with every eval-mode BatchNorm2d folded into the
     convolution in front of it (w' = w * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps)).
@@ -260,6 +271,8 @@ def fold_batch_norm(features, fuse_epilogues=True):
             continue
         out.append(fold_block(m) if isinstance(m, (models.Bottleneck, models.BasicBlock)) else copy.deepcopy(m))
         i += 1
+    if fuse_epilogues:
+        out.insert(0, _ChannelsLastEntry())
     return nn.Sequential(*out).eval()
 
 

@@ -115,15 +115,21 @@ class _FrozenTrunk(object):
     def __call__(self, features, x):
         if not (x.is_cuda and x.dtype == torch.float32 and _frozen(features)):
             return features(x)
-        if any(isinstance(m, nn.BatchNorm2d) and m.training for m in features.modules()):
+        if _bn_training(features):
             return features(x)                      # BN statistics are being updated: keep the plain trunk
-        key = (id(features), str(x.device))
+        # the folded copy is stale as soon as any weight or BN buffer under `features` is written in place
+        # (load_state_dict, manual surgery): the tensors' version counters are part of the key
+        key = (id(features), str(x.device), tuple(t._version for t in features.state_dict().values()))
         if self.folded is None or self.key != key:
             from .nn_utils import fold_batch_norm
             self.folded = fold_batch_norm(features).to(x.device).to(memory_format=torch.channels_last)
             self.key = key
         with torch.no_grad():
             return self.folded(x.contiguous(memory_format=torch.channels_last))
+
+
+def _bn_training(features):
+    return any(isinstance(m, nn.BatchNorm2d) and m.training for m in features.modules())
 
 
 def _many(forward_single, xs):
@@ -167,13 +173,16 @@ class DescriptorNet(nn.Module):
         return self.feature_reduc2(_apply_head(self.feature_reduc1, x))
 
     def forward(self, x1, x2=None, x3=None):
-        # the reference runs one trunk pass per branch (model/siamese.py:124-130); the branches share the weights and
-        # BN is in eval mode, so they go through together here
-        if self.training and x3 is not None:
-            return _many(self.forward_single, [x1, x2, x3])
-        if self.training:
-            return _many(self.forward_single, [x1, x2])
-        return self.forward_single(x1)
+        # the reference runs one trunk pass per branch (model/siamese.py:124-130); the branches share the weights, so with
+        # BN in eval mode (samples independent) they go through together here
+        xs = [x for x in (x1, x2, x3) if x is not None]
+        if not self.training:
+            return self.forward_single(x1)
+        if _bn_training(self.features):
+            # BatchNorm is learning (P.train_bn): batch statistics and running-stat updates must be per branch,
+            # exactly as the reference's one pass per branch
+            return tuple(self.forward_single(x) for x in xs)
+        return _many(self.forward_single, xs)
 
 
 class RegionDescriptorNet(nn.Module):

@@ -12,7 +12,7 @@ import torch
 
 from train.global_p import image_sizes, match_label_functions, mean_std_files
 from utils import (check_bool, check_file, check_folder, check_int, check_model, get_images_labels, log_detail,
-                   mean_avg_precision, parse_dataset_id, precision1, read_mean_std, similarity_matrix, synthetic_image_set)
+                   parse_dataset_id, read_mean_std, retrieval_metrics, synthetic_image_set)
 
 SYNTHETIC = 'synthetic:'
 
@@ -36,9 +36,10 @@ def is_synthetic(dataset_full):
 
 
 def synthetic_spec(dataset_full):
-    """'synthetic:<dataset id>[:n=100][:q=20][:labels=10][:size=224]' -> (id, dict)."""
+    """'synthetic:<dataset id>[:n=100][:q=20][:labels=10][:size=224][:struct=0]' -> (id, dict); struct = per cent of
+    per-label pattern mixed into the noise images (utils.dataset.synthetic_image_set)."""
     parts = dataset_full[len(SYNTHETIC):].split(':')
-    opts = dict(n=100, q=20, labels=10, size=224)
+    opts = dict(n=100, q=20, labels=10, size=224, struct=0)
     for p in parts[1:]:
         k, v = p.split('=')
         opts[k] = int(v)
@@ -63,8 +64,8 @@ def load_sets(dataset_full, labels, raw=False):
     if is_synthetic(dataset_full):
         _, o = synthetic_spec(dataset_full)
         size = (3, o['size'], o['size'])
-        ref = synthetic_image_set(o['n'], o['labels'], size, seed=1234, prefix='synthetic/ref')
-        qry = synthetic_image_set(o['q'], o['labels'], size, seed=4321, prefix='synthetic/test')
+        ref = synthetic_image_set(o['n'], o['labels'], size, seed=1234, prefix='synthetic/ref', structure=o['struct'] / 100.0)
+        qry = synthetic_image_set(o['q'], o['labels'], size, seed=4321, prefix='synthetic/test', structure=o['struct'] / 100.0)
         labels.extend(sorted(set(lab for _, lab, _ in ref)))
         return [t for t in qry if t[1] in labels], ref
     dataset_id = parse_dataset_id(dataset_full)
@@ -87,19 +88,18 @@ def load_sets(dataset_full, labels, raw=False):
 def evaluate_retrieval(test_embeddings, ref_embeddings, test_set, ref_set, device, labels, dba):
     """sim -> P@1 + mAP, the reference's result line, then the optional DBA pass.  Returns the
     (prec1, mAP) pair of the plain pass (the reference returns nothing; the prints are the API)."""
-    sim = similarity_matrix(test_embeddings, ref_embeddings)
-    prec1, c, t, _, _ = precision1(sim, test_set, ref_set)
-    mAP = mean_avg_precision(sim, test_set, ref_set)
-    print('Descriptor (TEST): {0} / {1} - acc: {2:.4f} - mAP:{3:.4f}'.format(c, t, prec1, mAP))
+    # sim = torch.mm(test_emb, ref_emb.t()) -> precision1 -> mean_avg_precision (reference test/classif_finetune_test.py:82-85),
+    # evaluated in query-row blocks when the matrix exceeds utils.metrics.SIM_BUDGET_BYTES (same values, no 40 GB matrix)
+    m = retrieval_metrics(test_embeddings, ref_embeddings, test_set, ref_set)
+    prec1, mAP = m['prec1'], m['mAP']
+    print('Descriptor (TEST): {0} / {1} - acc: {2:.4f} - mAP:{3:.4f}'.format(m['correct'], m['total'], prec1, mAP))
     if dba == 0:
         return prec1, mAP
     from .instance_avg import instance_avg
     print('Testing using instance feature augmentation')
     dba_embeddings, dba_set = instance_avg(device, ref_embeddings, ref_set, labels, dba)
-    sim = similarity_matrix(test_embeddings, dba_embeddings)
-    p1d, c, t, _, _ = precision1(sim, test_set, dba_set)
-    mAPd = mean_avg_precision(sim, test_set, dba_set)
-    print('Descriptor (TEST DBA k={4}): {0} / {1} - acc: {2:.4f} - mAP:{3:.4f}'.format(c, t, p1d, mAPd, dba))
+    d = retrieval_metrics(test_embeddings, dba_embeddings, test_set, dba_set)
+    print('Descriptor (TEST DBA k={4}): {0} / {1} - acc: {2:.4f} - mAP:{3:.4f}'.format(d['correct'], d['total'], d['prec1'], d['mAP'], dba))
     return prec1, mAP
 
 

@@ -95,6 +95,29 @@ def stage_batch(batch, trans, device):
     return stage_images([trans(im) for im, _, _ in batch], device)
 
 
+def fold_shape_buckets(f, dataset, batch_size):
+    """Call f(indices, items) on batches of SAME-SHAPED images: the dataset is bucketed by image shape (first-seen order,
+    dataset order inside a bucket), every bucket cut into batches of `batch_size`.  The reference walks a ragged region
+    dataset one image per step (train/classif_regions.py:107-132, model/siamese.py:184); bucketing keeps the backbone
+    batched whatever the mix of sizes.  Per-image results are independent, so the order of evaluation does not matter."""
+    buckets = {}
+    for i, item in enumerate(dataset):
+        buckets.setdefault((tuple(item[0].shape), item[0].dtype), []).append(i)
+    bs = max(int(batch_size), 1)
+    for idx in buckets.values():
+        for s in range(0, len(idx), bs):
+            ii = idx[s:s + bs]
+            f(ii, [dataset[j] for j in ii])
+
+
+def scatter_rows(slab, indices, rows):
+    """slab[indices] = rows (consecutive index runs are plain slice copies)."""
+    if indices == list(range(indices[0], indices[0] + len(indices))):
+        slab[indices[0]:indices[0] + len(indices)].copy_(rows)
+    else:
+        slab.index_copy_(0, torch.tensor(indices, dtype=torch.int64, device=slab.device), rows.to(slab.dtype))
+
+
 def test_transform(P):
     return None if P.test_pre_proc else P.test_trans
 
@@ -119,4 +142,6 @@ def prepare_for_inference(net, P):
     if getattr(P, 'fold_bn', False) and any(isinstance(m, torch.nn.BatchNorm2d) for m in net.features.modules()):
         dev = next(net.parameters()).device
         net.features = fold_batch_norm(net.features).to(dev)
+        if dev.type == 'cuda':
+            net.features = net.features.to(memory_format=torch.channels_last)     # MIOpen-run layers keep NHWC weights
     return net

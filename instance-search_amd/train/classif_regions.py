@@ -6,7 +6,7 @@ import torch
 from model.custom_modules import l2_normalize_rows
 from model.siamese import TuneClassif, TuneClassifSub
 from utils import fold_batches, move_device, tensor
-from ._common import base_model, load_weights, make_resident, stage_batch, test_transform
+from ._common import base_model, fold_shape_buckets, load_weights, make_resident, scatter_rows, stage_batch, test_transform
 from .classif_regions_p import P
 
 labels = []
@@ -50,20 +50,15 @@ def get_embeddings(net, dataset, device, out_size):
         make_resident(dataset, P.cuda_device)
     slab = tensor(device, len(dataset), out_size)
 
-    def run(slab, i, is_final, batch):
+    def run(indices, batch):
         with torch.no_grad():
             out = net(stage_batch(batch, trans, P.cuda_device))[0]
-            slab[i:i + len(batch)].copy_(_best_location_descriptors(out))
-        return slab
+            scatter_rows(slab, indices, _best_location_descriptors(out))
 
-    # the reference walks one image at a time (images may differ in size); same-sized images
-    # can be batched, which P.test_batch_size > 1 enables
-    bs = P.test_batch_size if _same_size(dataset) else 1
-    return fold_batches(run, slab, dataset, max(bs, 1))
-
-
-def _same_size(dataset):
-    return len(set(tuple(im.shape) for im, _, _ in dataset)) <= 1
+    # the reference walks one image at a time (images may differ in size); here images are bucketed by shape and every
+    # bucket goes through in batches of P.test_batch_size
+    fold_shape_buckets(run, dataset, P.test_batch_size)
+    return slab
 
 
 def get_class_net():

@@ -62,11 +62,29 @@ def mine_epoch_negatives(similarities, dataset, couples_list, semi_hard):
     lab = torch.tensor([table.setdefault(l, len(table)) for _, l, _ in dataset], dtype=torch.int32)
     i1 = torch.tensor([c[1][0] for c in couples_list], dtype=torch.int64)
     i2 = torch.tensor([c[1][1] for c in couples_list], dtype=torch.int64)
+    if not isinstance(similarities, torch.Tensor):
+        # SimilarityRows: the n x n matrix is over budget -- mine block by block of anchor rows (couples grouped by the block
+        # their anchor i1 falls in)
+        from utils.metrics import row_blocks
+        n = similarities.size(0)
+        neg = torch.full_like(i1, -1)
+        for r0, r1 in row_blocks(n, n):
+            sel = ((i1 >= r0) & (i1 < r1)).nonzero().flatten()
+            if sel.numel():
+                neg[sel] = _mine_block(similarities.rows(r0, r1), lab, i1[sel], i2[sel], semi_hard, r0)
+        return neg
+    return _mine_block(similarities, lab, i1, i2, semi_hard, 0)
+
+
+def _mine_block(similarities, lab, i1, i2, semi_hard, row_base):
+    """similarities: rows [row_base, row_base + rows) of the n x n matrix; i1 (anchors, all inside the block) and i2 absolute."""
     if similarities.is_cuda:
         from isx import ops
-        return ops.mine_negatives(similarities, lab.cuda(), i1.cuda(), i2.cuda(), semi_hard).cpu()
+        return ops.mine_negatives(similarities, lab.cuda(), i1.cuda(), i2.cuda(), semi_hard, row_base=row_base).cpu()
+    anchor_lab = lab[i1]
+    i1 = i1 - row_base
     rows = similarities[i1]
-    excl = lab[None, :] == lab[i1][:, None]
+    excl = lab[None, :] == anchor_lab[:, None]
     if semi_hard:
         excl = excl | (rows >= similarities[i1, i2][:, None])
     masked = rows.masked_fill(excl, -2.0)

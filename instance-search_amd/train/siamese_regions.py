@@ -10,7 +10,7 @@ from model.siamese import RegionDescriptorNet, TuneClassifSub
 from model.custom_modules import TripletLoss
 from utils import (choose_rand_neg, fold_batches, get_pos_couples, get_similarities, log, move_device, tensor,
                    test_print_descriptor, train_gen)
-from ._common import base_model, load_weights, make_resident, stage_batch, test_transform
+from ._common import base_model, fold_shape_buckets, load_weights, make_resident, scatter_rows, stage_batch, test_transform
 from .siamese_descriptor import mine_epoch_negatives, shuffle_couples
 from .siamese_regions_p import P
 
@@ -23,14 +23,13 @@ def get_embeddings(net, dataset, device, out_size):
         make_resident(dataset, P.cuda_device)
     slab = tensor(device, len(dataset), out_size)
 
-    def run(slab, i, is_final, batch):
+    def run(indices, batch):
         with torch.no_grad():
-            slab[i:i + len(batch)].copy_(net(stage_batch(batch, trans, P.cuda_device)))
-        return slab
+            scatter_rows(slab, indices, net(stage_batch(batch, trans, P.cuda_device)))
 
-    # one image per step in the reference; same-sized images may share a backbone pass
-    same = len(set(tuple(im.shape) for im, _, _ in dataset)) <= 1
-    return fold_batches(run, slab, dataset, max(P.test_batch_size, 1) if same else 1)
+    # one image per step in the reference; images bucketed by shape share a backbone pass here
+    fold_shape_buckets(run, dataset, P.test_batch_size)
+    return slab
 
 
 def get_siamese_net():

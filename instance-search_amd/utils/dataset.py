@@ -68,9 +68,24 @@ def synthetic_images(n, size=(3, 224, 224), seed=1234, device='cpu'):
     return ((x - mean) / std).to(device)
 
 
-def synthetic_image_set(n, n_labels, size=(3, 224, 224), seed=1234, prefix='synthetic'):
-    """An in-memory dataset of (tensor, label, path) tuples; label = 'cNNN' by index mod n_labels."""
-    imgs = synthetic_images(n, size, seed)
+def synthetic_image_set(n, n_labels, size=(3, 224, 224), seed=1234, prefix='synthetic', structure=0.0):
+    """An in-memory dataset of (tensor, label, path) tuples; label = 'cNNN' by index mod n_labels.
+    structure = 0: pure U[0,1) noise (labels carry no signal: retrieval at chance level).  structure = s in (0,1]:
+    pixel = (1-s) * noise + s * pattern[label], one smooth random pattern per label (a 7x7 U[0,1) grid, bilinearly
+    upsampled; pattern seed fixed so that query and gallery sets built with different `seed`s share the instances) --
+    a retrieval task a network can actually solve, for the end-to-end parity tests."""
+    if structure <= 0.0:
+        imgs = synthetic_images(n, size, seed)
+    else:
+        g = torch.Generator().manual_seed(seed)
+        noise = torch.rand(n, *size, generator=g)
+        gp = torch.Generator().manual_seed(777)
+        grid = torch.rand(n_labels, size[0], 7, 7, generator=gp)
+        pat = torch.nn.functional.interpolate(grid, size=size[1:], mode='bilinear', align_corners=False)
+        x = (1.0 - structure) * noise + structure * pat[torch.arange(n) % n_labels]
+        mean = torch.tensor(IMAGENET_MEAN).view(1, 3, 1, 1)
+        std = torch.tensor(IMAGENET_STD).view(1, 3, 1, 1)
+        imgs = (x - mean) / std
     return [(imgs[i], 'c%03d' % (i % n_labels), '%s/%06d.png' % (prefix, i)) for i in range(n)]
 
 

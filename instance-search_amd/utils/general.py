@@ -84,7 +84,16 @@ def tensor(device, *sizes):
     return torch.empty(*sizes, dtype=torch.float32, device='cuda' if device >= 0 else 'cpu')
 
 
+def is_main_process():
+    """True on rank 0 of a torch.distributed job and in a plain single-process run: the one process that prints result
+    lines, appends to the log file and writes checkpoints."""
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
 def log(P, message):
+    if not is_main_process():
+        return
     print(message)
     log_file = getattr(P, 'log_file', None)
     if log_file:
@@ -96,6 +105,6 @@ def log_detail(P, message, detail):
     if message is not None:
         log(P, message)
     log_file = getattr(P, 'log_file', None)
-    if log_file and detail:
+    if log_file and detail and is_main_process():
         with open(log_file, 'a') as f:
             f.write(str(detail) + '\n')

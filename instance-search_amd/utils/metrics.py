@@ -74,3 +74,57 @@ def mean_avg_precision(sim, test_set, ref_set, kth=1):
     qlab, glab = _label_ids(test_set, ref_set)
     aps = [a for a in _average_precisions(sim, qlab, glab, kth).tolist() if a == a]
     return sum(aps) / float(len(aps))
+
+
+# ---- evaluation without the whole score matrix -----------------------------------------------------------------
+# P@k, AP and the masked score sums are all PER QUERY ROW: a (queries x gallery) matrix larger than the budget is
+# evaluated in blocks of query rows, each block's scores materialised, consumed and dropped.  Same kernels on the same
+# rows -> the same bits as the one-matrix evaluation, at any gallery size (10 k x 1 M fp32 would be 40 GB; in blocks of
+# 256 queries it is 1 GB at a time).  The reference has no counterpart: it builds the full matrix (utils/metrics.py:25-55
+# consume it) and falls back to the CPU when it does not fit (utils/train_siamese.py:30-43).
+SIM_BUDGET_BYTES = 8 << 30
+
+
+def row_blocks(M, N, budget_bytes=None):
+    """[(r0, r1)] covering range(M) with (r1 - r0) * N * 4 <= budget (at least one row per block)."""
+    budget = SIM_BUDGET_BYTES if budget_bytes is None else budget_bytes
+    per = max(1, int(budget // max(1, 4 * N)))
+    if per >= M:
+        return [(0, M)] if M else []
+    if per >= 128:
+        per = per // 128 * 128                 # whole GEMM tiles
+    return [(r, min(r + per, M)) for r in range(0, M, per)]
+
+
+def retrieval_metrics(test_emb, ref_emb, test_set, ref_set, kth=1, budget_bytes=None, with_sums=False):
+    """precision1(...) + mean_avg_precision(...) (+ the pos / all score sums of test_descriptor_net) of
+    sim = test_emb @ ref_emb.T, evaluated in query-row blocks.  Returns a dict: prec1, correct, total, max_sim (M,1),
+    max_label, mAP, sum_pos, sum_all, blocks."""
+    from .train_siamese import similarity_matrix
+    M, N = test_emb.size(0), ref_emb.size(0)
+    qlab, glab = _label_ids(test_set, ref_set)
+    blocks = row_blocks(M, N, budget_bytes)
+    correct, max_sims, max_label, aps = 0, [], [], []
+    sum_pos, sum_all = 0.0, 0.0
+    for r0, r1 in blocks:
+        sim = similarity_matrix(test_emb[r0:r1], ref_emb)
+        _, c, _, ms, ml = precision1(sim, test_set[r0:r1], ref_set, kth)
+        correct += c
+        max_sims.append(ms)
+        max_label.extend(ml)
+        aps.extend(_average_precisions(sim, qlab[r0:r1], glab, kth).tolist())
+        if with_sums:
+            if sim.is_cuda:
+                from isx import ops
+                rows = ops.masked_sums(sim, qlab[r0:r1].cuda(), glab.cuda()).cpu()
+                for a, b in rows.tolist():              # row order, as the one-matrix evaluation adds them
+                    sum_pos += a
+                    sum_all += b
+            else:
+                mask = qlab[r0:r1][:, None] == glab[None, :]
+                sum_pos += float(sim[mask].double().sum())
+                sum_all += float(sim.double().sum())
+        del sim
+    valid = [a for a in aps if a == a]
+    return {"prec1": float(correct) / M, "correct": correct, "total": M, "max_sim": torch.cat(max_sims, 0), "max_label": max_label,
+            "mAP": sum(valid) / float(len(valid)), "sum_pos": sum_pos, "sum_all": sum_all, "blocks": len(blocks)}

@@ -109,7 +109,8 @@ def train_gen(train_type, P, test_print, test_net, net, train_set, testset_tuple
     rank, world = _dp()
     reducer = None
     if world > 1:
-        from isx.dp import GradAllReducer
+        from isx.dp import GradAllReducer, broadcast_module_state
+        broadcast_module_state(net, src=0)      # replicas start from rank 0's weights and buffers (the descriptor head is random-init)
         reducer = GradAllReducer(list(net.parameters()))
     stepper = _Stepper(P, net, create_batch, create_loss, reducer)
     for epoch in range(P.train_epochs):

@@ -7,24 +7,41 @@ import os
 import random
 
 import torch
+import torch.distributed as dist
 
 from model.nn_utils import set_net_train
 from .dataset import get_pos_couples
-from .general import log
+from .general import is_main_process, log
 from .metrics import _label_ids, mean_avg_precision, precision1
 
 
 def embeddings_device_dim(P, net, n, sim_matrix=False):
-    """(device, descriptor width): the configured GPU unless the slab (or the n x n matrix)
-    exceeds P.embeddings_cuda_size bytes."""
+    """(device, descriptor width).  The reference moves the slab -- or, with sim_matrix, everything -- to the CPU once it
+    exceeds P.embeddings_cuda_size bytes (2**30 there, utils/train_siamese.py:30-43).  Here only a SLAB beyond the budget
+    (sized for 288 GB of HBM) leaves the GPU; an n x n score matrix beyond the budget is never built: its consumers work on
+    query-row blocks (utils.metrics.retrieval_metrics, SimilarityRows below), same values, bounded memory."""
     device, out_size = P.cuda_device, P.feature_dim
     if hasattr(net, 'feature_size') and out_size <= 0:
         out_size = net.feature_size
     if n * out_size * 4 > P.embeddings_cuda_size:
         device = -1
-    if sim_matrix and n * n * 4 > P.embeddings_cuda_size:
-        device = -1
     return device, out_size
+
+
+class SimilarityRows(object):
+    """A descriptor slab standing in for its own n x n similarity matrix when that matrix is over budget: `rows(r0, r1)`
+    computes one block of rows on demand (isx_cosine_sim on the GPU)."""
+
+    def __init__(self, emb):
+        self.emb = emb
+        self.is_cuda = emb.is_cuda
+
+    def size(self, dim=None):
+        n = self.emb.size(0)
+        return (n, n) if dim is None else n
+
+    def rows(self, r0, r1):
+        return similarity_matrix(self.emb[r0:r1], self.emb)
 
 
 def similarity_matrix(a, b):
@@ -36,34 +53,30 @@ def similarity_matrix(a, b):
 
 
 def get_similarities(P, get_embeddings, net, dataset):
+    """(n x n similarities of the dataset's descriptors, device).  Over utils.metrics.SIM_BUDGET_BYTES the matrix is
+    returned as a SimilarityRows (row blocks on demand) -- train.siamese_descriptor.mine_epoch_negatives consumes both."""
+    from . import metrics
     set_net_train(net, False)
     d, o = embeddings_device_dim(P, net, len(dataset), sim_matrix=True)
     emb = get_embeddings(net, dataset, d, o)
-    sim = similarity_matrix(emb, emb)
+    n = emb.size(0)
+    sim = SimilarityRows(emb) if n * n * 4 > metrics.SIM_BUDGET_BYTES else similarity_matrix(emb, emb)
     set_net_train(net, True, bn_train=P.train_bn)
     return sim, d
 
 
 def test_descriptor_net(P, get_embeddings, net, test_set, test_ref_set, kth=1):
+    from .metrics import retrieval_metrics
     d, o = embeddings_device_dim(P, net, max(len(test_set), len(test_ref_set)))
-    sim = similarity_matrix(get_embeddings(net, test_set, d, o), get_embeddings(net, test_ref_set, d, o))
-    prec1, correct, total, max_sim, max_label = precision1(sim, test_set, test_ref_set, kth)
-    mAP = mean_avg_precision(sim, test_set, test_ref_set, kth)
-    qlab, glab = _label_ids(test_set, test_ref_set)
-    if sim.is_cuda:
-        from isx import ops
-        rows = ops.masked_sums(sim, qlab.cuda(), glab.cuda()).cpu()
-        sum_pos, sum_all = float(sum(rows[:, 0].tolist())), float(sum(rows[:, 1].tolist()))
-    else:
-        mask = qlab[:, None] == glab[None, :]
-        sum_pos, sum_all = float(sim[mask].double().sum()), float(sim.double().sum())
-    sum_neg = sum_all - sum_pos
-    sum_max = float(max_sim.double().sum())
+    m = retrieval_metrics(get_embeddings(net, test_set, d, o), get_embeddings(net, test_ref_set, d, o), test_set, test_ref_set, kth,
+                          with_sums=True)
+    sum_neg = m['sum_all'] - m['sum_pos']
+    sum_max = float(m['max_sim'].double().sum())
     lab_dict = dict((lab, {}) for _, lab, _ in test_set)
-    for (_, lab, _), got in zip(test_set, max_label):
+    for (_, lab, _), got in zip(test_set, m['max_label']):
         seen = lab_dict[lab]
         seen.setdefault(got, seen.get(got, 0) + 1)
-    return prec1, correct, total, sum_pos, sum_neg, sum_max, mAP, lab_dict
+    return m['prec1'], m['correct'], m['total'], m['sum_pos'], sum_neg, sum_max, m['mAP'], lab_dict
 
 
 def test_print_descriptor(train_type, P, net, testset_tuple, get_embeddings, best_score=0, epoch=0):
@@ -86,12 +99,16 @@ def test_print_descriptor(train_type, P, net, testset_tuple, get_embeddings, bes
     set_net_train(net, False)
     correct = evaluate('TEST - ', test_set, test_ref_set, 1)
     save_dir = getattr(P, 'save_dir', None)
+    # data parallel: every rank evaluates (same weights, same result, same control flow), rank 0 alone writes
+    main = is_main_process()
     if correct > best_score:
         best_score = correct
-        if save_dir:
+        if save_dir and main:
             torch.save(net.state_dict(), os.path.join(save_dir, 'best_siam.pth.tar'))
-    if save_dir:
+    if save_dir and main:
         torch.save(net.state_dict(), os.path.join(save_dir, 'model_siam_' + str(epoch) + '.pth.tar'))
+    if save_dir and dist.is_available() and dist.is_initialized():
+        dist.barrier()                      # nobody races ahead of (or reads) a half-written checkpoint
     couples = get_pos_couples(test_ref_set)
     sample = random.sample(test_ref_set, max(1, len(test_ref_set) // 10))
     sample = [x for x in sample if len(couples.get(x[1], ())) >= 3]

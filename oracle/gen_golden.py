@@ -416,10 +416,55 @@ def trunk_block():
     npz("trunk_block.npz", **out)
 
 
+class U8Mask(torch.Tensor):
+    """A uint8 label indicator with the torch-0.1.x mask semantics test/instance_avg.py:26 relies on: `1 - mask` is the
+    complement AND usable as an index mask (modern torch refuses uint8 masks)."""
+
+    def __rsub__(self, other):
+        assert other == 1
+        return self.as_subclass(torch.Tensor) == 0
+
+
+def dba():
+    """Database-side feature augmentation: the reference's own test/instance_avg.py:7-33 loop, imported in place and run
+    unmodified; harness-side shims only: a `utils` module exposing the reference's get_lab_indicators
+    (utils/dataset.py:65-76, itself unmodified) with its ByteTensors wrapped in U8Mask.  Fixture: descriptors, labels
+    (a singleton label, a pair, larger groups), outputs for k = -1, 0, 1, 2, 5."""
+    if "general" not in sys.modules:
+        load("general", R + "/utils/general.py")
+    dataset = load("dataset", R + "/utils/dataset.py")
+    u = types.ModuleType("utils")
+    u.get_lab_indicators = lambda ds, device: {k: v.as_subclass(U8Mask) for k, v in dataset.get_lab_indicators(ds, device).items()}
+    saved = sys.modules.get("utils")
+    sys.modules["utils"] = u
+    try:
+        ia = load("instance_avg", R + "/test/instance_avg.py")
+    finally:
+        if saved is not None:
+            sys.modules["utils"] = saved
+        else:
+            del sys.modules["utils"]
+    g = torch.Generator().manual_seed(20260303)
+    labs = [0, 1, 2, 0, 1, 0, 3, 1, 0, 2, 0, 1, 4, 4, 0, 5, 1, 2, 0, 4, 2, 1, 0, 6, 6, 6, 0, 2, 1, 0, 4, 2, 6, 0, 1, 6, 2, 0, 4, 1]
+    cent = torch.randn(7, 48, generator=g)
+    E = cent[torch.tensor(labs)] + 0.7 * torch.randn(len(labs), 48, generator=g)
+    E = E / E.norm(dim=1, keepdim=True)                                   # label 3 and label 5 are singletons
+    ds = [(None, "L%d" % l, None) for l in labs]
+    out = {"emb": E, "labels": np.asarray(labs, np.int32)}
+    for k in (-1, 0, 1, 2, 5):
+        new, _ = ia.instance_avg(-1, E.clone(), ds, sorted(set("L%d" % l for l in labs)), k)
+        out["k%s" % ("all" if k < 0 else k)] = new
+    npz("dba.npz", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "trunk":
         os.makedirs(OUT, exist_ok=True)
         trunk_block()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dba":
+        os.makedirs(OUT, exist_ok=True)
+        dba()
     else:
         main()
         trunk_block()
+        dba()

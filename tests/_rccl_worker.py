@@ -1,0 +1,91 @@
+"""Worker of tests/test_rccl_multi_gpu.py: one process per GPU under torch.distributed.run, REAL RCCL (backend nccl).
+Writes what it computed to <out>.<rank>; the pytest process compares."""
+import os
+import random
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+
+class TinyNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.features = nn.Sequential(nn.Conv2d(3, 8, 3, stride=2), nn.BatchNorm2d(8), nn.ReLU())
+        self.head = nn.Linear(8 * 7 * 7, 16)
+
+    def forward(self, x):
+        y = self.head(self.features(x).flatten(1))
+        return y / (y.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()
+
+
+def main():
+    out = sys.argv[1]
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from isx import ops, retrieval as R
+    from isx.dp import GradAllReducer, broadcast_module_state
+    res = {}
+    # ---- sharded gallery search: torch.distributed (RCCL) exchange and libisx's own RCCL communicator ----
+    g = torch.Generator().manual_seed(0)
+    N, D, k, M = 40007, 256, 100, 300
+    G = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+    G[N // 2 + 3] = G[5]                                     # a tie across the shard boundary
+    Q = torch.nn.functional.normalize(torch.randn(M, D, generator=g), dim=1)
+    Gd, Qd = ops.l2norm_rows(G.to(dev)), ops.l2norm_rows(Q.to(dev))
+    lo, hi = R.shard_bounds(N, world, rank)
+    for name, fast in (("fast", True), ("f32", False)):
+        gal = R.ShardedGallery(Gd[lo:hi], lo, fast=fast)
+        s, i = gal.search(Qd, k)
+        res["dist_" + name] = (s.cpu(), i.cpu())
+    nc = R.NativeComm()
+    assert nc.nranks == world
+    gal = R.ShardedGallery(Gd[lo:hi], lo, native_comm=nc)
+    s, i = gal.search(Qd, k)
+    res["native"] = (s.cpu(), i.cpu())
+    if rank == 0:
+        us, ui = ops.cosine_topk(Qd, Gd, k)                  # unsharded, this GPU alone
+        res["unsharded"] = (us.cpu(), ui.cpu())
+    torch.cuda.synchronize()
+    nc.close()
+    # replicated gallery, queries split by rank
+    rs, ri = R.ReplicatedGallery(Gd).search(Qd, k)
+    res["replicated"] = (rs.cpu(), ri.cpu())
+    # ---- gradient exchange: P ranks x 1/P of the batch + all-reduce(SUM) == one process with the whole batch ----
+    torch.manual_seed(100 + rank)                            # different initial weights per rank: the broadcast must fix that
+    net = TinyNet().to(dev)
+    broadcast_module_state(net)
+    w0 = {n: t.detach().clone().cpu() for n, t in net.state_dict().items()}
+    red = GradAllReducer(list(net.parameters()), bucket_mb=0.001)
+    x = torch.randn(8 * world, 3, 16, 16, generator=torch.Generator().manual_seed(9)).to(dev)
+    net.train()
+    for m in net.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eval()                                         # frozen BN, as in the reference's training
+    red.zero_grad()
+    red.arm()
+    net(x[rank * 8:(rank + 1) * 8]).sum().backward()
+    red.finish()
+    res["flat"] = red.flat.cpu()
+    res["w0"] = w0
+    if rank == 0:
+        ref = TinyNet().to(dev)
+        ref.load_state_dict({n: t.to(dev) for n, t in w0.items()})
+        ref.train()
+        for m in ref.modules():
+            if isinstance(m, nn.BatchNorm2d):
+                m.eval()
+        ref(x).sum().backward()
+        res["ref_flat"] = torch.cat([p.grad.reshape(-1) for p in ref.parameters()]).cpu()
+    torch.save(res, "%s.%d" % (out, rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -293,7 +293,8 @@ def test_metrics_and_descriptor_eval_golden(golden):
     P.cuda_device, P.feature_dim = 0, 0
     assert embeddings_device_dim(P, Net, 10) == (0, 32)
     assert embeddings_device_dim(P, Net, 2 ** 24) == (-1, 32)                  # slab over budget -> CPU
-    assert embeddings_device_dim(P, Net, 20000, sim_matrix=True) == (-1, 32)   # n*n*4 over budget
+    # an n x n matrix over budget no longer sends anything to the CPU: its consumers work on row blocks
+    assert embeddings_device_dim(P, Net, 20000, sim_matrix=True) == (0, 32)
     P.cuda_device, P.feature_dim = -1, 32
     Q, G = t(g["Q_n100"]), t(g["G_n100"])
     ts = [(Q[i], int(l), None) for i, l in enumerate(g["qlab_n100"])]
@@ -361,3 +362,94 @@ def test_instance_avg_matches_reference_loop():
                 agg += E[best[j]] * ((nn_ - j) / float(nn_ + 1))
             want[i] = agg / (agg.norm() + 1e-10)
         np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_instance_avg_matches_reference_fixture(golden):
+    """DBA against the output of the reference's OWN test/instance_avg.py:7-33 (run unmodified by oracle/gen_golden.py with
+    a harness-side uint8-mask shim): singleton labels kept, k = -1 / 0 / 1 / 2 / 5."""
+    from test.instance_avg import instance_avg
+    g = golden("dba.npz")
+    E = torch.from_numpy(g["emb"])
+    labs = ["L%d" % l for l in g["labels"]]
+    ds = [(None, l, None) for l in labs]
+    for key, k in (("kall", -1), ("k0", 0), ("k1", 1), ("k2", 2), ("k5", 5)):
+        got, same_ds = instance_avg(-1, E, ds, sorted(set(labs)), k)
+        assert same_ds is ds
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-5, atol=1e-6, err_msg=key)
+    np.testing.assert_array_equal(g["k0"], g["emb"])                     # k = 0: unchanged
+
+
+def test_region_embeddings_bucket_ragged_images_by_shape():
+    """Ragged region datasets (the reference walks them one image per step, train/classif_regions.py:107-132): images are
+    bucketed by shape and batched per bucket; every row lands at its dataset index and equals the one-at-a-time result."""
+    from isx import backbones
+    from model.siamese import RegionDescriptorNet, TuneClassifSub
+    from train import classif_regions as cr, siamese_regions as sr
+    from train._common import fold_shape_buckets
+    from utils.dataset import synthetic_image_set
+    a = synthetic_image_set(5, 3, size=(3, 288, 288), seed=1)
+    b = synthetic_image_set(4, 3, size=(3, 320, 288), seed=2)
+    ds = [a[0], b[0], a[1], b[1], b[2], a[2], a[3], b[3], a[4]]                       # interleaved sizes
+    seen = []
+    fold_shape_buckets(lambda ii, items: seen.append((ii, [tuple(t.shape) for t, _, _ in items])), ds, 3)
+    assert [ii for ii, _ in seen] == [[0, 2, 5], [6, 8], [1, 3, 4], [7]]
+    assert all(len(set(shapes)) == 1 for _, shapes in seen)
+    torch.manual_seed(0)
+    sub = TuneClassifSub(backbones.alexnet(pretrained=True), 3, (6, 6)).eval()
+    for P_ in (cr.P, sr.P):
+        P_.cuda_device, P_.test_pre_proc = -1, True
+    cr.P.test_batch_size = 4
+    batched = cr.get_embeddings(sub, ds, -1, 3)
+    cr.P.test_batch_size = 1
+    single = cr.get_embeddings(sub, ds, -1, 3)
+    np.testing.assert_allclose(batched.numpy(), single.numpy(), rtol=1e-5, atol=1e-6)
+    rd = RegionDescriptorNet(backbones.alexnet(pretrained=True), 3, 8, (6, 6)).eval()
+    sr.P.test_batch_size = 4
+    batched = sr.get_embeddings(rd, ds, -1, 8)
+    sr.P.test_batch_size = 1
+    single = sr.get_embeddings(rd, ds, -1, 8)
+    np.testing.assert_allclose(batched.numpy(), single.numpy(), rtol=1e-5, atol=1e-6)
+    assert abs(float(batched.norm(dim=1).mean()) - 1.0) < 1e-5
+
+
+def test_blocked_metrics_equal_the_one_matrix_evaluation(golden):
+    """utils.metrics.retrieval_metrics in query-row blocks (any budget) == precision1 + mean_avg_precision on the whole
+    matrix, bit for bit; SimilarityRows mining == whole-matrix mining."""
+    from train.siamese_descriptor import mine_epoch_negatives
+    from utils import mean_avg_precision, precision1
+    from utils.metrics import retrieval_metrics, row_blocks
+    from utils.train_siamese import SimilarityRows
+    g = golden("synthetic_retrieval.npz")
+    Q, G = t(g["Q_n1000"]), t(g["G_n1000"])
+    Q, G = Q / Q.norm(dim=1, keepdim=True), G / G.norm(dim=1, keepdim=True)
+    ts = [(None, int(l), None) for l in g["qlab_n1000"]]
+    rs = [(None, int(l), None) for l in g["glab_n1000"]]
+    sim = Q @ G.t()
+    for kth in (1, 2):
+        want_p = precision1(sim, ts, rs, kth)
+        want_map = mean_avg_precision(sim, ts, rs, kth)
+        for budget in (None, 4 * 1000 * 7, 4 * 1000):                       # one block, 7-row blocks, single rows
+            m = retrieval_metrics(Q, G, ts, rs, kth, budget_bytes=budget, with_sums=True)
+            assert (m["prec1"], m["correct"], m["total"]) == want_p[:3] and m["max_label"] == want_p[4]
+            # CPU BLAS sums a row block in another order than the whole matrix (last-bit score differences); on the GPU
+            # every score is its own k-ordered fma chain and the blocked evaluation is bit-identical (tests/test_gpu_parity.py)
+            np.testing.assert_allclose(m["max_sim"].numpy(), want_p[3].numpy(), rtol=0, atol=2e-7)
+            assert abs(m["mAP"] - want_map) <= 1e-12
+            assert m["blocks"] == len(row_blocks(Q.size(0), G.size(0), budget))
+        assert abs(m["sum_all"] - float(sim.double().sum())) < 1e-4            # same CPU-BLAS caveat
+    assert row_blocks(10, 1000, 4 * 1000 * 3) == [(0, 3), (3, 6), (6, 9), (9, 10)] and row_blocks(0, 5) == []
+    # mining on row blocks
+    import utils.metrics as M
+    ds = [(None, int(l), None) for l in g["glab_n100"]]
+    E = t(g["G_n100"]); E = E / E.norm(dim=1, keepdim=True)
+    full = E @ E.t()
+    couples = [(ds[i][1], (i, j), (None, None)) for i in range(100) for j in range(i, 100) if ds[i][1] == ds[j][1]][:150]
+    old = M.SIM_BUDGET_BYTES
+    try:
+        M.SIM_BUDGET_BYTES = 4 * 100 * 9
+        for semi in (True, False):
+            a = mine_epoch_negatives(full, ds, couples, semi)
+            b = mine_epoch_negatives(SimilarityRows(E), ds, couples, semi)
+            assert torch.equal(a, b)
+    finally:
+        M.SIM_BUDGET_BYTES = old

@@ -219,23 +219,60 @@ def test_folder_dataset_raw_ingest_end_to_end(tmp_path, capsys, monkeypatch):
 
 
 def test_bench_multi_rank_code_path_on_one_gpu():
-    """bench.py's N > 1 path (query all-gather, per-shard search, result all-gather, canonical merge, one JSON line from rank 0)
-    with two ranks sharing cuda:0 over gloo (ISX_BENCH_ONE_DEVICE=1): functional check only, the 8-GPU RCCL run is the driver's."""
+    """`python bench.py --gpus 2` from a BARE command line (no torchrun around it): the parent starts the two ranks itself
+    before touching the GPU.  Two ranks share cuda:0 over gloo here (ISX_BENCH_ONE_DEVICE=1): query all-gather, per-shard
+    search, result all-gather, canonical merge, one JSON line from rank 0.  Functional check only; the real RCCL run is
+    tests/test_rccl_multi_gpu.py (>= 2 GPUs) and the driver's SCALE bench."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, ISX_BENCH_ONE_DEVICE="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
            "--gallery", "2000", "--no-cpu-baseline", "--no-shard-bench"]
-    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                     # rank 0 only
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 2
-    assert d["config"]["gallery_rows_per_gpu"] == 2000 and "roofline" in d
+    assert d["config"]["gallery_rows_per_gpu"] == 2000 and d["config"]["ranks"] == 2 and d["config"]["collective_backend"] == "gloo"
+    assert d["roofline"] is not None and d["roofline"]["frac"] > 0 and "roofline_cosine_gemm" in d and "roofline_step" in d
+    assert d["roofline_cosine_gemm"]["shape"] == [64, 2000, 2048]          # the gathered query block of both ranks
+
+
+def test_descriptor_head_golden_on_gpu(golden):
+    """DescriptorNet head (L2 -> Shift -> Linear -> L2, reference model/siamese.py:105-121) on the GPU against the
+    fixture produced by the reference's own module (descriptor_head.npz)."""
+    from model.custom_modules import NormalizeL2, Shift
+    from model.siamese import _apply_head
+    g = golden("descriptor_head.npz")
+    fm = torch.from_numpy(g["fmap"]).cuda()
+    F_in, D = fm[0].numel(), g["w"].shape[0]
+    head = nn.Sequential(NormalizeL2(), Shift(F_in), nn.Linear(F_in, D)).cuda()
+    with torch.no_grad():
+        head[1].param.copy_(torch.from_numpy(g["shift"]).cuda())
+        head[2].weight.copy_(torch.from_numpy(g["w"]).cuda())
+        head[2].bias.copy_(torch.from_numpy(g["b"]).cuda())
+        got = NormalizeL2()(_apply_head(head, fm.reshape(fm.size(0), -1)))             # fused isx_l2norm_shift_rows prologue
+        slow = NormalizeL2()(head(fm.reshape(fm.size(0), -1)))
+    np.testing.assert_allclose(host(got), g["desc"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(slow), g["desc"], rtol=1e-5, atol=1e-6)
+    assert int(g["feature_size"]) == D
+
+
+def test_instance_avg_on_gpu_matches_reference_fixture(golden):
+    """DBA on the GPU -- isx_cosine_sim + label masking + isx_topk_rows + weighted gather -- against the
+    output of the reference's own test/instance_avg.py (fixture dba.npz)."""
+    from test.instance_avg import instance_avg
+    g = golden("dba.npz")
+    E = torch.from_numpy(g["emb"]).cuda()
+    labs = ["L%d" % l for l in g["labels"]]
+    ds = [(None, l, None) for l in labs]
+    for key, k in (("kall", -1), ("k0", 0), ("k1", 1), ("k2", 2), ("k5", 5)):
+        got, _ = instance_avg(0, E, ds, sorted(set(labs)), k)
+        assert got.is_cuda
+        np.testing.assert_allclose(host(got), g[key], rtol=1e-5, atol=1e-6, err_msg=key)

@@ -1,0 +1,150 @@
+"""End-to-end parity of the four evaluation entry points: the SAME synthetic dataset through `main(..., device=0)` (BN-folded
+NHWC trunk on the hand-written convolution kernels, HIP pooling / L2 / region selection / cosine GEMM / ranking) and through
+`main(..., device=-1)` (the reference's CPU path in plain torch fp32).  North star: cosine scores within 1e-5, mAP within
+1e-4, P@1 equal.  Reference: test/classif_finetune_test.py:80-85, test/classif_regions_test.py:66-76,
+test/siamese_descriptor_test.py:70-80, test/siamese_regions_test.py:69-79.
+
+The synthetic sets mix a per-label pattern into the noise images (struct=...), so that the retrieval task is not at
+chance level: P@1 / mAP then react to descriptor errors instead of to coin flips between near-equal scores."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-5          # |cos_gpu - cos_cpu| on every (query, gallery) pair -- BASELINE.json north_star
+MAP_TOL = 1e-4          # |mAP_gpu - mAP_cpu|
+
+
+def _calibrated_weights(kind, n_labels, path, feature_dim=0, regions_k=6):
+    """A state dict for `--weights=`: seeded ResNet-50 whose BatchNorm running statistics are CALIBRATED on a batch of the
+    synthetic images (one training-mode pass, cumulative average).  With the default identity statistics a random-init
+    ResNet-50 maps every image to almost the same descriptor (score spread 1e-4, ranks decided by fp32 rounding): a
+    comparison of ranked lists would be meaningless.  Calibrated, the score spread is ~0.05-0.1 and P@1 / mAP sit mid-range."""
+    from isx import backbones
+    from model.siamese import DescriptorNet, RegionDescriptorNet, TuneClassif, TuneClassifSub
+    from utils.dataset import synthetic_image_set
+    torch.manual_seed(0)
+    base = backbones.resnet50(pretrained=True)
+    if kind == "classif":
+        net = TuneClassif(base, n_labels)
+    elif kind == "classif_sub":
+        net = TuneClassifSub(base, n_labels, (7, 7))
+    elif kind == "descriptor":
+        net = DescriptorNet(TuneClassif(base, n_labels), feature_dim, (7, 7))
+    else:
+        net = RegionDescriptorNet(TuneClassifSub(base, n_labels, (7, 7)), regions_k, feature_dim, (7, 7))
+    if hasattr(net, "feature_reduc1"):
+        net.feature_reduc1[1].param.data.normal_(0, 0.002)                 # a non-trivial Shift
+    net = net.cuda()
+    cal = torch.stack([t for t, _, _ in synthetic_image_set(64, n_labels, seed=99, structure=0.7)]).cuda()
+    net.train()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = None
+            m.reset_running_stats()
+    with torch.no_grad():
+        net.features(cal)
+    net.eval()
+    torch.save({k: v.cpu() for k, v in net.state_dict().items()}, path)
+    return path
+
+
+def _run(main, args_gpu, args_cpu, monkeypatch):
+    from test import _common as C
+    seen = []
+    real = C.evaluate_retrieval
+
+    def spy(test_embeddings, ref_embeddings, test_set, ref_set, *a, **k):
+        seen.append((test_embeddings.detach().float().cpu(), ref_embeddings.detach().float().cpu(), test_embeddings.is_cuda,
+                     [l for _, l, _ in test_set], [l for _, l, _ in ref_set]))
+        return real(test_embeddings, ref_embeddings, test_set, ref_set, *a, **k)
+
+    monkeypatch.setattr(C, "evaluate_retrieval", spy)
+    torch.manual_seed(0)
+    res_gpu = main(*args_gpu)
+    torch.manual_seed(0)
+    res_cpu = main(*args_cpu)
+    (qg, gg, on_gpu, ql, gl), (qc, gc, on_cpu, ql2, gl2) = seen
+    assert on_gpu and not on_cpu and ql == ql2 and gl == gl2
+    return res_gpu, res_cpu, (qg, gg), (qc, gc), (ql, gl)
+
+
+def _check(res_gpu, res_cpu, emb_gpu, emb_cpu, labs, what):
+    from isx import ops
+    (qg, gg), (qc, gc) = emb_gpu, emb_cpu
+    ql, gl = labs
+    assert qg.shape == qc.shape and gg.shape == gc.shape
+    sim_gpu = ops.cosine_sim(qg.cuda(), gg.cuda()).cpu()          # the matrix the GPU main ranked
+    sim_cpu = torch.mm(qc, gc.t())                                # the matrix the CPU main ranked
+    dcos = float((sim_gpu - sim_cpu).abs().max())
+    ddesc = float(max((qg - qc).abs().max(), (gg - gc).abs().max()))
+    spread = float(sim_cpu.max() - sim_cpu.min())
+    print("%s: max|dcos| = %.3g, max|ddesc| = %.3g, score spread %.3g, P@1 %.4f / %.4f, mAP %.6f / %.6f"
+          % (what, dcos, ddesc, spread, res_gpu[0], res_cpu[0], res_gpu[1], res_cpu[1]))
+    assert spread > 5e-3, "degenerate score matrix (spread %.3g): the comparison would be vacuous" % spread
+    assert dcos <= COS_TOL, "%s: cosine scores differ by %.3g" % (what, dcos)
+    # ranked lists: the top-1 gallery item must be the same, except where the CPU path's own two best scores lie closer
+    # together than the measured score error (a tie within the arithmetic's resolution; both answers are then the
+    # reference's answer under a different summation order)
+    top_g, top_c = sim_gpu.argmax(1), sim_cpu.argmax(1)
+    unexplained = 0
+    for q in (top_g != top_c).nonzero().flatten().tolist():
+        if float(sim_cpu[q, top_c[q]] - sim_cpu[q, top_g[q]]) > 2 * dcos:
+            unexplained += 1
+    assert unexplained == 0, "%s: %d queries rank a different gallery item first" % (what, unexplained)
+    if bool((top_g == top_c).all()):
+        assert res_gpu[0] == res_cpu[0], "%s: P@1 %r vs %r" % (what, res_gpu[0], res_cpu[0])
+    assert abs(res_gpu[1] - res_cpu[1]) <= MAP_TOL, "%s: mAP %r vs %r" % (what, res_gpu[1], res_cpu[1])
+    assert 0.0 < res_cpu[1] <= 1.0
+
+
+def test_classif_finetune_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
+    """BASELINE configs[1] end to end: ResNet-50 global descriptors."""
+    from test import classif_finetune_test as T
+    w = _calibrated_weights("classif", 20, str(tmp_path / "w.pth"))
+    spec = "synthetic:CLICIDE_video_224sq:n=200:q=40:labels=20:struct=70"
+    r = _run(T.main, (spec, "resnet50", w, 0, False, 64, 0), (spec, "resnet50", w, -1, False, 64, 0), monkeypatch)
+    with capsys.disabled():
+        _check(*r, what="classif_finetune_test resnet50")
+
+
+def test_classif_finetune_main_classify_scores_gpu_vs_cpu(monkeypatch, capsys):
+    """--classify=true: descriptors are the L2-normalised class scores (AlexNet, configs[0]'s model, on the GPU)."""
+    from test import classif_finetune_test as T
+    spec = "synthetic:CLICIDE_video_224sq:n=120:q=30:labels=12:struct=50"
+    r = _run(T.main, (spec, "alexnet", "", 0, True, 32, 0), (spec, "alexnet", "", -1, True, 32, 0), monkeypatch)
+    with capsys.disabled():
+        _check(*r, what="classif_finetune_test alexnet --classify")
+
+
+def test_classif_regions_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
+    """BASELINE configs[2] end to end: 448x448 images -> 14x14 map -> 8x8 candidate windows, best-location descriptor."""
+    from test import classif_regions_test as T
+    from train import classif_regions as cr
+    monkeypatch.setattr(cr.P, "test_batch_size", 16)
+    w = _calibrated_weights("classif_sub", 10, str(tmp_path / "w.pth"))
+    spec = "synthetic:CLICIDE_video_224sq:n=60:q=20:labels=10:size=448:struct=70"
+    r = _run(T.main, (spec, "resnet50", w, 0, 0), (spec, "resnet50", w, -1, 0), monkeypatch)
+    with capsys.disabled():
+        _check(*r, what="classif_regions_test resnet50 @448")
+
+
+def test_siamese_descriptor_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
+    from test import siamese_descriptor_test as T
+    w = _calibrated_weights("descriptor", 12, str(tmp_path / "w.pth"), feature_dim=256)
+    spec = "synthetic:CLICIDE_video_224sq:n=120:q=30:labels=12:struct=70"
+    r = _run(T.main, (spec, "resnet50", w, 0, 256, 32, 0), (spec, "resnet50", w, -1, 256, 32, 0), monkeypatch)
+    with capsys.disabled():
+        _check(*r, what="siamese_descriptor_test resnet50")
+
+
+def test_siamese_regions_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
+    from test import siamese_regions_test as T
+    from train import siamese_regions as sr
+    monkeypatch.setattr(sr.P, "test_batch_size", 16)
+    w = _calibrated_weights("regions", 10, str(tmp_path / "w.pth"), feature_dim=128, regions_k=6)
+    spec = "synthetic:CLICIDE_video_224sq:n=60:q=20:labels=10:size=448:struct=70"
+    r = _run(T.main, (spec, "resnet50", w, 0, 128, 6, 0), (spec, "resnet50", w, -1, 128, 6, 0), monkeypatch)
+    with capsys.disabled():
+        _check(*r, what="siamese_regions_test resnet50 @448 k=6")

@@ -316,3 +316,46 @@ def test_sharded_gallery_leaves_the_fast_path_when_the_data_defeats_it(ops):
     counter = ops.cosine_topk_fast_fallback_counter(ok._ws, 200, 20000, 128, 20, True)
     torch.cuda.synchronize()
     assert int(counter.item()) == 0
+
+
+def _oracle_topk_chunked(Qrows, G, k, chunk=125000):
+    """O.cosine_topk of a few query rows against a gallery that stays on the GPU: 125k-row pieces are copied to the host one at a
+    time (1 GB each), searched by the scalar oracle with their global idx_base, and merged with the canonical comparator."""
+    q = host(Qrows)
+    cs, ci = [], []
+    for lo in range(0, G.size(0), chunk):
+        s, i = O.cosine_topk(q, host(G[lo:lo + chunk]), k, idx_base=lo)
+        cs.append(s); ci.append(i)
+    s, i = np.concatenate(cs, 1), np.concatenate(ci, 1)
+    out_s, out_i = np.empty((q.shape[0], k), np.float32), np.empty((q.shape[0], k), np.int64)
+    for r in range(q.shape[0]):
+        order = np.lexsort((i[r], -s[r].astype(np.float64)))[:k]                 # score desc, index asc
+        out_s[r], out_i[r] = s[r][order], i[r][order]
+    return out_s, out_i
+
+
+def test_config5_full_size_on_one_gpu(ops):
+    """BASELINE configs[4] at its stated size: 10 000 queries x 1 000 000 gallery rows x 2048, top-100, on ONE MI355X (8.2 GB
+    gallery + 4.1 GB fp16 image).  (a) the unsharded fast search, (b) the 8 x 125 k shards a node would hold, each searched with
+    its idx_base, merged with isx_topk_merge: identical bits; (c) the first shard's own 10 k x 125 k lists and (d) the merged
+    lists against the CPU oracle on sampled rows; (e) the all-fp32 search on sampled query rows."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M, N, D, k, P = 10000, 1000000, 2048, 100, 8
+    Q = ops.l2norm_rows(torch.randn(M, D, device="cuda", generator=g))
+    G = torch.empty(N, D, device="cuda")
+    for i in range(0, N, 125000):
+        G[i:i + 125000] = ops.l2norm_rows(torch.randn(125000, D, device="cuda", generator=g))
+    ts, ti = ops.cosine_topk_fast(Q, G, k, gallery_f16=ops.gallery_to_f16(G))
+    assert bool((ts[:, :-1] >= ts[:, 1:]).all()) and int(ti.min()) >= 0 and int(ti.max()) < N
+    parts = [ops.cosine_topk_fast(Q, G[p * N // P:(p + 1) * N // P], k, idx_base=p * N // P) for p in range(P)]
+    ms, mi = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(mi, ti) and torch.equal(ms.view(torch.int32), ts.view(torch.int32))
+    rows = [0, 4242, 9999]
+    os_, oi = O.cosine_topk(host(Q[rows]), host(G[:N // P]), k)                               # (c) the per-GPU shard of config 5
+    np.testing.assert_array_equal(host(parts[0][1][rows]), oi)
+    np.testing.assert_array_equal(host(parts[0][0][rows]), os_)
+    ws_, wi_ = _oracle_topk_chunked(Q[rows], G, k)                                            # (d) whole gallery
+    np.testing.assert_array_equal(host(ti[rows]), wi_)
+    np.testing.assert_array_equal(host(ts[rows]), ws_)
+    fs, fi = ops.cosine_topk(Q[:64].contiguous(), G, k)                                       # (e) every score on the fp32 matrix cores
+    assert torch.equal(fi, ti[:64]) and torch.equal(fs.view(torch.int32), ts[:64].view(torch.int32))

@@ -514,3 +514,47 @@ def test_conv1x1_dual_nhwc(ops, B, H, W, K1, K2, Cout, stride, relu):
     if relu:
         ref = torch.relu(ref)
     np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1)), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_blocked_metrics_bit_identical_and_1m_gallery(ops):
+    """Exact P@1 / mAP without the whole score matrix (utils.metrics.retrieval_metrics, query-row blocks): bit-identical to
+    the one-matrix evaluation at 1 k x 100 k for several block sizes; then a 1 k x 1 M run (4 GB of scores, 1 GB resident
+    at a time) whose AP is checked on sampled queries against the oracle's rank_full + average_precision of the same rows."""
+    from utils import mean_avg_precision, precision1
+    from utils.metrics import retrieval_metrics
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, D = 1000, 100000, 256
+    L = N // 10
+    cent = torch.randn(L, D, device="cuda", generator=g)
+    glab = torch.arange(N, device="cuda") % L
+    qlab = torch.arange(M, device="cuda") % L
+    G = ops.l2norm_rows(cent[glab] + 4.0 * torch.randn(N, D, device="cuda", generator=g))
+    Q = ops.l2norm_rows(cent[qlab] + 4.0 * torch.randn(M, D, device="cuda", generator=g))
+    ts = [(None, int(l), None) for l in qlab.tolist()]
+    rs = [(None, int(l), None) for l in glab.tolist()]
+    sim = ops.cosine_sim(Q, G)
+    want_p, want_map = precision1(sim, ts, rs), mean_avg_precision(sim, ts, rs)
+    for budget in (None, 4 * N * 128, 4 * N * 37):
+        m = retrieval_metrics(Q, G, ts, rs, budget_bytes=budget)
+        assert (m["prec1"], m["correct"], m["total"]) == want_p[:3] and m["max_label"] == want_p[4]
+        assert torch.equal(m["max_sim"], want_p[3]) and m["mAP"] == want_map
+    assert m["blocks"] == (M + 36) // 37 and 0.0 < want_map < 1.0
+    # 1 M-row gallery, 1 k queries, 1 GB of scores at a time
+    N2 = 1000000
+    L2 = N2 // 10
+    cent2 = torch.randn(L2, D, device="cuda", generator=g)
+    glab2 = torch.arange(N2, device="cuda") % L2
+    G2 = torch.empty(N2, D, device="cuda")
+    for lo in range(0, N2, 250000):
+        G2[lo:lo + 250000] = ops.l2norm_rows(cent2[glab2[lo:lo + 250000]] + 4.0 * torch.randn(250000, D, device="cuda", generator=g))
+    Q2 = ops.l2norm_rows(cent2[qlab] + 4.0 * torch.randn(M, D, device="cuda", generator=g))
+    rs2 = [(None, int(l), None) for l in glab2.tolist()]
+    m2 = retrieval_metrics(Q2, G2, ts, rs2, budget_bytes=1 << 30)
+    assert m2["blocks"] == 4 and 0.0 < m2["mAP"] < 1.0
+    rows = [0, 500, 999]
+    sim_rows = O.cosine_sim(host(Q2[rows]), host(G2))
+    ap = O.average_precision(O.rank_full(sim_rows), host(qlab[rows]).astype(np.int32), host(glab2).astype(np.int32))
+    from utils.metrics import _average_precisions
+    got = _average_precisions(ops.cosine_sim(Q2[rows].contiguous(), G2), qlab[rows].int().cpu(), glab2.int().cpu(), 1)
+    np.testing.assert_array_equal(got.numpy(), ap)

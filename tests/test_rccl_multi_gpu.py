@@ -1,0 +1,71 @@
+"""REAL multi-GPU runs (RCCL over xGMI, one process per GPU): skipped unless the box has >= 2 GPUs.  The world_size-2
+gloo tests (tests/test_distributed.py, tests/test_training.py) cover the same drivers on the CPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _n_gpus():
+    try:
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+needs2 = pytest.mark.skipif(_n_gpus() < 2, reason="needs >= 2 GPUs (RCCL)")
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ISX_BENCH_ONE_DEVICE"):
+        env.pop(k, None)
+    return env
+
+
+@needs2
+def test_rccl_sharded_search_and_grad_allreduce(tmp_path):
+    world = min(_n_gpus(), 4)
+    out = str(tmp_path / "r")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rccl_worker.py"), out]
+    p = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = [torch.load("%s.%d" % (out, k)) for k in range(world)]
+    us, ui = r[0]["unsharded"]
+    for k in range(world):
+        for name in ("dist_fast", "dist_f32", "native", "replicated"):
+            s, i = r[k][name]
+            assert torch.equal(i, ui), (k, name)                               # ranked lists: bit-exact, every rank, every exchange path
+            assert torch.equal(s.view(torch.int32), us.view(torch.int32)), (k, name)
+        for n in r[0]["w0"]:
+            assert torch.equal(r[k]["w0"][n], r[0]["w0"][n])                   # broadcast: identical replicas
+        assert torch.equal(r[k]["flat"], r[0]["flat"])                         # every rank holds the same summed gradient
+    np.testing.assert_allclose(r[0]["flat"].numpy(), r[0]["ref_flat"].numpy(), rtol=2e-5, atol=2e-6)
+    assert float(r[0]["flat"].abs().sum()) > 0
+
+
+@needs2
+def test_bench_two_gpus_bare_command_line():
+    """`python bench.py --gpus 2` with nothing around it: self-launch, RCCL, one JSON line."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64",
+           "--gallery", "4000", "--no-shard-bench"]
+    p = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 2 and d["value"] > 0

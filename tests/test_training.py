@@ -104,7 +104,7 @@ def _run_training(rank, world, port, out):
     from train import siamese_descriptor as sd
     from utils import train_gen
     import torch.optim as optim
-    torch.manual_seed(0)
+    torch.manual_seed(1000 * rank)          # replicas start from DIFFERENT weights: train_gen must broadcast rank 0's
     random.seed(0)
     net = _TinyNet()
     P = sd.P
@@ -162,6 +162,53 @@ def test_data_parallel_training_matches_single_process(tmp_path):
         moved += float((a[k].float() - init[k].float()).abs().sum())
     assert moved > 1e-3                                          # training really changed the weights
     assert torch.equal(a["features.1.running_mean"], init["features.1.running_mean"])     # BN frozen (train_bn False)
+
+
+def _run_uneven_reducer(rank, world, port, out):
+    """Rank 0 arms and runs a backward, rank 1 has an empty slice (never arms, no backward); a second step detaches the
+    gradients with set_to_none before the backward.  Every rank must issue the same per-bucket collectives."""
+    sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isx.dp import GradAllReducer, broadcast_module_state
+    torch.manual_seed(7 + rank)
+    net = _TinyNet()
+    broadcast_module_state(net)
+    r = GradAllReducer(list(net.parameters()), bucket_mb=0.00001)          # one bucket per parameter tensor
+    assert len(r.buckets) > 2
+    net.train()
+    x = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(3))
+    res = {}
+    # step 1: only rank 0 computes
+    r.zero_grad()
+    if rank == 0:
+        r.arm()
+        net(x, x, x)[0].sum().backward()
+    r.finish()
+    res["step1"] = r.flat.clone()
+    # step 2: somebody dropped the gradients (optimizer.zero_grad(set_to_none=True)); both ranks compute
+    for p in net.parameters():
+        p.grad = None
+    r.arm()
+    net(x, x, x)[0].sum().backward()
+    r.finish()
+    res["step2"] = r.flat.clone()
+    res["views"] = all(r._is_view(p) for p in r.params)
+    res["w0"] = net.head.weight.detach().clone()
+    torch.save(res, out + ".%d" % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_all_reducer_uneven_ranks_and_detached_grads(tmp_path):
+    out = str(tmp_path / "r")
+    mp.spawn(_run_uneven_reducer, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(a["w0"], b["w0"])                                   # broadcast made the replicas identical
+    assert torch.equal(a["step1"], b["step1"]) and float(a["step1"].abs().sum()) > 0
+    assert torch.equal(a["step2"], b["step2"]) and a["views"] and b["views"]
+    # step 2 = both ranks' (identical) gradients summed = 2 x step 1's single contribution
+    np.testing.assert_allclose(a["step2"].numpy(), 2 * a["step1"].numpy(), rtol=1e-6, atol=1e-7)
 
 
 def test_region_training_runs_and_learns_on_cpu():

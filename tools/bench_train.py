@@ -3,7 +3,9 @@
 DescriptorNet(ResNet-50) with per-epoch hard-negative mining, reference hyper-parameters (batch 64 as 8 micro-batches
 of 8, SGD lr 1e-3 momentum 0.9 wd 5e-4, BN frozen), synthetic 224x224 images.  Prints one JSON object.
     python tools/bench_train.py [--images 512] [--labels 64] [--epochs 2]
-Multi-GPU data-parallel runs use the same entry point under torch.distributed.run (isx/dp.GradAllReducer)."""
+Data parallel: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/bench_train.py`
+-- one rank per GPU (LOCAL_RANK), RCCL process group, every rank takes 1/N of each mini-batch (isx/dp.GradAllReducer,
+weights broadcast from rank 0 by utils.train_gen), rank 0 prints the line."""
 import argparse
 import json
 import os
@@ -22,11 +24,16 @@ def main():
     ap.add_argument("--labels", type=int, default=64)
     ap.add_argument("--epochs", type=int, default=2)
     args = ap.parse_args()
+    import torch.distributed as dist
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     from train import siamese_descriptor as sd
     from utils.dataset import get_pos_couples, synthetic_image_set
     torch.manual_seed(0); random.seed(0)
     P = sd.P
-    P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), 2048
+    P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = local, "resnet50", (7, 7), 2048
     P.train_epochs, P.train_batch_size, P.train_micro_batch, P.test_batch_size = args.epochs, 64, 8, 128
     P.train_loss_int, P.train_test_int, P.untrained_blocks, P.train_epoch_switch = 10 ** 9, 10 ** 9, -1, 1
     tr = synthetic_image_set(args.images, args.labels, seed=1)
@@ -48,7 +55,12 @@ def main():
     marks.append(t1)
     per_epoch = [b - a for a, b in zip(marks[:-1], marks[1:])]
     steady = per_epoch[-1]
-    print(json.dumps({"model": "DescriptorNet(resnet50, 2048)", "images": args.images, "labels": args.labels,
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    print(json.dumps({"model": "DescriptorNet(resnet50, 2048)", "images": args.images, "labels": args.labels, "n_gpus": world,
                       "triplets_per_epoch": n_couples, "epoch_seconds": per_epoch, "total_seconds": t1 - t0,
                       "triplets_per_s": n_couples / steady, "images_fwd_bwd_per_s": 3 * n_couples / steady,
                       "includes": "epoch embedding pass + isx_cosine_sim + isx_mine_negatives + forward/backward of 3 images per triplet + SGD"}))
