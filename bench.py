@@ -198,6 +198,8 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if os.environ.get("ISX_BENCH_MIOPEN_FIND", "0") == "1":      # A/B: let MIOpen benchmark its algorithms for the layers it still runs
+        torch.backends.cudnn.benchmark = True
     from isx import ops, retrieval
     from utils.dataset import synthetic_descriptors, synthetic_images
 

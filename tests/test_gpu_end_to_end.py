@@ -16,6 +16,20 @@ COS_TOL = 1e-5          # |cos_gpu - cos_cpu| on every (query, gallery) pair -- 
 MAP_TOL = 1e-4          # |mAP_gpu - mAP_cpu|
 
 
+@pytest.fixture(autouse=True)
+def _restore_global_params():
+    """The entry points mutate the module-level `P` objects (as the reference's do): put them back for the tests that follow."""
+    import copy
+    from train import classif_finetune, classif_regions, siamese_descriptor, siamese_regions
+    mods = (classif_finetune, classif_regions, siamese_descriptor, siamese_regions)
+    saved = [(m.P, copy.copy(m.P.__dict__), list(m.labels)) for m in mods]
+    yield
+    for (P, d, labs), m in zip(saved, mods):
+        P.__dict__.clear()
+        P.__dict__.update(d)
+        m.labels[:] = labs
+
+
 def _calibrated_weights(kind, n_labels, path, feature_dim=0, regions_k=6):
     """A state dict for `--weights=`: seeded ResNet-50 whose BatchNorm running statistics are CALIBRATED on a batch of the
     synthetic images (one training-mode pass, cumulative average).  With the default identity statistics a random-init
