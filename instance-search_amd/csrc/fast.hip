@@ -394,7 +394,194 @@ __global__ __launch_bounds__(512) void cosine_gemm_f16_big_kernel(const _Float16
     }
 }
 
-static int g_force_f16_tile = -1;        // debug / A-B hook: 0 = 128x128, 1 = 256x256, -1 = automatic
+// ---- 2c. ping-pong variant of the 256x256 tile for D % 64 == 0 (the shipped path of the filter pass) ------------
+// Same block tile, BK and swizzled [row][8 x 16 B] LDS image as 2b, different schedule (lab: scratch/lab/f16_pp_lab.hip):
+//  * operand tiles arrive by LDS-DMA (global_load_lds_dwordx4; the XOR swizzle is applied to the per-lane SOURCE address, the
+//    LDS side of a DMA is lane-linear) as 16-KB half-tiles (128 rows x 64 k) issued 1.5 k-tiles ahead and retired by ONE counted
+//    s_waitcnt vmcnt(4) per k-tile: no staging registers, no ds_write (the LDS store path was what held 2b at 870 TFLOP/s);
+//  * every 128x128 quadrant of the block tile is split 2 (M) x 4 (N) over the 8 waves: a wave owns a 64x32 piece of each quadrant
+//    = 4 x 2 tiles of v_mfma_f32_16x16x32_f16 (same k order per output as the 32x32x16 form: scores bit-identical to 2b);
+//  * a k-tile is two phases -- A: quadrants (0,0) + (0,1) [reads A0, B0, B1], B: quadrants (1,1) + (1,0) [reads A1] -- and a phase is
+//    [operand ds_read_b128s + DMA issue + lgkmcnt(0)] s_barrier [32 MFMAs] s_barrier.  Waves 4-7 run ONE barrier behind waves 0-3,
+//    so on every SIMD one wave is in its MFMA segment while its partner (wave w + 4) is in its load segment;
+//  * hazards: a half-tile is read one phase or more after the barrier that follows every wave's vmcnt wait for it (RAW), and is
+//    re-staged only after a barrier that follows the lgkmcnt(0) of both wave groups' reads of it (WAR).
+// Measured (10 240 x 16 384, plain store): 1 204 TFLOP/s at D = 2048 and 1 370 at D = 4096 against 861 / 1 020 for 2b; the k loop
+// itself runs at ~1.3 us per k-tile (1 650 TFLOP/s), the rest is the output burst of the plain-store epilogue.
+constexpr int PP_HT_B = 128 * HBK * 2;                   // one half-tile: 16 KB
+constexpr int PP_BUF_B = 4 * PP_HT_B;                    // [A0][A1][B0][B1] = 64 KB per k-tile
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// half-tile kinds in issue order within a k-tile: A0, B0 (first read in phase A), B1 (phase A), A1 (phase B) -> slot in the buffer
+__device__ __forceinline__ constexpr int pp_slot(int j) { return j == 0 ? 0 : j == 1 ? 2 : j == 2 ? 3 : 1; }
+
+template <bool FILTER>
+__global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __restrict__ Q, int64_t M,
+                                                          const _Float16* __restrict__ G, int64_t N, int D,
+                                                          float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n,
+                                                          const float* __restrict__ thr, uint8_t* __restrict__ gflag, int ngrp) {
+    __shared__ __attribute__((aligned(1024))) char lds[2 * PP_BUF_B];       // the ONLY LDS object (a second one makes hipcc drain vmcnt before ds_reads)
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    constexpr int GN = 8;
+    const int per_group = GN * tiles_m, gid = wg / per_group, first_n = gid * GN;
+    const int gsz = min(GN, tiles_n - first_n), within = wg - gid * per_group;
+    const int64_t m0 = (int64_t)(within / gsz) * GBM, n0 = (int64_t)(first_n + within % gsz) * GBN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    f32x4_t acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][bb][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // DMA sources: half-tile j, instruction i fills image rows wave*16 + i*8 + lane/8; slot lane%8 of a row holds chunk slot ^ hswz(row)
+    const _Float16* gsrc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool isb = pp_slot(j) >= 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wave * 16 + i * 8 + (lane >> 3);
+            int64_t gr = (isb ? n0 : m0) + (pp_slot(j) & 1) * 128 + r;
+            const int64_t lim = isb ? N : M;
+            gr = gr < lim ? gr : lim - 1;                       // clamp: rows past the edge are never stored
+            gsrc[j][i] = (isb ? G : Q) + gr * D + (((lane & 7) ^ hswz(r)) << 3);
+        }
+    }
+    const int T = D / HBK;                                      // D % 64 == 0 (launcher)
+    auto issue = [&](int j, int t) {                            // half-tile j of k-tile t -> buffer t & 1
+        char* dst = lds + (t & 1) * PP_BUF_B + pp_slot(j) * PP_HT_B + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j][i] + t * HBK),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+    // operand fragments of the 16x16x32 MFMA: lane l holds row (l & 15), chunk 4 s + l / 16 of its 16-row block
+    const int x0 = (lane >> 4) ^ ((lane >> 1) & 7);               // chunk ^ hswz(row) for s = 0 (block bases are multiples of 16 rows)
+    const int lrow = (lane & 15) * 128;
+    int a_ad[2], b_ad[2];
+    a_ad[0] = wm * 64 * 128 + lrow + (x0 << 4);
+    a_ad[1] = wm * 64 * 128 + lrow + ((x0 ^ 4) << 4);
+    b_ad[0] = 2 * PP_HT_B + wn * 32 * 128 + lrow + (x0 << 4);
+    b_ad[1] = 2 * PP_HT_B + wn * 32 * 128 + lrow + ((x0 ^ 4) << 4);
+    half8 af[4][2], bf[2][2][2];
+    auto read_a = [&](const char* buf, int ah) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) af[i][s] = *reinterpret_cast<const half8*>(buf + ah * PP_HT_B + i * 2048 + a_ad[s]);
+    };
+    auto read_b = [&](const char* buf, int bh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) bf[bh][j][s] = *reinterpret_cast<const half8*>(buf + bh * PP_HT_B + j * 2048 + b_ad[s]);
+    };
+    auto mfmas = [&](int ah) {
+        __builtin_amdgcn_s_setprio(1);                          // also keeps hipcc from moving MFMAs across the barriers
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah][bh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][s], bf[bh][j][s], acc[ah][bh][i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: k-tile 0 and half of k-tile 1 in flight; k-tile 0 landed and visible
+#pragma unroll
+    for (int h = 0; h < 6; ++h)
+        if (h / 4 < T) issue(h % 4, h / 4);
+    if (T > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();                  // waves 4-7 run one barrier behind (wave-uniform branch)
+
+    for (int t = 0; t < T; ++t) {
+        const char* buf = lds + (t & 1) * PP_BUF_B;
+        // ---- phase A
+        read_a(buf, 0);
+        read_b(buf, 0);
+        read_b(buf, 1);
+        if (t + 1 < T) { issue(2, t + 1); issue(3, t + 1); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase B: k-tile t + 1 retired before the barrier that precedes its first read
+        read_a(buf, 1);
+        if (t + 2 < T) { issue(0, t + 2); issue(1, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();                  // pairs the extra barrier of waves 4-7: every LDS read is behind us now
+
+    // epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r.  The two 16-column tiles j = 0, 1 of a
+    // piece form one 32-column group of the filter.
+    float* thr_s = reinterpret_cast<float*>(lds);
+    if (FILTER) {
+        if (tid < GBM) thr_s[tid] = (m0 + tid < M) ? thr[m0 + tid] : INFINITY;
+        __syncthreads();
+    }
+    const int l15 = lane & 15, lq = lane >> 4;
+#pragma unroll
+    for (int ah = 0; ah < 2; ++ah) {
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh) {
+            const int64_t ng = n0 + bh * 128 + wn * 32;              // first column of this wave's 32-column group (uniform)
+            const int64_t na = ng + l15, nb = na + 16;
+            const bool a_ok = na < N, b_ok = nb < N;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rbase = ah * 128 + wm * 64 + i * 16 + lq * 4;   // tile row of r = 0
+                float* cp = C + (m0 + rbase) * ldc + na;
+                uint8_t* fp = FILTER ? gflag + (m0 + rbase) * (int64_t)ngrp + (ng >> 5) : nullptr;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool row_ok = (m0 + rbase + r < M);
+                    const float va = acc[ah][bh][i][0][r], vb = acc[ah][bh][i][1][r];
+                    if (FILTER) {
+                        const float t = thr_s[rbase + r];
+                        const unsigned long long qm = __ballot(a_ok && va >= t) | __ballot(b_ok && vb >= t);
+                        const bool qq = ((qm >> (16 * lq)) & 0xFFFFull) != 0ull;      // any of this row's 32 columns
+                        if (row_ok && ng < N) {
+                            if (l15 == 0) fp[(int64_t)r * ngrp] = qq ? 1 : 0;
+                            if (qq) {
+                                if (a_ok) cp[(int64_t)r * ldc] = va;
+                                if (b_ok) cp[(int64_t)r * ldc + 16] = vb;
+                            }
+                        }
+                    } else if (row_ok) {
+                        if (a_ok) cp[(int64_t)r * ldc] = va;
+                        if (b_ok) cp[(int64_t)r * ldc + 16] = vb;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static int g_force_f16_tile = -1;        // debug / A-B hook: 0 = 128x128, 1 = 256x256, 2 = 256x256 register-staged (2b), -1 = automatic
 
 int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C, int64_t ldc, const float* thr,
                            uint8_t* gflag, hipStream_t st) {
@@ -404,11 +591,14 @@ int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, 
     const int ngrp = (int)((N + 31) / 32);
     // 256x256 tiles (one 512-thread workgroup per CU) once they fill the chip for >= 2 rounds
     const int64_t btm = (M + GBM - 1) / GBM, btn = (N + GBN - 1) / GBN;
-    const bool big = g_force_f16_tile >= 0 ? g_force_f16_tile == 1 : (btm * btn >= 512);
+    const bool big = g_force_f16_tile >= 0 ? g_force_f16_tile >= 1 : (btm * btn >= 512);
     if (big) {
         const dim3 grid((unsigned)(btm * btn)), block(512);
         const bool fullk = (D % HBK == 0);
-        if (gflag && fullk) hipLaunchKernelGGL((cosine_gemm_f16_big_kernel<true, true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
+        const bool pp = fullk && g_force_f16_tile != 2;            // 2 = the register-staged 2b kernel on full-k shapes too (A/B)
+        if (gflag && pp) hipLaunchKernelGGL((gemm_f16_pp_kernel<true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
+        else if (pp) hipLaunchKernelGGL((gemm_f16_pp_kernel<false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
+        else if (gflag && fullk) hipLaunchKernelGGL((cosine_gemm_f16_big_kernel<true, true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
         else if (gflag) hipLaunchKernelGGL((cosine_gemm_f16_big_kernel<true, false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
         else if (fullk) hipLaunchKernelGGL((cosine_gemm_f16_big_kernel<false, true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);
         else hipLaunchKernelGGL((cosine_gemm_f16_big_kernel<false, false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, (int)btm, (int)btn, thr, gflag, ngrp);

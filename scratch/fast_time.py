@@ -13,7 +13,7 @@ gh = ops.gallery_to_f16(G)
 ws = torch.empty((ops.cosine_topk_fast_workspace(M, N, D, k, True),), device=dev, dtype=torch.uint8)
 ws0 = torch.empty((ops.cosine_topk_workspace(M, N, D, k),), device=dev, dtype=torch.uint8)
 ref = ops.cosine_topk(Q, G, k, ws=ws0)
-for tile in (0, 1):
+for tile in (2, 1, 2, 1):
     lib().isx_debug_set_f16_tile(tile)
     fn = lambda: ops.cosine_topk_fast(Q, G, k, gallery_f16=gh, ws=ws)
     out = fn(); torch.cuda.synchronize()
