@@ -33,6 +33,7 @@
 //   eps_i = (2^-10 + 2^-22 + 3 D 2^-24) |q_i| max_j|g_j|  +  D 2^-26 qmax gmax        (inflated by 1 %)
 // Matrices whose largest |x| is outside [2^-20, 2^15], or not finite, take the exact fp32 path.
 #include <hip/hip_fp16.h>
+#include <type_traits>
 
 #include "isx_internal.hpp"
 
@@ -537,46 +538,69 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __rest
     if (wm == 0) __builtin_amdgcn_s_barrier();                  // pairs the extra barrier of waves 4-7: every LDS read is behind us now
 
     // epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r.  The two 16-column tiles j = 0, 1 of a
-    // piece form one 32-column group of the filter.
-    float* thr_s = reinterpret_cast<float*>(lds);
+    // piece form one 32-column group of the filter.  The k loop is short (fp16 rate), so the epilogue is kept lean: thresholds
+    // come from LDS (one 16-B read per four rows), the "any score of the group >= thr" test is two compares + wave ballots per row,
+    // group flags are collected in LDS ([group][row] bytes, four rows per ds_write_b32) and leave as eight byte stores per row
+    // at the end; scores are stored only for flagged groups.
+    float* thr_s = reinterpret_cast<float*>(lds);                       // 256 floats
+    uint8_t* flg_s = reinterpret_cast<uint8_t*>(lds) + 1024;            // [8 groups][256 rows]
     if (FILTER) {
         if (tid < GBM) thr_s[tid] = (m0 + tid < M) ? thr[m0 + tid] : INFINITY;
         __syncthreads();
     }
     const int l15 = lane & 15, lq = lane >> 4;
+    const bool interior = (m0 + GBM <= M) && (n0 + GBN <= N);           // uniform: the common case carries no edge tests at all
+    auto store_tile = [&](auto IN) {
+        constexpr bool IN_ = decltype(IN)::value;
 #pragma unroll
-    for (int ah = 0; ah < 2; ++ah) {
+        for (int ah = 0; ah < 2; ++ah) {
 #pragma unroll
-        for (int bh = 0; bh < 2; ++bh) {
-            const int64_t ng = n0 + bh * 128 + wn * 32;              // first column of this wave's 32-column group (uniform)
-            const int64_t na = ng + l15, nb = na + 16;
-            const bool a_ok = na < N, b_ok = nb < N;
+            for (int bh = 0; bh < 2; ++bh) {
+                const int64_t ng = n0 + bh * 128 + wn * 32;              // first column of this wave's 32-column group (uniform)
+                const int64_t na = ng + l15, nb = na + 16;
+                const bool a_ok = IN_ || na < N, b_ok = IN_ || nb < N;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int rbase = ah * 128 + wm * 64 + i * 16 + lq * 4;   // tile row of r = 0
-                float* cp = C + (m0 + rbase) * ldc + na;
-                uint8_t* fp = FILTER ? gflag + (m0 + rbase) * (int64_t)ngrp + (ng >> 5) : nullptr;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool row_ok = (m0 + rbase + r < M);
-                    const float va = acc[ah][bh][i][0][r], vb = acc[ah][bh][i][1][r];
+                for (int i = 0; i < 4; ++i) {
+                    const int rbase = ah * 128 + wm * 64 + i * 16 + lq * 4;   // tile row of r = 0
+                    float* cp = C + (m0 + rbase) * ldc + na;
                     if (FILTER) {
-                        const float t = thr_s[rbase + r];
-                        const unsigned long long qm = __ballot(a_ok && va >= t) | __ballot(b_ok && vb >= t);
-                        const bool qq = ((qm >> (16 * lq)) & 0xFFFFull) != 0ull;      // any of this row's 32 columns
-                        if (row_ok && ng < N) {
-                            if (l15 == 0) fp[(int64_t)r * ngrp] = qq ? 1 : 0;
-                            if (qq) {
+                        const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(thr_s + rbase);
+                        unsigned fl = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float va = acc[ah][bh][i][0][r], vb = acc[ah][bh][i][1][r];
+                            const unsigned long long qm = IN_ ? (__ballot(va >= t4[r]) | __ballot(vb >= t4[r]))
+                                                              : (__ballot(a_ok && va >= t4[r]) | __ballot(b_ok && vb >= t4[r]));
+                            const bool qq = ((unsigned)(qm >> (lane & 48)) & 0xFFFFu) != 0u;      // any of this row's 32 columns
+                            fl |= (qq ? 1u : 0u) << (8 * r);
+                            if (qq && (IN_ || m0 + rbase + r < M)) {
                                 if (a_ok) cp[(int64_t)r * ldc] = va;
                                 if (b_ok) cp[(int64_t)r * ldc + 16] = vb;
                             }
                         }
-                    } else if (row_ok) {
-                        if (a_ok) cp[(int64_t)r * ldc] = va;
-                        if (b_ok) cp[(int64_t)r * ldc + 16] = vb;
+                        if (l15 == 0) *reinterpret_cast<unsigned*>(flg_s + (bh * 4 + wn) * 256 + rbase) = fl;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            if (IN_ || m0 + rbase + r < M) {
+                                if (a_ok) cp[(int64_t)r * ldc] = acc[ah][bh][i][0][r];
+                                if (b_ok) cp[(int64_t)r * ldc + 16] = acc[ah][bh][i][1][r];
+                            }
+                        }
                     }
                 }
             }
+        }
+    };
+    if (interior) store_tile(std::true_type{});
+    else store_tile(std::false_type{});
+    if (FILTER) {
+        __syncthreads();
+        if (tid < GBM && m0 + tid < M) {
+            uint8_t* fp = gflag + (m0 + tid) * (int64_t)ngrp + (n0 >> 5);
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (interior || n0 + g * 32 < N) fp[g] = flg_s[g * 256 + tid];
         }
     }
 }

@@ -189,6 +189,52 @@ def test_f16_gemm_is_exact_on_half_inputs(ops, M, N, D):
     assert np.abs(sim[0, 1:]).max() > 0                                  # subnormal operands contributed
 
 
+@pytest.fixture
+def force_f16_tile():
+    """isx_debug_set_f16_tile: 0 = 128x128, 1 = 256x256 (ping-pong LDS-DMA kernel when D % 64 == 0), 2 = 256x256 register-staged."""
+    from isx._lib import lib
+    f = lib().isx_debug_set_f16_tile
+    f.restype, f.argtypes = None, [ctypes.c_int]
+    yield f
+    f(-1)
+
+
+@pytest.mark.parametrize("M,N,D", [(130, 257, 64), (300, 1000, 128), (513, 700, 192), (257, 600, 2048), (256, 512, 256), (1, 1, 64)])
+def test_f16_pingpong_kernel_edge_shapes(ops, force_f16_tile, M, N, D):
+    """The ping-pong 256x256 kernel (LDS-DMA half-tiles, 16x16x32 MFMA; csrc/fast.hip 2c) on ragged M / N, one, two and three
+    k-tiles: same bits as the 128x128 and the register-staged 256x256 kernels, and inside the fp32-accumulation bound."""
+    rng = np.random.default_rng(M + N + D)
+    q = rng.standard_normal((M, D)).astype(np.float16)
+    g = rng.standard_normal((N, D)).astype(np.float16)
+    out = {}
+    for tile in (0, 1, 2):
+        force_f16_tile(tile)
+        out[tile] = host(ops.cosine_sim_f16(dev(q), dev(g)))
+    np.testing.assert_array_equal(out[1].view(np.int32), out[0].view(np.int32))
+    np.testing.assert_array_equal(out[1].view(np.int32), out[2].view(np.int32))
+    want = q.astype(np.float64) @ g.astype(np.float64).T
+    bound = (np.abs(q.astype(np.float64)) @ np.abs(g.astype(np.float64)).T) * D * 2.0 ** -23 + 1e-30
+    assert (np.abs(out[1] - want) <= bound).all()
+
+
+@pytest.mark.parametrize("M,N,D,k", [(37, 9000, 64, 10), (300, 20000, 128, 100), (513, 30000, 192, 33)])
+def test_fast_search_through_the_pingpong_filter_on_small_shapes(ops, force_f16_tile, M, N, D, k):
+    """Forces the 256x256 ping-pong filter kernel (normally reserved for launches of >= 512 tiles) on shapes with ragged edges
+    in both the plain (bootstrap chunk) and the filter epilogue: the search result must still equal the oracle bit for bit."""
+    rng = np.random.default_rng(k)
+    Q, G = unit(rng, M, D), unit(rng, N, D)
+    force_f16_tile(1)
+    check_vs_oracle(ops, Q, G, k, idx_base=3)
+    # narrow chunks: several filtered chunks with a ragged last one
+    Qd, Gd = dev(Q), dev(G)
+    need = ops.cosine_topk_fast_workspace(M, N, D, k, True)
+    ws = torch.empty((max(need // 3, 1 << 20),), dtype=torch.uint8, device="cuda")
+    want_s, want_i = O.cosine_topk(Q, G, k, idx_base=3)
+    ts, ti = ops.cosine_topk_fast(Qd, Gd, k, idx_base=3, gallery_f16=ops.gallery_to_f16(Gd), ws=ws)
+    np.testing.assert_array_equal(host(ti), want_i)
+    np.testing.assert_array_equal(host(ts).view(np.int32), want_s.view(np.int32))
+
+
 def test_gallery_to_f16_scaling(ops):
     rng = np.random.default_rng(21)
     G = unit(rng, 500, 64) * np.float32(0.3)
