@@ -1,14 +1,22 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output under gpurun_out/ into the tracked summaries of profiles/.
 
-  python profiles/summarize_prof.py <round-tag> <kernel_stats.csv> [<pmc FETCH_SIZE csv> <pmc WRITE_SIZE csv>]
+  python profiles/summarize_prof.py <tag> <dir of `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`>
+                                    [<dir of the --pmc FETCH_SIZE pass> <dir of the --pmc WRITE_SIZE pass>]
 
-Writes profiles/<tag>_kernel_stats.csv (every isx:: kernel + the 12 heaviest others) and, when
-PMC passes are given, profiles/<tag>_pmc_hbm.csv plus profiles/roofline_traffic.json (HBM bytes per
-launch = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB: MI355X_MICROARCH.md, FETCH_SIZE reads 1/2 of wide
-coalesced loads on gfx950, WRITE_SIZE is exact)."""
+Writes
+  profiles/<tag>_kernel_stats.csv           every isx:: kernel + the 12 heaviest others (the rocprofv3 --stats table)
+  profiles/<tag>_isx_kernels_by_shape.csv   libisx kernels averaged per launch shape (grid size) over the whole run
+  profiles/<tag>_step_breakdown.csv         ONE steady-state bench step (the launches between two consecutive gap_l2 launches)
+and, when the two PMC passes are given (same command, counters in passes of their own: FETCH_SIZE and WRITE_SIZE do not fit one pass),
+  profiles/<tag>_pmc_hbm.csv                HBM bytes per kernel family of one steady-state step
+  profiles/roofline_traffic.json            the same numbers keyed the way bench.py looks them up, stamped with their source
+HBM bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced
+reads, WRITE_SIZE is exact; both count at the L2's fabric side, so Infinity-Cache hits are included)."""
 import collections
 import csv
+import datetime
+import glob
 import json
 import os
 import sys
@@ -16,11 +24,48 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit("no *%s under %s" % (suffix, d))
+    return hits[-1]
+
+
+def is_isx(name):
+    return "isx::" in name or "_ZN3isx" in name
+
+
+def family(name):
+    """bench.py's roofline family of a kernel name (None: not a family the bench reports)."""
+    if "conv1x1_dual_nhwc_kernel" in name:
+        return "isx_conv1x1_dual_nhwc"
+    if "conv3x3_nhwc_kernel" in name:
+        return "isx_conv3x3_nhwc"
+    if "gap_l2_nhwc_kernel" in name or "gap_l2_kernel" in name:
+        return "gap_l2"
+    if "cosine_gemm_kernel<" in name:
+        args = name.split("cosine_gemm_kernel<", 1)[1].split(">", 1)[0].replace(" ", "").split(",")
+        return "isx_conv1x1_nhwc" if args[3] == "2" else "cosine_gemm"
+    return None
+
+
+def one_step(rows, name_key, start_key):
+    """The launches of one steady-state step: after the second-to-last gap_l2 launch up to (and including) the last one."""
+    rows = sorted(rows, key=lambda r: int(r[start_key]))
+    idx = [i for i, r in enumerate(rows) if "gap_l2" in r[name_key]]
+    if len(idx) < 3:
+        raise SystemExit("fewer than three steps in the trace")
+    a, b = idx[-3], idx[-2]                        # not the very last step: the instrumented pass may follow different paths
+    return rows[a + 1:b + 1]
+
+
 def main():
-    tag, stats = sys.argv[1], sys.argv[2]
+    tag, run_dir = sys.argv[1], sys.argv[2]
+    stats = find(run_dir, "_kernel_stats.csv")
+    trace = find(run_dir, "_kernel_trace.csv")
     rows = list(csv.DictReader(open(stats)))
-    keep = [r for r in rows if "isx::" in r["Name"] or "_ZN3isx" in r["Name"]]
-    others = [r for r in rows if "isx::" not in r["Name"] and "_ZN3isx" not in r["Name"]][:12]
+    keep = [r for r in rows if is_isx(r["Name"])]
+    others = [r for r in rows if not is_isx(r["Name"])][:12]
     with open(os.path.join(HERE, tag + "_kernel_stats.csv"), "w", newline="") as f:
         w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
         w.writeheader()
@@ -28,43 +73,52 @@ def main():
             r = dict(r)
             r["Name"] = r["Name"][:160]
             w.writerow(r)
-    # per-launch-shape averages of the hand-written kernels from the kernel trace next to the stats file
-    trace = stats.replace("_kernel_stats.csv", "_kernel_trace.csv")
-    if os.path.exists(trace):
-        per = collections.defaultdict(list)
-        for r in csv.DictReader(open(trace)):
-            if "isx::" in r["Kernel_Name"] or "_ZN3isx" in r["Kernel_Name"]:
-                per[(r["Kernel_Name"].split("(")[0][:90], r["Grid_Size_X"], r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-        with open(os.path.join(HERE, tag + "_isx_kernels_by_shape.csv"), "w", newline="") as f:
-            w = csv.writer(f)
-            w.writerow(["kernel", "grid_threads", "workgroup", "launches", "avg_us", "min_us", "max_us"])
-            for (k, g, wg), v in sorted(per.items()):
-                w.writerow([k, g, wg, len(v), "%.1f" % (sum(v) / len(v) / 1e3), "%.1f" % (min(v) / 1e3), "%.1f" % (max(v) / 1e3)])
+    trows = list(csv.DictReader(open(trace)))
+    per = collections.defaultdict(list)
+    for r in trows:
+        if is_isx(r["Kernel_Name"]):
+            per[(r["Kernel_Name"].split("(")[0][:90], r["Grid_Size_X"], r["Workgroup_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(HERE, tag + "_isx_kernels_by_shape.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid_threads", "workgroup", "launches", "avg_us", "min_us", "max_us"])
+        for (k, g, wg), v in sorted(per.items()):
+            w.writerow([k, g, wg, len(v), "%.1f" % (sum(v) / len(v) / 1e3), "%.1f" % (min(v) / 1e3), "%.1f" % (max(v) / 1e3)])
+    step = one_step(trows, "Kernel_Name", "Start_Timestamp")
+    wall = (int(step[-1]["End_Timestamp"]) - int(step[0]["Start_Timestamp"])) / 1e3
+    agg = collections.OrderedDict()
+    for r in step:
+        k = (r["Kernel_Name"].split("(")[0][:90], r["Grid_Size_X"])
+        a = agg.setdefault(k, [0, 0.0])
+        a[0] += 1
+        a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    with open(os.path.join(HERE, tag + "_step_breakdown.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "grid_threads", "launches_in_step", "us_in_step", "share_of_step_wall", "family"])
+        for (k, g), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, g, n, "%.1f" % us, "%.4f" % (us / wall), family(k) or ""])
+        w.writerow(["(step wall clock, first launch start to last launch end)", "", len(step), "%.1f" % wall, "1.0", ""])
     if len(sys.argv) >= 5:
-        per = collections.defaultdict(lambda: collections.defaultdict(list))
-        for cname, path in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
-            for r in csv.DictReader(open(path)):
-                if r["Counter_Name"] == cname and ("isx::" in r["Kernel_Name"] or "_ZN3isx" in r["Kernel_Name"]):
-                    per[(r["Kernel_Name"][:100], r["Grid_Size"])][cname].append(float(r["Counter_Value"]))
+        fam = collections.defaultdict(lambda: {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
+        for cname, d in (("FETCH_SIZE", sys.argv[3]), ("WRITE_SIZE", sys.argv[4])):
+            crow = [r for r in csv.DictReader(open(find(d, "_counter_collection.csv"))) if r["Counter_Name"] == cname]
+            for r in one_step(crow, "Kernel_Name", "Start_Timestamp"):
+                fm = family(r["Kernel_Name"])
+                if fm:
+                    fam[fm][cname] += float(r["Counter_Value"])
+                    if cname == "FETCH_SIZE":
+                        fam[fm]["launches"] += 1
         out = {}
         with open(os.path.join(HERE, tag + "_pmc_hbm.csv"), "w", newline="") as f:
             w = csv.writer(f)
-            w.writerow(["kernel", "grid_size", "launches", "FETCH_SIZE_KiB_avg", "WRITE_SIZE_KiB_avg", "hbm_bytes_per_launch_corrected"])
-            for (k, grid), d in sorted(per.items()):
-                fe = sum(d["FETCH_SIZE"]) / max(1, len(d["FETCH_SIZE"]))
-                wr = sum(d["WRITE_SIZE"]) / max(1, len(d["WRITE_SIZE"]))
-                tot = (2.0 * fe + wr) * 1024.0
-                w.writerow([k, grid, len(d["FETCH_SIZE"]), "%.1f" % fe, "%.1f" % wr, "%.0f" % tot])
-                out.setdefault(k.split("(")[0].replace("void isx::", "").split("<")[0], {})[grid] = tot
-        # bench.py looks the GEMM traffic up by problem shape: grid = tiles * 256 threads
-        traffic = {"cosine_gemm_kernel": {}}
-        for grid, tot in out.get("cosine_gemm_kernel", {}).items():
-            tiles = int(grid) // 256
-            # bench step 1024 x 10000: whichever tile shape the launcher picked (128x128, 64x128, 128x64, 64x64)
-            for shape, ts in (("1024x10000x2048", (8 * 79, 16 * 79, 8 * 157, 16 * 157)), ("10000x32768x2048", (79 * 256,))):
-                if tiles in ts:
-                    traffic["cosine_gemm_kernel"][shape] = tot
-        json.dump(traffic, open(os.path.join(HERE, "roofline_traffic.json"), "w"), indent=1)
+            w.writerow(["family", "launches_in_step", "FETCH_SIZE_KiB_sum", "WRITE_SIZE_KiB_sum", "hbm_bytes_per_step_corrected(2*FETCH+WRITE)"])
+            for fm, d in sorted(fam.items()):
+                tot = (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0
+                w.writerow([fm, d["launches"], "%.1f" % d["FETCH_SIZE"], "%.1f" % d["WRITE_SIZE"], "%.0f" % tot])
+                out[fm] = {"bytes": tot, "launches": d["launches"]}
+        src = ("profiles/%s_pmc_hbm.csv: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (kernel trace only) over one steady-state step "
+               "of `python bench.py`, bytes = 2 x FETCH_SIZE + WRITE_SIZE, summed over the family's launches in the step; collected %s"
+               % (tag, datetime.date.today().isoformat()))
+        json.dump({"source": src, "kernels": out}, open(os.path.join(HERE, "roofline_traffic.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
