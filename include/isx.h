@@ -12,8 +12,13 @@
  *   - every pointer is a DEVICE pointer owned by the caller, row-major contiguous;
  *     fp32 values, int64 indices, int32 labels, fp64 AP values
  *   - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*) and
- *     returns; no allocation, no synchronisation, no global state: safe to capture
- *     in a hipGraph and re-entrant from several host threads on distinct streams
+ *     returns; no allocation, no synchronisation, no global state in the entry points
+ *     declared here: safe to capture in a hipGraph and re-entrant from several host
+ *     threads on distinct streams.  (The library also exports four UNDECLARED
+ *     process-global A/B hooks -- isx_debug_set_gemm_cfg, isx_debug_set_conv_cfg,
+ *     isx_debug_set_f16_tile, isx_debug_fast_fallback_rows -- for tests and
+ *     scratch/ timing scripts: they force a tile shape for every later call of
+ *     the process, never change a result, and are not part of this ABI.)
  *   - return 0 = ISX_OK, <0 = error; isx_last_error() gives a thread-local message
  *   - canonical ranking order everywhere: (score DESCENDING, index ASCENDING),
  *     -0.0 == +0.0; gallery indices must be < 2^32

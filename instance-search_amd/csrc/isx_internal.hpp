@@ -19,6 +19,11 @@ int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t
 int launch_conv1x1_gemm(const float* x, int64_t M, const float* w, int64_t N, int D, float* y, const float* bias, const float* residual, int relu,
                         hipStream_t st);
 
+// Streaming variant for the HBM-bound Cin = 64 layers (stream1x1.hip): persistent workgroups, weights in registers, pixel tiles by LDS-DMA.
+bool conv1x1_stream_applicable(int64_t M, int Cin, int Cout, const float* x);
+int launch_conv1x1_stream(const float* x, int64_t M, const float* w, int Cout, const float* bias, const float* res, int relu, float* y,
+                          hipStream_t st);
+
 // fp16-operand variant (fast.hip): approximate scores, fp32 accumulate; gflag == nullptr -> plain GEMM.
 int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C, int64_t ldc, const float* thr,
                     uint8_t* gflag, hipStream_t st);

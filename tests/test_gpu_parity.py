@@ -416,6 +416,34 @@ def test_conv1x1_nhwc(ops, M, Cin, Cout, res, relu):
     np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1).reshape(M, Cout)), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("M,Cout", [(16384, 256), (16384 + 77, 256), (40000, 64), (16384 + 5, 64), (70001, 256)])
+@pytest.mark.parametrize("res,relu", [(False, True), (True, True), (True, False)])
+def test_conv1x1_stream_equals_general(ops, M, Cout, res, relu):
+    """Cin = 64 layers with >= 16384 pixels take the streaming kernel (csrc/stream1x1.hip: persistent workgroups, weights in
+    registers, LDS-DMA pixel ring): same bits as the tiled GEMM path (debug cfg 9) and as the oracle's fma chain, including
+    ragged last tiles and more tiles than workgroups (70001 pixels = 1094 tiles of 64 on 256 workgroups)."""
+    from isx._lib import lib
+    rng = np.random.default_rng(M + Cout)
+    x = np.maximum(rng.standard_normal((M, 64), dtype=np.float32), 0)
+    w = rng.standard_normal((Cout, 64), dtype=np.float32) * np.float32(0.125)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    r = rng.standard_normal((M, Cout), dtype=np.float32) if res else None
+    xt = dev(x).view(1, M, 1, 64).permute(0, 3, 1, 2)
+    rt = dev(r).view(1, M, 1, Cout).permute(0, 3, 1, 2) if res else None
+    set_cfg = lib().isx_debug_set_conv_cfg
+    try:
+        set_cfg(9)
+        general = host(ops.conv1x1_nhwc(xt, dev(w), dev(b), rt, relu).permute(0, 2, 3, 1).reshape(M, Cout))
+        set_cfg(-1)
+        stream = host(ops.conv1x1_nhwc(xt, dev(w), dev(b), rt, relu).permute(0, 2, 3, 1).reshape(M, Cout))
+    finally:
+        set_cfg(-1)
+    np.testing.assert_array_equal(stream.view(np.int32), general.view(np.int32))
+    rows = np.r_[0:300, M // 2:M // 2 + 300, M - 300:M]                   # oracle on three row windows (first, middle, ragged end)
+    want = O.conv1x1_nhwc(x[rows], w, b, r[rows] if res else None, relu)
+    np.testing.assert_array_equal(stream[rows], want)
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,stride", [(1, 4, 4, 32, 32, 1), (2, 7, 7, 64, 64, 1), (3, 8, 6, 64, 128, 2), (2, 14, 14, 128, 96, 1),
                                                    (1, 9, 11, 256, 130, 2), (5, 5, 5, 32, 64, 1), (2, 1, 1, 32, 32, 1), (1, 3, 2, 512, 512, 2)])
 @pytest.mark.parametrize("res,relu", [(False, True), (True, True), (False, False)])
