@@ -285,9 +285,9 @@ ISX_API int isx_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float* w,
     if (M == 0) return ISX_OK;
     ISX_REQUIRE(x && w && bias && y, "isx_conv1x1_nhwc: null pointer");
     ISX_REQUIRE(y != x && y != residual, "isx_conv1x1_nhwc: y must not alias x or residual");
-    // HBM-bound first-stage layers (Cin = 64): streaming kernel (stream1x1.hip), same arithmetic; debug cfg 9 = general path (A/B)
-    if (g_force_conv_cfg != 9 && conv1x1_stream_applicable(M, Cin, Cout, x))
-        return launch_conv1x1_stream(x, M, w, Cout, bias, residual, relu ? 1 : 0, y, (hipStream_t)stream);
+    // first-stage layers at 56x56 (Cin 64 / 256, HBM-bound): streaming kernel (stream1x1.hip), same arithmetic; debug cfg 9 = general path (A/B)
+    if (g_force_conv_cfg != 9 && conv1x1_stream_applicable(M, Cin, Cout, x, residual))
+        return launch_conv1x1_stream(x, M, w, Cin, Cout, bias, residual, relu ? 1 : 0, y, (hipStream_t)stream);
     return launch_conv1x1_gemm(x, M, w, Cout, Cin, y, bias, residual, relu ? 1 : 0, (hipStream_t)stream);
 }
 

@@ -20,8 +20,8 @@ int launch_conv1x1_gemm(const float* x, int64_t M, const float* w, int64_t N, in
                         hipStream_t st);
 
 // Streaming variant for the HBM-bound Cin = 64 layers (stream1x1.hip): persistent workgroups, weights in registers, pixel tiles by LDS-DMA.
-bool conv1x1_stream_applicable(int64_t M, int Cin, int Cout, const float* x);
-int launch_conv1x1_stream(const float* x, int64_t M, const float* w, int Cout, const float* bias, const float* res, int relu, float* y,
+bool conv1x1_stream_applicable(int64_t M, int Cin, int Cout, const float* x, const float* res);
+int launch_conv1x1_stream(const float* x, int64_t M, const float* w, int Cin, int Cout, const float* bias, const float* res, int relu, float* y,
                           hipStream_t st);
 
 // fp16-operand variant (fast.hip): approximate scores, fp32 accumulate; gflag == nullptr -> plain GEMM.
