@@ -325,6 +325,155 @@ __global__ __launch_bounds__(512) void gemm_pp2(const _Float16* __restrict__ Q, 
                 }
 }
 
+template <int MF>
+__global__ __launch_bounds__(512) void gemm_pp3(const _Float16* __restrict__ Q, int64_t M, const _Float16* __restrict__ G, int64_t N, int D,
+                                                float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    constexpr int GN = 8;
+    const int per_group = GN * tiles_m, gid = wg / per_group, first_n = gid * GN;
+    const int gsz = min(GN, tiles_n - first_n), within = wg - gid * per_group;
+    const int64_t m0 = (int64_t)(within / gsz) * BM, n0 = (int64_t)(first_n + within % gsz) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][bb][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const _Float16* gsrc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = ht_slot(j);
+        const bool isb = slot >= 2;
+        const int half_ = slot & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wave * 16 + i * 8 + (lane >> 3);
+            int64_t gr = (isb ? n0 : m0) + half_ * 128 + r;
+            const int64_t lim = isb ? N : M;
+            gr = gr < lim ? gr : lim - 1;
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            gsrc[j][i] = (isb ? G : Q) + gr * D + c * 8;
+        }
+    }
+    const int T = D / BK;
+    auto issue = [&](int j, int t) {
+        char* dst = lds + (t & 1) * BUF_B + ht_slot(j) * HT_B + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j][i] + t * BK),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+    const int x0 = (lane >> 4) ^ ((lane >> 1) & 7);
+    const int lrow = (lane & 15) * 128;
+    int a_ad[2], b_ad[2];
+    a_ad[0] = wm * 64 * 128 + lrow + (x0 << 4);
+    a_ad[1] = wm * 64 * 128 + lrow + ((x0 ^ 4) << 4);
+    b_ad[0] = 2 * HT_B + wn * 32 * 128 + lrow + (x0 << 4);
+    b_ad[1] = 2 * HT_B + wn * 32 * 128 + lrow + ((x0 ^ 4) << 4);
+    half8 af[4][2], bf[2][2][2];
+    auto read_a = [&](const char* buf, int ah) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) af[i][s] = *reinterpret_cast<const half8*>(buf + ah * HT_B + i * 2048 + a_ad[s]);
+    };
+    auto read_b = [&](const char* buf, int bh) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) bf[bh][j][s] = *reinterpret_cast<const half8*>(buf + bh * HT_B + j * 2048 + b_ad[s]);
+    };
+    // MFMA segment with the DMA issue of this wave riding in its own instruction stream (phase A: A1 of k-tile t + 1; phase B:
+    // A0, B0, B1 of k-tile t + 2)
+    auto mfmas2 = [&](int ah, int t) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah][bh][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i][s], bf[bh][j][s], acc[ah][bh][i][j], 0, 0, 0);
+                if (ah == 0) {
+                    if (s == 0 && bh == 0 && t + 1 < T) issue(3, t + 1);
+                } else if (t + 2 < T) {
+                    if (s == 0 && bh == 0) issue(0, t + 2);
+                    if (s == 0 && bh == 1) issue(1, t + 2);
+                    if (s == 1 && bh == 0) issue(2, t + 2);
+                }
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    issue(0, 0); issue(1, 0); issue(2, 0); issue(3, 0);
+    if (T > 1) { issue(0, 1); issue(1, 1); issue(2, 1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < T; ++t) {
+        const char* buf = lds + (t & 1) * BUF_B;
+        // ---- phase A
+        read_a(buf, 0);
+        read_b(buf, 0);
+        read_b(buf, 1);
+        // retire A1 of this k-tile (issued in MFMA segment A of the previous one); younger: A0 / B0 / B1 of k-tile t + 1
+        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LGKMCNT0();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas2(0, t);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase B
+        read_a(buf, 1);
+        // retire A0 / B0 / B1 of k-tile t + 1 (issued in MFMA segment B of the previous k-tile); younger: A1 of k-tile t + 1
+        if (t + 1 < T) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LGKMCNT0();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas2(1, t);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int64_t n = n0 + bh * 128 + wn * 32 + j * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t m = m0 + ah * 128 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                        if (m < M && n < N) C[m * ldc + n] = acc[ah][bh][i][j][r];
+                    }
+                }
+}
+
+static void launch_pp3(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C) {
+    const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
+    static bool once = false;
+    if (!once) { CK(hipFuncSetAttribute((const void*)gemm_pp3<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_B)); once = true; }
+    hipLaunchKernelGGL(gemm_pp3<0>, dim3(tm * tn), dim3(512), 2 * BUF_B, 0, Q, M, G, N, D, C, N, tm, tn);
+}
+
 static void launch_pp2(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C) {
     const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
     static bool once = false;
@@ -395,6 +544,9 @@ int main(int argc, char** argv) {
         t = time_ms([&] { launch_pp2(dq, M, dg, N, D, c1); });
         CK(hipGetLastError());
         printf("ping-pong 2 phases         : %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
+        t = time_ms([&] { launch_pp3(dq, M, dg, N, D, c1); });
+        CK(hipGetLastError());
+        printf("ping-pong, DMA in MFMA segs: %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
         fflush(stdout);
     }
     CK(hipMemcpy(h0.data(), c0, h0.size() * 4, hipMemcpyDeviceToHost));
@@ -407,5 +559,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(c1, 0xFF, (size_t)M * N * 4));
     launch_pp2(dq, M, dg, N, D, c1); CK(hipDeviceSynchronize());
     compare("ping-pong 2 phases");
+    CK(hipMemset(c1, 0xFF, (size_t)M * N * 4));
+    launch_pp3(dq, M, dg, N, D, c1); CK(hipDeviceSynchronize());
+    compare("ping-pong, DMA in MFMA segs");
     return 0;
 }

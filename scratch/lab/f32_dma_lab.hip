@@ -26,7 +26,7 @@ template <int TM, int TN> struct Cfg {
 };
 
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void gemm32_dma(const float* __restrict__ Q, int64_t M, const float* __restrict__ G, int64_t N, int D,
+__global__ __launch_bounds__(256, TM * TN == 4 ? 4 : 5) void gemm32_dma(const float* __restrict__ Q, int64_t M, const float* __restrict__ G, int64_t N, int D,
                                                   float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n) {
     using K = Cfg<TM, TN>;
     __shared__ __attribute__((aligned(1024))) char lds[2 * K::STAGE_B];
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void gemm32_dma(const float* __restrict__ Q, i
         b_ad[p] = lds + (K::BM + wn * 32 * TN + l31) * ROW_B + (((2 * p + half) ^ sw) << 4);
     }
     auto swap2 = [&](f32x4& v) {
-        asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
         // now: x = step 4p, z = step 4p + 1, y = step 4p + 2, w = step 4p + 3   (steps of two k each; chunk pair = 8 k)
     };
     auto body = [&](auto SC, int t) {
