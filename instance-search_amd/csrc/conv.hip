@@ -114,25 +114,7 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel
     }
 
     const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ncol = (int)(n0 + wn_u * (32 * TN) + j * 32) + l31;
-            const bool n_ok = ncol < N;
-            const float bias_v = n_ok ? bias[ncol] : 0.0f;
-            const int lane_off = 4 * half * (int)ldc + ncol;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t mu = m0 + wm_u * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2);     // uniform
-                if (n_ok && mu + 4 * half < M) {
-                    float y = acc[i][j][e] + bias_v;
-                    if (res) y += (res + mu * ldc)[lane_off];
-                    (C + mu * ldc)[lane_off] = relu ? fmaxf(y, 0.0f) : y;
-                }
-            }
-        }
-    }
+    conv_epilogue_buffers<TM, TN>(acc, C, res, bias, relu, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31, half);
 }
 
 template <int TM, int TN, int BK>
@@ -240,24 +222,7 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_k
     }
 
     const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int ncol = (int)(n0 + wn_u * (32 * TN) + j * 32) + l31;
-            const bool n_ok = ncol < N;
-            const float bias_v = n_ok ? bias[ncol] : 0.0f;
-            const int lane_off = 4 * half * (int)ldc + ncol;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t mu = m0 + wm_u * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2);     // uniform
-                if (n_ok && mu + 4 * half < M) {
-                    const float y = acc[i][j][e] + bias_v;
-                    (C + mu * ldc)[lane_off] = relu ? fmaxf(y, 0.0f) : y;
-                }
-            }
-        }
-    }
+    conv_epilogue_buffers<TM, TN>(acc, C, nullptr, bias, relu, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31, half);
 }
 
 template <int TM, int TN, int BK>

@@ -66,13 +66,15 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
     const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
     if (PRE_RES) {
         const float* res = reinterpret_cast<const float*>(gflag);
-        const int ncol = (int)(n0 + wn_u * 32) + l31;
-        const int lane_off = 4 * half * (int)ldc + ncol;
+        if (res) {
+            const auto rr = conv_tile_rsrc(res, m0, M, ldc, BM);
+            const unsigned lo = conv_lane_off(n0 + wn_u * 32 + l31, N, wm_u * 32 + 4 * half, ldc);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t mu = m0 + wm_u * 32 + (e & 3) + 8 * (e >> 2);        // uniform
-            const float* rp = res + mu * ldc;
-            pre_res[e] = (res && ncol < N && mu + 4 * half < M) ? rp[lane_off] : 0.0f;
+            for (int e = 0; e < 16; ++e)
+                pre_res[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0));
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) pre_res[e] = 0.0f;
         }
     }
 
@@ -104,24 +106,33 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (EPI == 2) {
+        // Convolution epilogue through BUFFER instructions: a wave-uniform descriptor of the tile's rows (clipped at row M by the
+        // hardware), one 32-bit lane offset per 32x32 MFMA tile (a column >= N gets an offset outside the descriptor: its loads return
+        // 0, its stores are dropped) and the row offset (e & 3) + 8 (e >> 2) as an SGPR: ~4 instructions per output element and no
+        // branch, where per-element 64-bit addresses and edge tests cost ~20 (a fifth of a K = 256 tile's time).
         const float* res = reinterpret_cast<const float*>(gflag);
+        const auto rc = conv_tile_rsrc(C, m0, M, ldc, BM);
+        const auto rr = conv_tile_rsrc(res ? res : C, m0, M, ldc, BM);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int ncol = (int)(n0 + wn_u * (32 * TN) + j * 32) + l31;
-                const bool n_ok = ncol < N;
-                const float bias_v = n_ok ? thr[ncol] : 0.0f;
-                const int lane_off = 4 * half * (int)ldc + ncol;
+                const float bias_v = ncol < N ? thr[ncol] : 0.0f;
+                const unsigned lo = conv_lane_off(ncol, N, wm_u * (32 * TM) + i * 32 + 4 * half, ldc);
+                float rv[16];
+                if (!PRE_RES && res) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0));
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const int64_t mu = m0 + wm_u * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2);     // uniform
-                    if (n_ok && mu + 4 * half < M) {
-                        float y = acc[i][j][e] + bias_v;
-                        if (PRE_RES) { if (res) y += pre_res[e]; }
-                        else if (res) y += (res + mu * ldc)[lane_off];
-                        (C + mu * ldc)[lane_off] = ngrp ? fmaxf(y, 0.0f) : y;
-                    }
+                    float y = acc[i][j][e] + bias_v;
+                    if (PRE_RES) { if (res) y += pre_res[e]; }
+                    else if (res) y += rv[e];
+                    if (ngrp) y = fmaxf(y, 0.0f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rc, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0);
                 }
             }
         }
@@ -213,10 +224,10 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
         const double t = rounds * k.wg_per_cu * (k.tm * k.tn) / k.eff;
         if (t < best_t) { best_t = t; best = c; }
     }
-    // convolution epilogue with a residual read, or a very short K loop: the launch is bound by the bytes of
-    // the epilogue, which 64x64 tiles (6 resident workgroups per CU) overlap best (measured on the ResNet-50
-    // shapes: 64->256 +res 3.2 vs 4.7 ms, 128->512 1.75 vs 2.7, 256->1024 1.15 vs 1.65, 512->2048 0.97 vs 1.19)
-    if (epi == 2) best = (gmax != nullptr) ? 3 : 2;      // without a residual 128x64 tiles (5 waves/SIMD) win or tie on every trunk shape
+    // (Round 1 forced 64x64 tiles on residual layers and 128x64 on the others: the per-element epilogue was a visible share of a tile.
+    // With the buffer-instruction epilogue the same round / tail model as for the score GEMM picks the convolution tiles: 128x128
+    // wherever the grid fills the chip -- 256->1024 + residual 0.90 -> 0.87 ms, 512->2048 + residual 0.85 -> 0.81, 512->256 1.64 -> 1.58 --
+    // and 128x64 for Cout = 64.)
     if (g_force_cfg >= 0 && g_force_cfg < 4) best = g_force_cfg;
     switch (best) {
         case 0: launch_cfg<2, 2, 16>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;

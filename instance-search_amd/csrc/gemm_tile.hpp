@@ -82,6 +82,54 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
     }
 }
 
+// Buffer descriptor of the rows [m0, min(m0 + BM, M)) of a row-major (M, ldc) fp32 matrix: wave-uniform by construction (kernel
+// arguments and the tile index), so hipcc keeps it in SGPRs (no waterfall loop around the buffer instructions).
+__device__ __forceinline__ auto conv_tile_rsrc(const float* base, int64_t m0, int64_t M, int64_t ldc, int BM) {
+    const int64_t rows = (M - m0) < BM ? (M - m0) : BM;
+    const float* b0 = base + m0 * ldc;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)b0);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)b0 >> 32));
+    const unsigned nbytes = __builtin_amdgcn_readfirstlane((unsigned)(rows * ldc * 4));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, (int)nbytes, 0x00020000);
+}
+// byte offset of (tile row `row`, column ncol) inside that descriptor; a column past N is sent outside it
+__device__ __forceinline__ unsigned conv_lane_off(int64_t ncol, int64_t N, int row, int64_t ldc) {
+    return ncol < N ? (unsigned)((row * ldc + ncol) * 4) : 0x80000000u;
+}
+
+
+// Convolution epilogue of one wave's TM x TN accumulator tiles through BUFFER instructions: y = act(acc + bias[n] (+ residual)).
+// rc / rr: descriptors of the block tile's rows of C / the residual; row0 = the wave's first tile row (wave-uniform).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_buffers(const f32x16 (&acc)[TM][TN], float* __restrict__ C, const float* __restrict__ res,
+                                                      const float* __restrict__ bias, int relu, int64_t m0, int64_t M, int64_t n0, int64_t N,
+                                                      int64_t ldc, int BM, int row0, int col0, int l31, int half) {
+    const auto rc = conv_tile_rsrc(C, m0, M, ldc, BM);
+    const auto rr = conv_tile_rsrc(res ? res : C, m0, M, ldc, BM);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ncol = (int)n0 + col0 + j * 32 + l31;
+            const float bias_v = ncol < N ? bias[ncol] : 0.0f;
+            const unsigned lo = conv_lane_off(ncol, N, row0 + i * 32 + 4 * half, ldc);
+            float rv[16];
+            if (res) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float y = acc[i][j][e] + bias_v;
+                if (res) y += rv[e];
+                if (relu) y = fmaxf(y, 0.0f);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rc, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0);
+            }
+        }
+    }
+}
+
 // MFMAs of one staged k-tile.  Small tiles (TM * TN <= 2) have too few MFMAs per k-step to hide an LDS round trip
 // behind: the operand reads of HALF a k-tile are issued back to back, then the MFMAs (counted lgkmcnt(n) waits instead
 // of a drain per step; +4 % on the trunk's 1x1 convolutions).  a_base / b_base: this lane's first operand element.
