@@ -246,7 +246,7 @@ using namespace isx;
 // (the backbone layers of model/ModelDefinition.py's torchvision ResNets inside `features`, model/siamese.py:20,107,151).
 ISX_API int isx_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float* w, int Cout, const float* bias, const float* residual,
                              int relu, float* y, isx_stream_t stream) {
-    ISX_REQUIRE(M >= 0 && Cin > 0 && Cout > 0, "isx_conv1x1_nhwc: bad shape M=%lld Cin=%d Cout=%d", (long long)M, Cin, Cout);
+    ISX_REQUIRE(M >= 0 && Cin > 0 && Cout > 0 && Cout <= (1 << 20), "isx_conv1x1_nhwc: bad shape M=%lld Cin=%d Cout=%d (Cout <= 2^20: 32-bit offsets inside a tile's rows)", (long long)M, Cin, Cout);
     if (M == 0) return ISX_OK;
     ISX_REQUIRE(x && w && bias && y, "isx_conv1x1_nhwc: null pointer");
     ISX_REQUIRE(y != x && y != residual, "isx_conv1x1_nhwc: y must not alias x or residual");
@@ -262,6 +262,7 @@ ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, c
     ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (stride == 1 || stride == 2),
                 "isx_conv3x3_nhwc: bad shape B=%lld H=%d W=%d Cin=%d Cout=%d stride=%d", (long long)B, H, W, Cin, Cout, stride);
     ISX_REQUIRE(Cin % 32 == 0, "isx_conv3x3_nhwc: Cin=%d must be a multiple of 32", Cin);
+    ISX_REQUIRE(Cout <= (1 << 20), "isx_conv3x3_nhwc: Cout=%d above 2^20 (32-bit offsets inside a tile's rows)", Cout);
     ISX_REQUIRE(H < 32767 && W < 32767 && B * H * W < (1ll << 31), "isx_conv3x3_nhwc: input has too many pixels for 32-bit pixel indices");
     if (B == 0) return ISX_OK;
     ISX_REQUIRE(x && w_ohwi && bias && y, "isx_conv3x3_nhwc: null pointer");
@@ -293,6 +294,7 @@ ISX_API int isx_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_
     ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && K1 > 0 && K2 > 0 && Cout > 0 && (stride == 1 || stride == 2),
                 "isx_conv1x1_dual_nhwc: bad shape B=%lld H=%d W=%d K1=%d K2=%d Cout=%d stride=%d", (long long)B, H, W, K1, K2, Cout, stride);
     ISX_REQUIRE(K1 % 32 == 0 && K2 % 32 == 0, "isx_conv1x1_dual_nhwc: K1=%d and K2=%d must be multiples of 32", K1, K2);
+    ISX_REQUIRE(Cout <= (1 << 20), "isx_conv1x1_dual_nhwc: Cout=%d above 2^20 (32-bit offsets inside a tile's rows)", Cout);
     ISX_REQUIRE(B * H * W < (1ll << 31), "isx_conv1x1_dual_nhwc: input has too many pixels for 32-bit pixel indices");
     if (B == 0) return ISX_OK;
     ISX_REQUIRE(t && x && w_cat && bias && y, "isx_conv1x1_dual_nhwc: null pointer");
