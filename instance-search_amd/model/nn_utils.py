@@ -74,9 +74,11 @@ def extract_layers(net):
 
 
 # A/B switches (environment).  ISX_CONV1X1=0 sends the 1x1 trunk convolutions back to MIOpen.  ISX_CONV3X3: "auto"
-# (default) runs the implicit-GEMM kernel where it wins on MI355X -- Cin <= 128, the wide-image layers whose separate
-# epilogue pass costs as much as a fifth of the convolution (measured at B = 1024: 64->64 @56 2.08 vs 2.55 ms,
-# 128->128 @56/2 2.01 vs 2.23; from Cin = 256 on MIOpen's igemm + epilogue is 3-5 % faster) -- "1" everywhere, "0" never, an integer N > 1: Cin <= N.
+# (default) runs the implicit-GEMM kernel where it wins on MI355X -- every 3x3 convolution of a BN-folded residual block (round 2,
+# with the buffer-instruction epilogue: 1.93-1.98 ms against MIOpen's igemm + zero fill + separate epilogue pass 2.05-2.15 ms at
+# Cin >= 256, B = 1024; ResNet-50 extraction +2-3 % at B = 256 and at 448x448) and stand-alone convolutions with Cin <= 128; the
+# 13x13 AlexNet layers (192->384, 384->256, 256->256) stay with MIOpen (-5 % otherwise) -- "1" everywhere, "0" never, an integer
+# N > 1: Cin <= N.
 _CONV3X3_MODE = os.environ.get("ISX_CONV3X3", "auto")
 _IMPLICIT_GEMM_3X3 = _CONV3X3_MODE != "0"
 _GEMM_1X1 = os.environ.get("ISX_CONV1X1", "1") != "0"
@@ -97,6 +99,7 @@ class _ConvBiasAct(nn.Module):
         self.relu = relu
         self.plain = False            # True: no epilogue of its own (projection shortcut, bias merged elsewhere)
         self._w_ohwi = None           # (Cout,3,3,Cin) copy of a 3x3 weight for the implicit-GEMM kernel, built on first use
+        self.in_block = False         # True: a convolution of a BN-folded residual block (_FusedBlock)
 
     def _pointwise(self):
         c = self.conv
@@ -106,7 +109,8 @@ class _ConvBiasAct(nn.Module):
         c = self.conv
         return (_IMPLICIT_GEMM_3X3 and c.kernel_size == (3, 3) and c.padding == (1, 1) and c.groups == 1 and c.dilation == (1, 1)
                 and c.stride in ((1, 1), (2, 2)) and c.in_channels % 32 == 0
-                and (_CONV3X3_MODE == "1" or c.in_channels <= (int(_CONV3X3_MODE) if _CONV3X3_MODE.isdigit() and int(_CONV3X3_MODE) > 1 else 128)))
+                and (_CONV3X3_MODE == "1" or (_CONV3X3_MODE == "auto" and self.in_block)
+                     or c.in_channels <= (int(_CONV3X3_MODE) if _CONV3X3_MODE.isdigit() and int(_CONV3X3_MODE) > 1 else 128)))
 
     def forward(self, x, residual=None):
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self._three_by_three()
@@ -177,6 +181,8 @@ class _FusedBlock(nn.Module):
     def __init__(self, convs, downsample):
         super().__init__()
         self.convs = nn.ModuleList([_ConvBiasAct(c, relu=True) for c in convs])
+        for c in self.convs:
+            c.in_block = True
         self.downsample = None
         if downsample is not None:
             d = _ConvBiasAct(downsample, relu=False)
