@@ -3,7 +3,7 @@
 
 Workload (BASELINE configs[1], "ResNet-50 fully-conv global descriptors, 10k-image synthetic
 gallery"): one STEP = one batch of synthetic 224x224 images through the whole path
-    images --ResNet-50 trunk (fp32; 1x1 / wide 3x3 convolutions + every epilogue: libisx, rest: MIOpen)-->
+    images --ResNet-50 trunk (fp32; every 1x1 / 3x3 convolution of the residual blocks + every epilogue: libisx, 7x7 stem: MIOpen)-->
            (B,2048,7,7) feature map --isx_gap_l2 (HIP)--> L2-normalised 2048-d descriptors
            --[N>1: RCCL all-gather of the query descriptors]--
            --isx_cosine_sim (fp32 MFMA) + isx_topk_rows (HIP) against this rank's gallery shard-->
