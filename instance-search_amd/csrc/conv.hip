@@ -66,25 +66,32 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel
     const int c4 = (threadIdx.x % CH) << 2;
     int kh = 0, kw = 0, ci0 = 0;                  // tap / channel offset of the NEXT k-tile to load (uniform)
     float4 ra[NA], rb[BN * BK / 1024];
-    const float* ap[NA];                          // source of the next k-tile inside the current tap
-    bool aok[NA];                                 // current tap inside the image for this row?
+    // A rows come through BUFFER loads: a wave-uniform descriptor that starts at the first input pixel this tile can touch, one 32-bit
+    // byte offset per staged row (recomputed once per filter tap), the channel offset inside the tap as the SGPR offset.  A padding
+    // tap gets an offset outside the descriptor and loads zeros: no per-k-tile address arithmetic, no select on the loaded values.
+    int64_t mf = m0 < M ? m0 : M - 1;
+    const int hw_ = g.Ho * g.Wo;
+    const int bf = (int)(mf / hw_), remf = (int)(mf - (int64_t)bf * hw_);
+    const int hof = remf / g.Wo, wof = remf - hof * g.Wo;
+    int64_t base_pix = ((int64_t)bf * g.H + (hof * g.stride - 1)) * g.W + (wof * g.stride - 1);      // top-left tap of the tile's first row
+    base_pix = base_pix > 0 ? base_pix : 0;
+    const int64_t left = ((int64_t)(M / hw_) * g.H * g.W - base_pix) * g.Cin * 4;                     // bytes up to the end of the input
+    const auto xr = uniform_rsrc(x + base_pix * g.Cin, left);
+    unsigned voff[NA];                            // byte offset of the current tap's pixel of each staged row (0xFFFFFFFF: padding)
     auto load_a = [&]() {
         if (ci0 == 0) {                           // new tap (uniform branch, once per Cin / BK k-tiles)
 #pragma unroll
             for (int j = 0; j < NA; ++j) {
                 const int hi = (hw0[j] >> 16) - 1 + kh, wi = (hw0[j] & 0xFFFF) - 1 + kw;
-                aok[j] = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-                // padding taps read the window's centre pixel (always inside the image) and discard it: the load
-                // itself stays unconditional (no exec-masked branch in the k loop)
-                const int pix = aok[j] ? pbase[j] + kh * g.W + kw : pbase[j] + g.W + 1;
-                ap[j] = x + (int64_t)pix * g.Cin + c4;
+                const bool ok = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+                voff[j] = ok ? (unsigned)(((int64_t)pbase[j] + kh * g.W + kw - base_pix) * g.Cin + c4) * 4u : 0xFFFFFFFFu;
             }
         }
+        const unsigned soff = (unsigned)ci0 * 4u;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const float4 v = *reinterpret_cast<const float4*>(ap[j]);
-            ra[j] = make_float4(aok[j] ? v.x : 0.f, aok[j] ? v.y : 0.f, aok[j] ? v.z : 0.f, aok[j] ? v.w : 0.f);
-            ap[j] += BK;
+            // (bit_cast of the whole vector: indexing the builtin's result through `auto` gave element 0 four times with hipcc 7.2)
+            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[j], soff, 0));
         }
         ci0 += BK;
         if (ci0 == g.Cin) { ci0 = 0; if (++kw == 3) { kw = 0; ++kh; } }

@@ -84,13 +84,18 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 
 // Buffer descriptor of the rows [m0, min(m0 + BM, M)) of a row-major (M, ldc) fp32 matrix: wave-uniform by construction (kernel
 // arguments and the tile index), so hipcc keeps it in SGPRs (no waterfall loop around the buffer instructions).
+// Raw buffer descriptor over [base, base + nbytes) from WAVE-UNIFORM inputs (readfirstlane makes that provable to hipcc: no waterfall
+// loops around the buffer instructions).  The two address halves go through unsigned temporaries: readfirstlane returns int, and
+// a sign-extended low half would corrupt the high half of the pointer.
+__device__ __forceinline__ auto uniform_rsrc(const void* base, int64_t nbytes) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)base);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)base >> 32));
+    const unsigned nb = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nbytes < 0xFFFFFFFFll ? (nbytes > 0 ? nbytes : 0) : 0xFFFFFFFFll));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | (uintptr_t)lo), 0, (int)nb, 0x00020000);
+}
 __device__ __forceinline__ auto conv_tile_rsrc(const float* base, int64_t m0, int64_t M, int64_t ldc, int BM) {
     const int64_t rows = (M - m0) < BM ? (M - m0) : BM;
-    const float* b0 = base + m0 * ldc;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)b0);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)b0 >> 32));
-    const unsigned nbytes = __builtin_amdgcn_readfirstlane((unsigned)(rows * ldc * 4));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, (int)nbytes, 0x00020000);
+    return uniform_rsrc(base + m0 * ldc, rows * ldc * 4);
 }
 // byte offset of (tile row `row`, column ncol) inside that descriptor; a column past N is sent outside it
 __device__ __forceinline__ unsigned conv_lane_off(int64_t ncol, int64_t N, int row, int64_t ldc) {
