@@ -36,12 +36,36 @@ __device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int
     tile_n = first_n + within % gsz;
 }
 
+// Raw buffer descriptor over [base, base + nbytes) from WAVE-UNIFORM inputs (readfirstlane makes that provable to hipcc: no waterfall
+// loops around the buffer instructions).  The two address halves go through unsigned temporaries: readfirstlane returns int, and
+// a sign-extended low half would corrupt the high half of the pointer.
+__device__ __forceinline__ auto uniform_rsrc(const void* base, int64_t nbytes) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)base);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)base >> 32));
+    const unsigned nb = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nbytes < 0xFFFFFFFFll ? (nbytes > 0 ? nbytes : 0) : 0xFFFFFFFFll));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | (uintptr_t)lo), 0, (int)nb, 0x00020000);
+}
+
 // ROWS x BK k = ROWS*CH float4; thread t takes idx = j*256 + t: row = idx/CH, chunk = idx%CH.
 // ALIGNED: 16-B aligned rows AND D a multiple of BK (unconditional 16-B loads); otherwise scalar loads with a zero-filled k tail.
 template <bool ALIGNED, int ROWS, int BK>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t rows, int D, int64_t row0, int k0,
                                           float4 (&reg)[ROWS * BK / 1024]) {
     constexpr int CH = BK / 4;               // 16-B chunks per staged row
+    if (ALIGNED) {
+        // ALIGNED: D % BK == 0, 16-B aligned rows.  Buffer loads: a wave-uniform descriptor of the tile's rows (loop invariant), one
+        // constant 32-bit offset per staged chunk, the k offset as SGPR: no address arithmetic inside the k loop.  Rows past the edge
+        // fall outside the descriptor and load zeros (they are never stored).
+        const int64_t left = rows - row0;
+        const auto rs = uniform_rsrc(P + row0 * D, (left < ROWS ? left : ROWS) * (int64_t)D * 4);
+#pragma unroll
+        for (int j = 0; j < ROWS * CH / 256; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            const unsigned vo = (unsigned)(idx / CH) * (unsigned)D * 4u + (unsigned)((idx % CH) << 4);
+            reg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)k0 * 4u, 0));
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < ROWS * CH / 256; ++j) {
         const int idx = j * 256 + threadIdx.x;
@@ -49,14 +73,10 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t r
         r = r < rows ? r : rows - 1;                       // clamp: rows past the edge are never stored
         const int k = k0 + ((idx % CH) << 2);
         const float* src = P + r * D + k;
-        if (ALIGNED) {
-            reg[j] = *reinterpret_cast<const float4*>(src);     // ALIGNED: D % BK == 0, no k tail, no exec-masked branch around the load
-        } else {
-            reg[j].x = (k + 0 < D) ? src[0] : 0.f;
-            reg[j].y = (k + 1 < D) ? src[1] : 0.f;
-            reg[j].z = (k + 2 < D) ? src[2] : 0.f;
-            reg[j].w = (k + 3 < D) ? src[3] : 0.f;
-        }
+        reg[j].x = (k + 0 < D) ? src[0] : 0.f;
+        reg[j].y = (k + 1 < D) ? src[1] : 0.f;
+        reg[j].z = (k + 2 < D) ? src[2] : 0.f;
+        reg[j].w = (k + 3 < D) ? src[3] : 0.f;
     }
 }
 
@@ -84,15 +104,6 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 
 // Buffer descriptor of the rows [m0, min(m0 + BM, M)) of a row-major (M, ldc) fp32 matrix: wave-uniform by construction (kernel
 // arguments and the tile index), so hipcc keeps it in SGPRs (no waterfall loop around the buffer instructions).
-// Raw buffer descriptor over [base, base + nbytes) from WAVE-UNIFORM inputs (readfirstlane makes that provable to hipcc: no waterfall
-// loops around the buffer instructions).  The two address halves go through unsigned temporaries: readfirstlane returns int, and
-// a sign-extended low half would corrupt the high half of the pointer.
-__device__ __forceinline__ auto uniform_rsrc(const void* base, int64_t nbytes) {
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)base);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)base >> 32));
-    const unsigned nb = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nbytes < 0xFFFFFFFFll ? (nbytes > 0 ? nbytes : 0) : 0xFFFFFFFFll));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | (uintptr_t)lo), 0, (int)nb, 0x00020000);
-}
 __device__ __forceinline__ auto conv_tile_rsrc(const float* base, int64_t m0, int64_t M, int64_t ldc, int BM) {
     const int64_t rows = (M - m0) < BM ? (M - m0) : BM;
     return uniform_rsrc(base + m0 * ldc, rows * ldc * 4);
