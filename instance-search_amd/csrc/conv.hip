@@ -174,33 +174,36 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_k
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int c4 = (threadIdx.x % CH) << 2;
-    const float* ap[NA];                          // source of the next k-tile of each staged row
+    // A rows through buffer loads (as load_tile / conv3x3): descriptor 1 = the tile's rows of t, descriptor 2 = the block input from the
+    // first pixel the tile samples; one 32-bit offset per staged row and source, the channel offset inside the source as SGPR offset
+    const int64_t mleft = M - m0;
+    const auto r1 = uniform_rsrc(t + m0 * g.K1, (mleft < BM ? mleft : BM) * (int64_t)g.K1 * 4);
+    const int hw_ = g.Ho * g.Wo;
+    auto pixel_of = [&](int64_t m) {
+        const int b = (int)(m / hw_), rem = (int)(m - (int64_t)b * hw_);
+        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+        return (int64_t)(b * g.H + ho * g.stride) * g.W + wo * g.stride;
+    };
+    const int64_t base_pix = pixel_of(m0 < M ? m0 : M - 1);
+    const auto r2 = uniform_rsrc(x + base_pix * g.K2, ((int64_t)(M / hw_) * g.H * g.W - base_pix) * g.K2 * 4);
+    unsigned vo1[NA], vo2[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        int64_t m = m0 + (j * 256 + threadIdx.x) / CH;
-        m = m < M ? m : M - 1;
-        ap[j] = t + m * g.K1 + c4;
+        const int row = (j * 256 + threadIdx.x) / CH;
+        int64_t m = m0 + row;
+        m = m < M ? m : M - 1;                    // rows past the edge repeat the last one (never stored)
+        vo1[j] = (unsigned)((m - m0) * g.K1 + c4) * 4u;
+        vo2[j] = (unsigned)((pixel_of(m) - base_pix) * g.K2 + c4) * 4u;
     }
-    int kdone = 0;                                // channels of the current source already issued (uniform)
-    bool second = false;
+    int kdone = 0;                                // channels already issued (uniform)
     float4 ra[NA], rb[BN * BK / 1024];
     auto load_a = [&]() {
-        if (!second && kdone == g.K1) {           // switch to the block input, sampled with the projection's stride
-            second = true;
+        if (kdone < g.K1) {                       // uniform
 #pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                int64_t m = m0 + (j * 256 + threadIdx.x) / CH;
-                m = m < M ? m : M - 1;
-                const int hw = g.Ho * g.Wo;
-                const int b = (int)(m / hw), rem = (int)(m - (int64_t)b * hw);
-                const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-                ap[j] = x + ((int64_t)(b * g.H + ho * g.stride) * g.W + wo * g.stride) * g.K2 + c4;
-            }
-        }
+            for (int j = 0; j < NA; ++j) ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r1, vo1[j], (unsigned)kdone * 4u, 0));
+        } else {                                  // the block input, sampled with the projection's stride
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            ra[j] = *reinterpret_cast<const float4*>(ap[j]);
-            ap[j] += BK;
+            for (int j = 0; j < NA; ++j) ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r2, vo2[j], (unsigned)(kdone - g.K1) * 4u, 0));
         }
         kdone += BK;
     };
