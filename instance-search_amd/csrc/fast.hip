@@ -409,6 +409,14 @@ __global__ __launch_bounds__(512) void cosine_gemm_f16_big_kernel(const _Float16
 //    re-staged only after a barrier that follows the lgkmcnt(0) of both wave groups' reads of it (WAR).
 // Measured (10 240 x 16 384, plain store): 1 204 TFLOP/s at D = 2048 and 1 370 at D = 4096 against 861 / 1 020 for 2b; the k loop
 // itself runs at ~1.3 us per k-tile (1 650 TFLOP/s), the rest is the output burst of the plain-store epilogue.
+// raw buffer descriptor from wave-uniform inputs (see gemm_tile.hpp uniform_rsrc; repeated here: fast.hip does not include it)
+__device__ __forceinline__ auto uniform_rsrc16(const void* base, int64_t nbytes) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)base);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((uintptr_t)base >> 32));
+    const unsigned nb = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nbytes < 0xFFFFFFFFll ? (nbytes > 0 ? nbytes : 0) : 0xFFFFFFFFll));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | (uintptr_t)lo), 0, (int)nb, 0x00020000);
+}
+
 constexpr int PP_HT_B = 128 * HBK * 2;                   // one half-tile: 16 KB
 constexpr int PP_BUF_B = 4 * PP_HT_B;                    // [A0][A1][B0][B1] = 64 KB per k-tile
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -443,27 +451,31 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __rest
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][bb][i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // DMA sources: half-tile j, instruction i fills image rows wave*16 + i*8 + lane/8; slot lane%8 of a row holds chunk slot ^ hswz(row)
-    const _Float16* gsrc[4][2];
+    // DMA sources: half-tile j, instruction i fills image rows wave*16 + i*8 + lane/8; slot lane%8 of a row holds chunk slot ^ hswz(row).
+    // buffer_load ... lds: a wave-uniform descriptor of the tile's 256 rows per operand, one constant 32-bit lane offset per
+    // (half-tile, instruction), the k-tile offset as SGPR -- no vector address arithmetic in the load segments, where every
+    // instruction beside the partner's MFMA stream is expensive.  Rows past the edge fall outside the descriptor (zeros, never stored).
+    const auto rq = uniform_rsrc16(Q + m0 * D, ((M - m0) < GBM ? (M - m0) : GBM) * (int64_t)D * 2);
+    const auto rg = uniform_rsrc16(G + n0 * D, ((N - n0) < GBN ? (N - n0) : GBN) * (int64_t)D * 2);
+    unsigned gvo[4][2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const bool isb = pp_slot(j) >= 2;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = wave * 16 + i * 8 + (lane >> 3);
-            int64_t gr = (isb ? n0 : m0) + (pp_slot(j) & 1) * 128 + r;
-            const int64_t lim = isb ? N : M;
-            gr = gr < lim ? gr : lim - 1;                       // clamp: rows past the edge are never stored
-            gsrc[j][i] = (isb ? G : Q) + gr * D + (((lane & 7) ^ hswz(r)) << 3);
+            gvo[j][i] = (unsigned)((pp_slot(j) & 1) * 128 + r) * (unsigned)D * 2u + (unsigned)(((lane & 7) ^ hswz(r)) << 4);
         }
     }
     const int T = D / HBK;                                      // D % 64 == 0 (launcher)
     auto issue = [&](int j, int t) {                            // half-tile j of k-tile t -> buffer t & 1
         char* dst = lds + (t & 1) * PP_BUF_B + pp_slot(j) * PP_HT_B + wave * 2048;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j][i] + t * HBK),
-                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+            if (pp_slot(j) >= 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, gvo[j][i], (unsigned)t * (HBK * 2), 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, gvo[j][i], (unsigned)t * (HBK * 2), 0, 0);
+        }
     };
     // operand fragments of the 16x16x32 MFMA: lane l holds row (l & 15), chunk 4 s + l / 16 of its 16-row block
     const int x0 = (lane >> 4) ^ ((lane >> 1) & 7);               // chunk ^ hswz(row) for s = 0 (block bases are multiples of 16 rows)
