@@ -364,6 +364,9 @@ def main():
             e = traffic.get("kernels", {}).get(key)
             if not default_cfg or not isinstance(e, dict) or (world > 1 and not per_gpu_only):
                 return None
+            t = trunk.get(key)
+            if t is not None and ksteps and e.get("launches") != t["n"] // ksteps:
+                return None                    # the profile was taken with a different kernel dispatch: stale, not reported
             return e.get("bytes")
 
         line = {
