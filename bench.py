@@ -3,7 +3,7 @@
 
 Workload (BASELINE configs[1], "ResNet-50 fully-conv global descriptors, 10k-image synthetic
 gallery"): one STEP = one batch of synthetic 224x224 images through the whole path
-    images --ResNet-50 trunk (fp32; every 1x1 / 3x3 convolution of the residual blocks + every epilogue: libisx, 7x7 stem: MIOpen)-->
+    images --ResNet-50 trunk (fp32; the fused 7x7 stem, every 1x1 / 3x3 convolution of the residual blocks and every epilogue: libisx; MIOpen runs nothing)-->
            (B,2048,7,7) feature map --isx_gap_l2 (HIP)--> L2-normalised 2048-d descriptors
            --[N>1: RCCL all-gather of the query descriptors]--
            --isx_cosine_sim (fp32 MFMA) + isx_topk_rows (HIP) against this rank's gallery shard-->
@@ -394,6 +394,7 @@ def main():
             "isx_conv1x1_nhwc": "cosine_gemm_kernel<ALIGNED, TM, TN, EPI = 2, BK> + conv1x1_stream_kernel for Cin = 64 (isx_conv1x1_nhwc: 1x1 convolutions as fp32-MFMA GEMMs over the pixels, bias/residual/ReLU fused)",
             "isx_conv1x1_dual_nhwc": "conv1x1_dual_nhwc_kernel (isx_conv1x1_dual_nhwc: last 1x1 conv + projection shortcut as one GEMM)",
             "isx_conv3x3_nhwc": "conv3x3_nhwc_kernel (isx_conv3x3_nhwc: implicit GEMM, bias/residual/ReLU fused)",
+            "isx_stem7x7_pool_nhwc": "stem7x7_pool_kernel (isx_stem7x7_pool_nhwc: conv 7x7/2 + bias + ReLU + maxpool 3/2/1 as one kernel)",
         }
         for name, t in sorted(trunk.items()):
             mf = t["flop"] / (t["ms"] * 1e-3) / 1e12

@@ -88,6 +88,15 @@ int isx_images_u8_to_f32(const uint8_t* img, int64_t B, int H, int W, float mean
  * y: (B,H,W,C), out: (B,Ho,Wo,C), Ho = (H-1)/2 + 1; C % 4 == 0. */
 int isx_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int H, int W, int C, float* out, isx_stream_t stream);
 
+/* The whole stem as ONE kernel: conv 7x7 / stride 2 / padding 3 (3 -> 64 channels, bn1 folded into w and bias) + ReLU +
+ * MaxPool2d(3, stride 2, padding 1) on a channels-last image batch; the convolution output never reaches memory.  Replaces
+ * conv1, bn1, relu, maxpool of the torchvision ResNet `features` trunk (model/ModelDefinition.py, split by model/nn_utils.py:56-71,
+ * run from model/siamese.py:20,107,151).  conv = fp32 fma chain over (kh, kw, c) ascending (bit-exact vs the oracle).
+ * x: (B,H,W,3) fp32, 16-B aligned, W % 4 == 0, W <= 224; w_ohwi: (64,7,7,3); bias: (64); out: (B,Hp,Wp,64) with
+ * Hc = (H-1)/2 + 1, Hp = (Hc-1)/2 + 1 (same for W). */
+int isx_stem7x7_pool_nhwc(const float* x, int64_t B, int H, int W, const float* w_ohwi, const float* bias, float* out,
+                          isx_stream_t stream);
+
 /* 1x1 stride-1 convolution of the inference trunk on channels-last activations, epilogue fused: one
  * fp32-MFMA GEMM over the M = B*H*W pixels,
  *   y[m][co] = act(sum_ci x[m][ci] * w[co][ci] + bias[co] + (residual ? residual[m][co] : 0)),

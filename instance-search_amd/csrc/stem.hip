@@ -1,0 +1,213 @@
+// stem.hip -- the ResNet stem as ONE kernel: conv 7x7 / stride 2 / padding 3 (3 -> 64 channels, BN folded into the weights) + bias + ReLU +
+// MaxPool2d(3, stride 2, padding 1) on channels-last activations, from the normalised image straight to the (B, H/4, W/4, 64) map.
+//
+// Why a kernel of its own: as separate passes the stem writes and re-reads its (B, 112, 112, 64) fp32 convolution output (3.3 GB at
+// B = 1024) and MIOpen's implicit GEMM zero-fills it first: 2.75 + 0.54 + 0.83 ms of the 70 ms bench step for 1.5 ms of matrix-core work.
+// Here the convolution output never leaves the registers:
+//   * one persistent 512-thread workgroup per image (or band of an image) walks DOWN the image in steps of 8 convolution rows x 112
+//     columns: 896 pixels x 64 channels = 56 accumulator tiles of v_mfma_f32_32x32x2_f32, 7 per wave (wave w: channels 32 (w & 1) ..,
+//     column blocks 7 (w >> 1) ..);
+//   * the 21 input rows a step touches arrive by LDS-DMA (global_load_lds_dwordx4, exec-masked at the row end) into one of two LDS
+//     buffers, a step ahead; rows keep a 4-pixel zero border, rows outside the image are zero-filled: padding needs no test;
+//   * K is ordered (kh, kw, c) with the 21 values of a filter row padded to 22 (zero weight): the A operand of k-step s of filter row
+//     kh is the LDS word at lane_base + kh * row + 2 s (+ 24 per column block): ONE base register, everything else immediate offsets;
+//     the weights sit in LDS as [k][64] for the whole kernel (one ds_read per 7 MFMAs);
+//   * an accumulator row block is 4 columns x 8 rows, ordered so that ONE lane holds, for its channel, the 8 rows of two adjacent
+//     columns = four complete 2x2 pooling cells: the 3x3/2 max needs only the row above (carried in registers from the previous
+//     step) and the column to the left (the other half-wave: ds_bpermute; across waves: 4 KB of LDS), then 28 dword stores per lane.
+// Arithmetic: acc = fp32 fma chain over (kh, kw, c) ascending from +0 (padding taps contribute fma(0, w, acc) = acc), y = max(acc + bias, 0),
+// out = max over the window: bit-identical to oracle/isx_oracle.c::isxo_stem7x7_pool_nhwc (tests/test_gpu_parity.py).
+// Reference: the torchvision ResNet stem (conv1, bn1, relu, maxpool) inside the `features` trunk built by model/ModelDefinition.py and
+// split by model/nn_utils.py:56-71; run from model/siamese.py:20,107,151.
+#include <stdlib.h>
+
+#include "gemm_tile.hpp"
+
+namespace isx {
+
+constexpr int ST_RSF = 696;                    // floats per staged input row: 12 (4-pixel zero border) + 3 * 224 + 12
+constexpr int ST_ROWS = 21;                    // input rows under 8 convolution rows: 2 * 7 + 7
+constexpr int ST_BUF_F = ST_ROWS * ST_RSF;     // 58 464 B per buffer
+constexpr int ST_K = 154;                      // 7 filter rows x (21 + 1 zero)
+constexpr int ST_W_F = ST_K * 64;              // 39 424 B
+constexpr int ST_X_F = 4 * 2 * 4 * 32;         // cross-wave column exchange: [column group][channel block][pooled row][channel]
+constexpr int ST_NSTORE = 28;                  // output stores per lane and step
+constexpr int ST_MAXW = 224;
+
+struct StemGeom { int H, W, Hc, Wc, Hp, Wp, steps, bands; };
+
+__global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restrict__ x, StemGeom g, const float* __restrict__ w_ohwi,
+                                                           const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(1024))) float lds[2 * ST_BUF_F + ST_W_F + ST_X_F];      // 160 448 B
+    float* const in_lds = lds;
+    float* const w_lds = lds + 2 * ST_BUF_F;
+    float* const x_lds = w_lds + ST_W_F;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nblk = wave & 1, cg = wave >> 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int img = blockIdx.x / g.bands, band = blockIdx.x - img * g.bands;
+    const int t_first = (int)((int64_t)band * g.steps / g.bands), t_end = (int)((int64_t)(band + 1) * g.steps / g.bands);
+    const int t_start = t_first > 0 ? t_first - 1 : 0;            // a band below the top runs one step early for its carry row (no stores)
+    const float* __restrict__ x_img = x + (int64_t)img * g.H * g.W * 3;
+    const int nchunk = g.W * 3 / 4;                                // 16-B chunks per input row
+
+    // ---- prologue: zero the input buffers (borders stay zero for the whole kernel), weights into LDS as [kh * 22 + kw * 3 + c][co]
+    for (int e = tid; e < 2 * ST_BUF_F / 4; e += 512) reinterpret_cast<float4*>(in_lds)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = tid; e < 64 * 147; e += 512) {
+        const int co = e / 147, r = e - co * 147, kh = r / 21, kwc = r - kh * 21;
+        w_lds[(kh * 22 + kwc) * 64 + co] = w_ohwi[e];
+    }
+    for (int e = tid; e < 7 * 64; e += 512) w_lds[((e >> 6) * 22 + 21) * 64 + (e & 63)] = 0.0f;
+    __syncthreads();
+
+    // input rows 16 t - 3 .. 16 t + 17 of step t into buffer `buf`: 63 (row, 64-chunk part) items, wave w takes items w, w + 8, ...
+    auto issue_dma = [&](int t, int buf) {
+        const int r0 = 16 * t - 3;
+#pragma unroll
+        for (int i8 = 0; i8 < 8; ++i8) {
+            const int item = i8 * 8 + wave;
+            if (item < 63) {
+                const int row = item / 3, part = item - row * 3;
+                const int ir = r0 + row;
+                const int chunk = part * 64 + lane;
+                float* dst_row = in_lds + buf * ST_BUF_F + row * ST_RSF + 12;
+                if ((unsigned)ir < (unsigned)g.H) {
+                    if (chunk < nchunk)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x_img + (int64_t)ir * g.W * 3 + chunk * 4),
+                                                         (__attribute__((address_space(3))) void*)(dst_row + part * 256), 16, 0, 0);
+                } else if (chunk < nchunk) {
+                    reinterpret_cast<float4*>(dst_row)[chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    };
+
+    // A operand: MFMA row m of a column block is convolution row 2 (m >> 3) + ((m >> 1) & 1), column 4 b + 2 ((m >> 2) & 1) + (m & 1)
+    const int am = l31;
+    const int a_row = 2 * (am >> 3) + ((am >> 1) & 1), a_col = 28 * cg + 2 * ((am >> 2) & 1) + (am & 1);
+    const int a_lane = a_row * 2 * ST_RSF + 6 * a_col + 3 + h;                  // + kh * ST_RSF + 2 s' + 24 b  (immediates)
+    const float* const bp = w_lds + h * 64 + 32 * nblk + l31;                   // + (22 kh + 2 s') * 64
+
+    const float bias_v = bias[32 * nblk + l31];
+    float carry[7][2];                                                          // convolution row 8 t - 1 of this lane's two columns (after ReLU)
+#pragma unroll
+    for (int b = 0; b < 7; ++b) carry[b][0] = carry[b][1] = 0.0f;
+
+    // output: descriptor of the image's pooled rows; lane offset of (column q = 14 cg + 2 b + h, channel); the pooled row is the SGPR offset
+    const int64_t out_img_bytes = (int64_t)g.Hp * g.Wp * 256;
+    const auto out_rs = uniform_rsrc(out + (int64_t)img * g.Hp * g.Wp * 64, out_img_bytes);
+    const auto null_rs = uniform_rsrc(out, 0);
+    unsigned o_off[7];
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+        const int q = 14 * cg + 2 * b + h;
+        o_off[b] = q < g.Wp ? (unsigned)((q * 64 + 32 * nblk + l31) * 4) : 0x80000000u;
+    }
+
+    issue_dma(t_start, 0);
+    int buf = 0;
+    for (int t = t_start; t < t_end; ++t, buf ^= 1) {
+        // this step's rows have landed (everything older than the previous step's stores), and every wave is done with the other buffer
+        if (t == t_start) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_NSTORE) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < t_end) issue_dma(t + 1, buf ^ 1);
+
+        f32x16 acc[7];
+#pragma unroll
+        for (int b = 0; b < 7; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.0f;
+        const float* const ap = in_lds + buf * ST_BUF_F + a_lane;
+        float av[2][7], bv[2];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) av[0][b] = ap[24 * b];
+        bv[0] = bp[0];
+#pragma unroll
+        for (int s = 0; s < 77; ++s) {
+            if (s + 1 < 77) {
+                const int kh = (s + 1) / 11, sp = (s + 1) % 11;
+#pragma unroll
+                for (int b = 0; b < 7; ++b) av[(s + 1) & 1][b] = ap[kh * ST_RSF + 2 * sp + 24 * b];
+                bv[(s + 1) & 1] = bp[(22 * kh + 2 * sp) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 7; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][b], bv[s & 1], acc[b], 0, 0, 0);
+        }
+
+        // ---- epilogue: bias + ReLU, 3x3 / stride 2 max.  acc[b][4 gg + 2 r + c] = convolution row 8 t + 2 gg + r, column 28 cg + 4 b + 2 h + c
+        float own[7][4], rgt[7][4];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            float v[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool ok = (8 * t + 2 * (e >> 2) + ((e >> 1) & 1) < g.Hc) && (28 * cg + 4 * b + 2 * h + (e & 1) < g.Wc);
+                v[e] = ok ? fmaxf(acc[b][e] + bias_v, 0.0f) : 0.0f;            // 0 = identity of the max (values are >= 0 after the ReLU)
+            }
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const float top0 = gg ? v[4 * gg - 2] : carry[b][0], top1 = gg ? v[4 * gg - 1] : carry[b][1];
+                rgt[b][gg] = fmaxf(fmaxf(top1, v[4 * gg + 1]), v[4 * gg + 3]);
+                own[b][gg] = fmaxf(fmaxf(fmaxf(top0, v[4 * gg]), v[4 * gg + 2]), rgt[b][gg]);
+            }
+            carry[b][0] = v[14];
+            carry[b][1] = v[15];
+        }
+        // the column to the left: the other half-wave's right column (same block for h = 1, the previous block for h = 0)
+        if (h) {
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) x_lds[((cg * 2 + nblk) * 4 + gg) * 32 + l31] = rgt[6][gg];
+        }
+        float swp[7][4];
+#pragma unroll
+        for (int b = 0; b < 7; ++b)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg)
+                swp[b][gg] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, rgt[b][gg])));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float left0[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) left0[gg] = cg ? x_lds[(((cg - 1) * 2 + nblk) * 4 + gg) * 32 + l31] : 0.0f;
+        const auto rs = t >= t_first ? out_rs : null_rs;
+#pragma unroll
+        for (int b = 0; b < 7; ++b)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const float left = h ? swp[b][gg] : (b ? swp[b > 0 ? b - 1 : 0][gg] : left0[gg]);
+                const float y = fmaxf(own[b][gg], left);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs, o_off[b], (unsigned)((4 * t + gg) * g.Wp * 256), 0);
+            }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace isx
+
+// conv 7x7 / stride 2 / padding 3 (3 -> 64) + bias + ReLU + MaxPool2d(3, 2, 1) on a channels-last image batch.
+ISX_API int isx_stem7x7_pool_nhwc(const float* x, int64_t B, int H, int W, const float* w_ohwi, const float* bias, float* out,
+                                  isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && H > 0 && W > 0, "isx_stem7x7_pool_nhwc: bad shape B=%lld H=%d W=%d", (long long)B, H, W);
+    ISX_REQUIRE(W % 4 == 0 && W <= isx::ST_MAXW, "isx_stem7x7_pool_nhwc: W=%d must be a multiple of 4 and <= %d", W, isx::ST_MAXW);
+    ISX_REQUIRE(H <= 32768 && B < (1ll << 24), "isx_stem7x7_pool_nhwc: B=%lld H=%d too large", (long long)B, H);
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(x && w_ohwi && bias && out && out != x, "isx_stem7x7_pool_nhwc: null or aliased pointer");
+    ISX_REQUIRE((((uintptr_t)x) % 16) == 0, "isx_stem7x7_pool_nhwc: x must be 16-B aligned");
+    isx::StemGeom g;
+    g.H = H; g.W = W;
+    g.Hc = (H - 1) / 2 + 1; g.Wc = (W - 1) / 2 + 1;
+    g.Hp = (g.Hc - 1) / 2 + 1; g.Wp = (g.Wc - 1) / 2 + 1;
+    g.steps = (g.Hc + 7) / 8;
+    ISX_REQUIRE((int64_t)g.Hp * g.Wp * 256 < (1ll << 31), "isx_stem7x7_pool_nhwc: pooled map of one image above 2 GiB");
+    int bands = 1;                                               // few images: split each into bands of steps so that every CU has work
+    while (B * bands < 256 && bands * 4 <= g.steps) bands *= 2;
+    g.bands = bands;
+    hipLaunchKernelGGL(isx::stem7x7_pool_kernel, dim3((unsigned)(B * bands)), dim3(512), 0, (hipStream_t)stream, x, g, w_ohwi, bias, out);
+    ISX_CHECK_LAUNCH("isx_stem7x7_pool_nhwc");
+    return ISX_OK;
+}

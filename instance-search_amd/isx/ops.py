@@ -144,6 +144,36 @@ def bias_relu_maxpool(y, bias):
     return out
 
 
+STEM_MAX_W = 224
+
+
+def stem7x7_pool_applicable(x, conv):
+    """Can `stem7x7_pool` run this convolution (the ResNet stem: 3 -> 64, 7x7, stride 2, padding 3) on x?"""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and x.shape[3] % 4 == 0 and x.shape[3] <= STEM_MAX_W
+            and x.is_contiguous(memory_format=torch.channels_last) and conv.in_channels == 3 and conv.out_channels == 64
+            and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (2, 2) and tuple(conv.padding) == (3, 3)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and x.data_ptr() % 16 == 0)
+
+
+def stem7x7_pool(x, w_ohwi, bias):
+    """relu(conv7x7 / stride 2 / padding 3 (x) + bias) -> MaxPool2d(3, 2, 1) of a channels-last (B,3,H,W) fp32 batch as ONE kernel.
+    w_ohwi: (64,7,7,3) contiguous (= conv.weight.permute(0,2,3,1)).  Returns channels-last (B,64,Hp,Wp)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.IsxError("x must be a channels-last float32 CUDA tensor (B,3,H,W)")
+    _on_current_device(x, "x")
+    B, _, H, W = x.shape
+    w = _f32(w_ohwi, "w_ohwi")
+    if tuple(w.shape) != (64, 7, 7, 3):
+        raise _lib.IsxError("w_ohwi must be (64, 7, 7, 3)")
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1
+    out = torch.empty((B, 64, Hp, Wp), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    bp = _f32(bias, "bias").data_ptr()
+    _timed("isx_stem7x7_pool_nhwc", 2.0 * B * Hc * Wc * 147 * 64, 4.0 * (B * H * W * 3 + B * Hp * Wp * 64 + 147 * 64),
+           lambda: check(lib().isx_stem7x7_pool_nhwc(x.data_ptr(), B, H, W, w.data_ptr(), bp, out.data_ptr(), _stream()), "isx_stem7x7_pool_nhwc"))
+    return out
+
+
 def conv1x1_nhwc(x, weight, bias, residual=None, relu=True):
     """1x1 stride-1 convolution of a channels-last (B,Cin,H,W) fp32 tensor with the epilogue fused:
     act(conv(x, weight) + bias (+ residual)) as ONE fp32-MFMA GEMM over the B*H*W pixels.  weight: (Cout,Cin[,1,1]).

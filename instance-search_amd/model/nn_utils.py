@@ -82,6 +82,7 @@ def extract_layers(net):
 _CONV3X3_MODE = os.environ.get("ISX_CONV3X3", "auto")
 _IMPLICIT_GEMM_3X3 = _CONV3X3_MODE != "0"
 _GEMM_1X1 = os.environ.get("ISX_CONV1X1", "1") != "0"
+_FUSED_STEM = os.environ.get("ISX_STEM", "1") != "0"       # 0: stem convolution back to MIOpen + the separate bias/ReLU/maxpool pass
 _FUSE_PROJECTION = os.environ.get("ISX_FUSE_PROJECTION", "1") != "0"     # last 1x1 conv + projection shortcut as one GEMM
 
 
@@ -155,9 +156,14 @@ class _StemConvPool(nn.Module):
     def forward(self, x):
         c = self.cba
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and c.conv.out_channels % 4 == 0):
+            from isx import ops
+            if _FUSED_STEM and ops.stem7x7_pool_applicable(x, c.conv):
+                # 224-wide (or narrower) images: convolution + bias + ReLU + pooling as ONE kernel, nothing in between touches memory
+                if c._w_ohwi is None or c._w_ohwi.device != x.device:
+                    c._w_ohwi = c.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+                return ops.stem7x7_pool(x, c._w_ohwi, c.bias)
             y = c.conv(x)
             if y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous():
-                from isx import ops
                 return ops.bias_relu_maxpool(y, c.bias)
             return self.pool(ops_bias_act(y, c.bias, c.relu))
         return self.pool(c(x))

@@ -297,6 +297,44 @@ ISXO_API void isxo_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin
             }
 }
 
+/* The torchvision ResNet stem on a channels-last image batch (conv1 7x7 / stride 2 / padding 3 with bn1 folded, relu, maxpool 3/2/1;
+ * the first four modules of the `features` trunk of model/ModelDefinition.py as split by model/nn_utils.py:56-71):
+ * conv = fma chain over (kh, kw, c) ascending, padding taps contribute fma(0, w, acc); y = relu(conv + bias); out = max over the
+ * in-bounds 3x3 window.  x: (B,H,W,3), w: (64,7,7,3), out: (B,Hp,Wp,64). */
+ISXO_API void isxo_stem7x7_pool_nhwc(const float* x, int64_t B, int H, int W, const float* w, const float* bias, float* out) {
+    const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
+    float* y = (float*)malloc((size_t)Hc * Wc * 64 * sizeof(float));
+    for (int64_t b = 0; b < B; ++b) {
+        for (int ho = 0; ho < Hc; ++ho)
+            for (int wo = 0; wo < Wc; ++wo)
+                for (int co = 0; co < 64; ++co) {
+                    float acc = 0.0f;
+                    for (int kh = 0; kh < 7; ++kh)
+                        for (int kw = 0; kw < 7; ++kw) {
+                            const int hi = ho * 2 - 3 + kh, wi = wo * 2 - 3 + kw;
+                            const int ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
+                            const float* xp = x + ((b * H + (ok ? hi : 0)) * W + (ok ? wi : 0)) * 3;
+                            const float* wp = w + (((int64_t)co * 7 + kh) * 7 + kw) * 3;
+                            for (int c = 0; c < 3; ++c) acc = fmaf(ok ? xp[c] : 0.0f, wp[c], acc);
+                        }
+                    y[((int64_t)ho * Wc + wo) * 64 + co] = fmaxf(acc + bias[co], 0.0f);
+                }
+        for (int po = 0; po < Hp; ++po)
+            for (int qo = 0; qo < Wp; ++qo)
+                for (int co = 0; co < 64; ++co) {
+                    float m = -INFINITY;
+                    for (int kh = 0; kh < 3; ++kh)
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const int hi = po * 2 - 1 + kh, wi = qo * 2 - 1 + kw;
+                            if (hi < 0 || hi >= Hc || wi < 0 || wi >= Wc) continue;
+                            m = fmaxf(m, y[((int64_t)hi * Wc + wi) * 64 + co]);
+                        }
+                    out[(((b * Hp) + po) * Wp + qo) * 64 + co] = m;
+                }
+    }
+    free(y);
+}
+
 /* Fused form of  torch.mm -> (sort | topk): per query the k best gallery rows in
  * canonical order, global index = idx_base + local row.  Entries beyond N are
  * (-inf, -1). */

@@ -120,6 +120,15 @@ def bias_relu_maxpool_nhwc(y, bias):
     return out
 
 
+def stem7x7_pool_nhwc(x, w_ohwi, bias):
+    """x: (B,H,W,3), w_ohwi: (64,7,7,3) -> relu(conv7x7/2 + bias) -> maxpool 3/2/1: (B,Hp,Wp,64)."""
+    x = _f32(x); w = _f32(w_ohwi); bias = _f32(bias); B, H, W, _ = x.shape
+    Hc, Wc = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = np.empty((B, (Hc - 1) // 2 + 1, (Wc - 1) // 2 + 1, 64), np.float32)
+    lib().isxo_stem7x7_pool_nhwc(_p(x, F32P), C.c_int64(B), H, W, _p(w, F32P), _p(bias, F32P), _p(out, F32P))
+    return out
+
+
 def conv1x1_nhwc(x, w, bias, res=None, relu=True):
     """x: (M, Cin) pixels, w: (Cout, Cin), res: (M, Cout) or None -> (M, Cout)."""
     x = _f32(x); w = _f32(w); bias = _f32(bias); M, Cin = x.shape; Cout = w.shape[0]

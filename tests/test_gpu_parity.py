@@ -476,6 +476,26 @@ def test_conv3x3_nhwc(ops, B, H, W, Cin, Cout, stride, res, relu):
     np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1)), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 224, 224), (3, 224, 224), (2, 50, 36), (1, 8, 4), (5, 100, 224), (2, 230, 200), (1, 1, 4), (300, 32, 32),
+                                   (1, 17, 12)])
+def test_stem7x7_pool(ops, B, H, W):
+    """The fused stem (csrc/stem.hip: conv 7x7/2 + bias + ReLU + maxpool 3/2/1, one kernel, convolution output never stored) against
+    the oracle's fma chain bit for bit: full 224 x 224 images (one workgroup per image and, for few images, bands of rows with a
+    recomputed carry row), ragged heights (last step partly outside), narrow images (masked columns / partial DMA rows), more images
+    than CUs; and within 1e-4 of torch's conv2d + relu + max_pool2d on the same device."""
+    rng = np.random.default_rng(H * 1000 + W + B)
+    x = rng.standard_normal((B, H, W, 3), dtype=np.float32)
+    w = rng.standard_normal((64, 7, 7, 3), dtype=np.float32) * np.float32(147 ** -0.5)
+    b = rng.standard_normal(64, dtype=np.float32)
+    xt = dev(x).permute(0, 3, 1, 2)
+    got = host(ops.stem7x7_pool(xt, dev(w), dev(b)).permute(0, 2, 3, 1))
+    want = O.stem7x7_pool_nhwc(x, w, b)
+    assert got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+    ref = torch.nn.functional.max_pool2d(torch.relu(torch.nn.functional.conv2d(xt, dev(w).permute(0, 3, 1, 2), dev(b), stride=2, padding=3)), 3, 2, 1)
+    np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1)), rtol=1e-4, atol=1e-4)
+
+
 @pytest.mark.parametrize("B,H,W,C", [(1, 1, 1, 4), (2, 7, 9, 8), (3, 112, 112, 64), (2, 12, 13, 36), (1, 2, 2, 4)])
 def test_bias_relu_maxpool(ops, B, H, W, C):
     rng = np.random.default_rng(H + C)
