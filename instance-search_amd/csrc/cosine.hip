@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
 // smallest estimated time  rounds(T tiles over S slots) * tile_work / efficiency  -- large
 // problems get 128x128, mid-size ones (bench: 512 x 10k) avoid a half-empty last round.
 struct TileCfg { int tm, tn, wg_per_cu; float eff; };
-static const TileCfg kCfgs[] = { {2, 2, 4, 0.845f}, {1, 2, 4, 0.79f}, {2, 1, 4, 0.805f}, {1, 1, 6, 0.72f} };
+static const TileCfg kCfgs[] = { {2, 2, 4, 0.92f}, {1, 2, 4, 0.87f}, {2, 1, 4, 0.89f}, {1, 1, 6, 0.84f} };     // 10 000 x 32 768 x 2048: 145 / 137 / 140 / 132 TFLOP/s
 static int g_force_cfg = -1;            // debug / A-B hook
 void set_gemm_cfg(int c) { g_force_cfg = c; }
 
@@ -220,7 +220,11 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
         // fades quadratically for longer ones (fitted on MI355X, 256 ... 10k query rows x 10k ... 100k)
         const double x = tiles / slots;
         const double t0 = (c == 0 ? 0.22 : c == 3 ? 0.15 : 0.25);
-        const double rounds = x + (x <= 0.7 ? t0 : t0 * (0.7 / x) * (0.7 / x));
+        double rounds = x + (x <= 0.7 ? t0 : t0 * (0.7 / x) * (0.7 / x));
+        // a CU works its tiles off at the rate of its matrix pipe however many of them are resident: the launch cannot end before the
+        // CU with one tile more than the average is done (50 176 x 512 x 2048: 1568 tiles of 128x128 = 6.1 per CU took 7 tile times)
+        const double per_cu = (double)((int64_t)((tiles + 255.0) / 256.0)) / k.wg_per_cu;
+        rounds = rounds > per_cu ? rounds : per_cu;
         const double t = rounds * k.wg_per_cu * (k.tm * k.tn) / k.eff;
         if (t < best_t) { best_t = t; best = c; }
     }

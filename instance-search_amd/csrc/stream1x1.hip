@@ -186,7 +186,9 @@ static int launch_stream(const float* x, int64_t M, const float* w, const float*
 // true when the streaming kernel covers the shape (the caller falls back to the tiled GEMM otherwise): the Cin = 64 layers of the first
 // ResNet stage at 56x56 -- 64->64, 64->256 (+ residual) -- with enough pixels to fill the chip.  (Measured and NOT dispatched: the
 // KC = 4 instantiations for 256->64 / 256->128 -- 128 weight registers per lane, four barriers per tile -- ran 1.12 / 1.92 ms against
-// 1.01 / 1.88 ms for the tiled GEMM at B = 1024.)
+// 1.01 / 1.88 ms for the tiled GEMM at B = 1024; a 128 -> 512 (+ residual) instantiation -- KC = 2, two column halves per pixel tile on
+// workgroup pairs of one XCD -- ran 1.09 ms against 1.02 ms: with MFMA and HBM time balanced the per-step barrier of this kernel costs
+// more than the tiled GEMM's four independent workgroups per CU.)
 bool conv1x1_stream_applicable(int64_t M, int Cin, int Cout, const float* x, const float* res) {
     (void)res;
     return Cin == 64 && (Cout == 64 || Cout == 256) && M >= 16384 && ((((uintptr_t)x) & 15) == 0);
