@@ -2,7 +2,8 @@
 """Condense rocprofv3 output under gpurun_out/ into the tracked summaries of profiles/.
 
   python profiles/summarize_prof.py <tag> <dir of `rocprofv3 --kernel-trace --stats -- python3 bench.py ...`>
-                                    [<dir of the --pmc FETCH_SIZE pass> <dir of the --pmc WRITE_SIZE pass>]
+                                    [<dir of the --pmc FETCH_SIZE pass> <dir of the --pmc WRITE_SIZE pass>
+                                     [<dir of the --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE pass>]]
 
 Writes
   profiles/<tag>_kernel_stats.csv           every isx:: kernel + the 12 heaviest others (the rocprofv3 --stats table)
@@ -11,6 +12,11 @@ Writes
 and, when the two PMC passes are given (same command, counters in passes of their own: FETCH_SIZE and WRITE_SIZE do not fit one pass),
   profiles/<tag>_pmc_hbm.csv                HBM bytes per kernel family of one steady-state step
   profiles/roofline_traffic.json            the same numbers keyed the way bench.py looks them up, stamped with their source
+and, with the third counter pass,
+  profiles/<tag>_pmc_mfma.csv               matrix-pipe utilisation per kernel family of one steady-state step: SQ_VALU_MFMA_BUSY_CYCLES /
+                                            (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), the average clock (cycles / kernel time) and, from both,
+                                            the TFLOP/s the family could reach at 100 % pipe utilisation AT THAT CLOCK (v_mfma_f32_32x32x2_f32:
+                                            4096 FLOP per 64 cycles = 64 FLOP per SIMD and cycle; 157.3 TFLOP/s at 2.4 GHz)
 HBM bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced
 reads, WRITE_SIZE is exact; both count at the L2's fabric side, so Infinity-Cache hits are included)."""
 import collections
@@ -123,6 +129,29 @@ def main():
                "of `python bench.py`, bytes = 2 x FETCH_SIZE + WRITE_SIZE, summed over the family's launches in the step; collected %s"
                % (tag, datetime.date.today().isoformat()))
         json.dump({"source": src, "kernels": out}, open(os.path.join(HERE, "roofline_traffic.json"), "w"), indent=1)
+    if len(sys.argv) >= 6:
+        rows = list(csv.DictReader(open(find(sys.argv[5], "_counter_collection.csv"))))
+        one = {}
+        for cname in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
+            one[cname] = one_step([r for r in rows if r["Counter_Name"] == cname], "Kernel_Name", "Start_Timestamp")
+        fam = collections.defaultdict(lambda: collections.defaultdict(float))
+        for cname, rs in one.items():
+            for r in rs:
+                fm = family(r["Kernel_Name"]) or "(other)"
+                fam[fm][cname] += float(r["Counter_Value"])
+                if cname == "GRBM_GUI_ACTIVE":
+                    fam[fm]["ns"] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                    fam[fm]["launches"] += 1
+        with open(os.path.join(HERE, tag + "_pmc_mfma.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["family", "launches_in_step", "kernel_us_in_step(with counters on)", "avg_clock_GHz", "mfma_pipe_busy", "fp32_mfma_peak_at_that_clock_TFLOPs"])
+            for fm, d in sorted(fam.items()):
+                cyc = d["GRBM_GUI_ACTIVE"] / 8.0
+                if cyc <= 0 or d["ns"] <= 0:
+                    continue
+                clock = cyc / d["ns"]
+                w.writerow([fm, int(d["launches"]), "%.1f" % (d["ns"] / 1e3), "%.3f" % clock, "%.3f" % (d["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024.0)),
+                            "%.1f" % (clock * 1024 * 64 / 1e3)])
 
 
 if __name__ == "__main__":

@@ -477,7 +477,7 @@ def test_conv3x3_nhwc(ops, B, H, W, Cin, Cout, stride, res, relu):
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 224, 224), (3, 224, 224), (2, 50, 36), (1, 8, 4), (5, 100, 224), (2, 230, 200), (1, 1, 4), (300, 32, 32),
-                                   (1, 17, 12)])
+                                   (1, 17, 12), (1, 223, 224), (2, 300, 4), (257, 16, 8), (4, 129, 220)])
 def test_stem7x7_pool(ops, B, H, W):
     """The fused stem (csrc/stem.hip: conv 7x7/2 + bias + ReLU + maxpool 3/2/1, one kernel, convolution output never stored) against
     the oracle's fma chain bit for bit: full 224 x 224 images (one workgroup per image and, for few images, bands of rows with a
