@@ -21,19 +21,15 @@ namespace isx {
 // Bottleneck / both convolutions of BasicBlock inside the `features` trunk.
 struct Conv3x3Geom { int H, W, Cin, Ho, Wo, stride; };
 
+// one (64 TM) x (64 TN) output tile at rows m0.., columns n0..; lds: BK * (64 TM + 64 TN + 2 pads) floats
 template <int TM, int TN, int BK>
-__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
-                                                           Conv3x3Geom g, float* __restrict__ C, TileMap tm,
-                                                           const float* __restrict__ bias, const float* __restrict__ res, int relu) {
+__device__ __forceinline__ void conv3x3_tile(float* __restrict__ lds, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
+                                             const Conv3x3Geom& g, float* __restrict__ C, int64_t m0, int64_t n0,
+                                             const float* __restrict__ bias, const float* __restrict__ res, int relu) {
     constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
     constexpr int CH = BK / 4, NA = BM * CH / 256;
-    __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
     float* Bs = lds + BK * LDA;
-
-    int tile_m, tile_n;
-    tile_of_block(tm, tile_m, tile_n);
-    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
     const int D = 9 * g.Cin;
     const int64_t ldc = N;
 
@@ -125,12 +121,53 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel
 }
 
 template <int TM, int TN, int BK>
+__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
+                                                           Conv3x3Geom g, float* __restrict__ C, TileMap tm,
+                                                           const float* __restrict__ bias, const float* __restrict__ res, int relu) {
+    __shared__ float lds[BK * (64 * TM + 64 * TN + 2 * lds_pad(BK))];
+    int tile_m, tile_n;
+    tile_of_block(tm, tile_m, tile_n);
+    conv3x3_tile<TM, TN, BK>(lds, x, M, Wt, N, g, C, (int64_t)tile_m * (64 * TM), (int64_t)tile_n * (64 * TN), bias, res, relu);
+}
+
+// 128x128 tiles with a 64x64 TAIL.  A launch whose tile count is a little above a whole number of rounds (1024 resident workgroups) ends
+// with a few 128x128 tiles running alone on their CUs at half the matrix-pipe rate while the other CUs idle -- 256->256 at 14x14, B = 1024:
+// 3136 tiles = 3 rounds + 64 tiles, 256 us of tail in a 1.79 ms launch.  Here the rows past the last whole round are cut into 64x64
+// tiles (a quarter of the work each, four times as many): the same blocks of the grid, same arithmetic per output element.
+__global__ __launch_bounds__(256, 4) void conv3x3_tail_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N, Conv3x3Geom g,
+                                                              float* __restrict__ C, TileMap tm_big, TileMap tm_small, int64_t m_split,
+                                                              const float* __restrict__ bias, const float* __restrict__ res, int relu) {
+    __shared__ float lds[16 * (128 + 128 + 2 * lds_pad(16))];                        // = 32 * (64 + 64 + 2 * lds_pad(32)) floats
+    static_assert(16 * (128 + 128 + 2 * lds_pad(16)) >= 32 * (64 + 64 + 2 * lds_pad(32)), "LDS of the small tile");
+    const int nbig = tm_big.tiles_m * tm_big.tiles_n;                                // a multiple of 8: the XCD of a block is the same in both numberings
+    int tile_m, tile_n;
+    if ((int)blockIdx.x < nbig) {
+        tile_of_block(tm_big, tile_m, tile_n, (int)blockIdx.x, nbig);
+        conv3x3_tile<2, 2, 16>(lds, x, M, Wt, N, g, C, (int64_t)tile_m * 128, (int64_t)tile_n * 128, bias, res, relu);
+    } else {
+        tile_of_block(tm_small, tile_m, tile_n, (int)blockIdx.x - nbig, tm_small.tiles_m * tm_small.tiles_n);
+        conv3x3_tile<1, 1, 32>(lds, x, M, Wt, N, g, C, m_split + (int64_t)tile_m * 64, (int64_t)tile_n * 64, bias, res, relu);
+    }
+}
+
+template <int TM, int TN, int BK>
 static void launch_conv3x3(const float* x, int64_t M, const float* w, int64_t N, const Conv3x3Geom& g, float* y, const float* bias,
                            const float* res, int relu, hipStream_t st) {
     TileMap tm;
     tm.m_active = nullptr;
     tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
     tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
+    const int64_t split = (TM == 2 && TN == 2) ? gemm_tail_split_rows(M, N) : 0;
+    if (split > 0) {
+        TileMap small;
+        small.m_active = nullptr;
+        tm.tiles_m = (int)(split / 128);
+        small.tiles_m = (int)((M - split + 63) / 64);
+        small.tiles_n = (int)((N + 63) / 64);
+        hipLaunchKernelGGL(conv3x3_tail_kernel, dim3((unsigned)(tm.tiles_m * tm.tiles_n + small.tiles_m * small.tiles_n)), dim3(256), 0, st, x, M, w, N, g, y,
+                           tm, small, split, bias, res, relu);
+        return;
+    }
     hipLaunchKernelGGL((conv3x3_nhwc_kernel<TM, TN, BK>), dim3((unsigned)(tm.tiles_m * tm.tiles_n)), dim3(256), 0, st, x, M, w, N, g, y, tm, bias,
                        res, relu);
 }
@@ -145,19 +182,13 @@ static void launch_conv3x3(const float* x, int64_t M, const float* w, int64_t N,
 struct DualGeom { int H, W, Ho, Wo, stride, K1, K2; };
 
 template <int TM, int TN, int BK>
-__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t M,
-                                                                                      const float* __restrict__ Wt, int64_t N, DualGeom g,
-                                                                                      float* __restrict__ C, TileMap tm,
-                                                                                      const float* __restrict__ bias, int relu) {
+__device__ __forceinline__ void conv1x1_dual_tile(float* __restrict__ lds, const float* __restrict__ t, const float* __restrict__ x, int64_t M,
+                                                  const float* __restrict__ Wt, int64_t N, const DualGeom& g, float* __restrict__ C, int64_t m0, int64_t n0,
+                                                  const float* __restrict__ bias, int relu) {
     constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
     constexpr int CH = BK / 4, NA = BM * CH / 256;
-    __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
     float* Bs = lds + BK * LDA;
-
-    int tile_m, tile_n;
-    tile_of_block(tm, tile_m, tile_n);
-    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
     const int D = g.K1 + g.K2;
     const int64_t ldc = N;
 
@@ -236,12 +267,50 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_k
 }
 
 template <int TM, int TN, int BK>
+__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t M,
+                                                                                      const float* __restrict__ Wt, int64_t N, DualGeom g,
+                                                                                      float* __restrict__ C, TileMap tm,
+                                                                                      const float* __restrict__ bias, int relu) {
+    __shared__ float lds[BK * (64 * TM + 64 * TN + 2 * lds_pad(BK))];
+    int tile_m, tile_n;
+    tile_of_block(tm, tile_m, tile_n);
+    conv1x1_dual_tile<TM, TN, BK>(lds, t, x, M, Wt, N, g, C, (int64_t)tile_m * (64 * TM), (int64_t)tile_n * (64 * TN), bias, relu);
+}
+
+// 128x128 tiles + 64x64 tail in one grid (see conv3x3_tail_kernel)
+__global__ __launch_bounds__(256, 4) void conv1x1_dual_tail_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt,
+                                                                   int64_t N, DualGeom g, float* __restrict__ C, TileMap tm_big, TileMap tm_small,
+                                                                   int64_t m_split, const float* __restrict__ bias, int relu) {
+    __shared__ float lds[16 * (128 + 128 + 2 * lds_pad(16))];
+    const int nbig = tm_big.tiles_m * tm_big.tiles_n;
+    int tile_m, tile_n;
+    if ((int)blockIdx.x < nbig) {
+        tile_of_block(tm_big, tile_m, tile_n, (int)blockIdx.x, nbig);
+        conv1x1_dual_tile<2, 2, 16>(lds, t, x, M, Wt, N, g, C, (int64_t)tile_m * 128, (int64_t)tile_n * 128, bias, relu);
+    } else {
+        tile_of_block(tm_small, tile_m, tile_n, (int)blockIdx.x - nbig, tm_small.tiles_m * tm_small.tiles_n);
+        conv1x1_dual_tile<1, 1, 32>(lds, t, x, M, Wt, N, g, C, m_split + (int64_t)tile_m * 64, (int64_t)tile_n * 64, bias, relu);
+    }
+}
+
+template <int TM, int TN, int BK>
 static void launch_dual(const float* t, const float* x, int64_t M, const float* w, int64_t N, const DualGeom& g, float* y, const float* bias, int relu,
                         hipStream_t st) {
     TileMap tm;
     tm.m_active = nullptr;
     tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
     tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
+    const int64_t split = (TM == 2 && TN == 2) ? gemm_tail_split_rows(M, N) : 0;
+    if (split > 0) {
+        TileMap small;
+        small.m_active = nullptr;
+        tm.tiles_m = (int)(split / 128);
+        small.tiles_m = (int)((M - split + 63) / 64);
+        small.tiles_n = (int)((N + 63) / 64);
+        hipLaunchKernelGGL(conv1x1_dual_tail_kernel, dim3((unsigned)(tm.tiles_m * tm.tiles_n + small.tiles_m * small.tiles_n)), dim3(256), 0, st, t, x, M, w, N, g,
+                           y, tm, small, split, bias, relu);
+        return;
+    }
     hipLaunchKernelGGL((conv1x1_dual_nhwc_kernel<TM, TN, BK>), dim3((unsigned)(tm.tiles_m * tm.tiles_n)), dim3(256), 0, st, t, x, M, w, N, g, y, tm,
                        bias, relu);
 }
@@ -286,7 +355,8 @@ ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, c
     ISX_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), "isx_conv3x3_nhwc: too many tiles");
     // measured on the ResNet-50 shapes at B = 1024 (ms, 128x128 / 128x64 / 64x64): 64->64 @56 3.70 / 2.10 / 2.04,
     // 128->128 @28 1.89 / 1.98 / 1.97, 256->256 @14 1.93 / 1.98 / 1.91, 512->512 @7 2.08 / 2.04 / 1.94
-    int best = (N >= 128 && N <= 256 && M > 131072) ? 0 : 3;
+    // 128x128 tiles (+ 64x64 tail) once they fill at least one round of the chip, 64x64 below that and for Cout = 64
+    int best = (N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) >= 1024) ? 0 : 3;
     if (g_force_conv_cfg == 0 || g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
     hipStream_t st = (hipStream_t)stream;
     switch (best) {
@@ -318,7 +388,7 @@ ISX_API int isx_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_
     ISX_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), "isx_conv1x1_dual_nhwc: too many tiles");
     // measured at B = 1024 (ms, 128x128 / 128x64 / 64x64): layer 1 2.10 / 2.22 / 2.21, layer 2 2.64 / 2.68 / 2.84,
     // layer 3 2.54 / 2.54 / 2.75, layer 4 (50 k pixels) 2.55 / 2.48 / 2.72
-    int best = (M > 131072 && N >= 128) ? 0 : 2;
+    int best = (N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) >= 1024) ? 0 : 2;      // 128x128 (+ 64x64 tail) from one full round on
     if (g_force_conv_cfg == 0 || g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
     hipStream_t st = (hipStream_t)stream;
     if (best == 0) launch_dual<2, 2, 16>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);
@@ -329,5 +399,8 @@ ISX_API int isx_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_
 }
 
 // Debug / A-B hook (not declared in include/isx.h): force the conv3x3 tile shape (0, 2, 3), -1 = automatic.
-ISX_API void isx_debug_set_conv_cfg(int c) { g_force_conv_cfg = c; }
+ISX_API void isx_debug_set_conv_cfg(int c) {
+    isx::g_tail_split = (c != 7);        // 7 = automatic tile choice WITHOUT the 64x64 tails (A/B)
+    g_force_conv_cfg = (c == 7) ? -1 : c;
+}
 

@@ -23,6 +23,8 @@
 //
 // The same kernel, epilogue mode 2, is the 1x1 convolution of the inference trunk (entry point in conv.hip); the chunked
 // running-top-k driver at the end of this file (run_topk_chunks) serves isx_cosine_topk and both phases of fast.hip.
+#include <stdlib.h>
+
 #include "gemm_tile.hpp"
 
 namespace isx {
@@ -31,20 +33,14 @@ namespace isx {
 // EPI: 0 = store scores, 1 = top-k filter (thr, gflag, ngrp), 2 = 1x1-convolution epilogue: thr = bias[n],
 // gflag = residual (float, same layout as C) or null, ngrp = relu flag
 template <bool ALIGNED, int TM, int TN, int EPI, int BK>
-__global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
-                                                          const float* __restrict__ G, int64_t N, int D,
-                                                          float* __restrict__ C, int64_t ldc, TileMap tm,
-                                                          const float* __restrict__ thr, uint8_t* __restrict__ gflag,
-                                                          int ngrp) {
+__device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const float* __restrict__ Q, int64_t M,
+                                                 const float* __restrict__ G, int64_t N, int D,
+                                                 float* __restrict__ C, int64_t ldc, int64_t m0, int64_t n0,
+                                                 const float* __restrict__ thr, uint8_t* __restrict__ gflag,
+                                                 int ngrp) {
     constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
-    __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
     float* Bs = lds + BK * LDA;
-
-    int tile_m, tile_n;
-    tile_of_block(tm, tile_m, tile_n);
-    const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
-    if (tm.m_active && m0 >= *tm.m_active) return;          // uniform: whole tile beyond the live rows
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -172,6 +168,52 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
     }
 }
 
+template <bool ALIGNED, int TM, int TN, int EPI, int BK>
+__global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
+                                                          const float* __restrict__ G, int64_t N, int D,
+                                                          float* __restrict__ C, int64_t ldc, TileMap tm,
+                                                          const float* __restrict__ thr, uint8_t* __restrict__ gflag,
+                                                          int ngrp) {
+    __shared__ float lds[BK * (64 * TM + 64 * TN + 2 * lds_pad(BK))];
+    int tile_m, tile_n;
+    tile_of_block(tm, tile_m, tile_n);
+    const int64_t m0 = (int64_t)tile_m * (64 * TM), n0 = (int64_t)tile_n * (64 * TN);
+    if (tm.m_active && m0 >= *tm.m_active) return;          // uniform: whole tile beyond the live rows
+    cosine_gemm_tile<ALIGNED, TM, TN, EPI, BK>(lds, Q, M, G, N, D, C, ldc, m0, n0, thr, gflag, ngrp);
+}
+
+// 1x1-convolution GEMM (EPI = 2) as 128x128 tiles with a 64x64 TAIL: the rows past the last whole round of 1024 resident workgroups run
+// as 64x64 tiles in the same grid (see conv3x3_tail_kernel in conv.hip: a few 128x128 tiles alone on their CUs at the end of a launch of
+// three to twelve rounds cost 3-10 % of it).  Same arithmetic per output element.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256, 4) void conv1x1_tail_kernel(const float* __restrict__ Q, int64_t M, const float* __restrict__ G, int64_t N, int D,
+                                                              float* __restrict__ C, int64_t ldc, TileMap tm_big, TileMap tm_small, int64_t m_split,
+                                                              const float* __restrict__ bias, uint8_t* __restrict__ res, int relu) {
+    __shared__ float lds[16 * (128 + 128 + 2 * lds_pad(16))];
+    static_assert(16 * (128 + 128 + 2 * lds_pad(16)) >= 32 * (64 + 64 + 2 * lds_pad(32)), "LDS of the small tile");
+    const int nbig = tm_big.tiles_m * tm_big.tiles_n;                 // a multiple of 8: a block's XCD is the same in both numberings
+    int tile_m, tile_n;
+    if ((int)blockIdx.x < nbig) {
+        tile_of_block(tm_big, tile_m, tile_n, (int)blockIdx.x, nbig);
+        cosine_gemm_tile<ALIGNED, 2, 2, 2, 16>(lds, Q, M, G, N, D, C, ldc, (int64_t)tile_m * 128, (int64_t)tile_n * 128, bias, res, relu);
+    } else {
+        tile_of_block(tm_small, tile_m, tile_n, (int)blockIdx.x - nbig, tm_small.tiles_m * tm_small.tiles_n);
+        cosine_gemm_tile<ALIGNED, 1, 1, 2, 32>(lds, Q, M, G, N, D, C, ldc, m_split + (int64_t)tile_m * 64, (int64_t)tile_n * 64, bias, res, relu);
+    }
+}
+
+// rows covered by whole rounds of 128x128 tiles when the rest of the grid is a partial round (0: no split)
+int g_tail_split = 1;
+int64_t gemm_tail_split_rows(int64_t M, int64_t N) {
+    static const bool env_off = [] { const char* e = getenv("ISX_TAIL_SPLIT"); return e && e[0] == '0'; }();      // A/B from the environment
+    if (env_off) return 0;
+    const int64_t tn = (N + 127) / 128, tiles = ((M + 127) / 128) * tn, slots = 1024;
+    if (!g_tail_split || tn > slots || slots % tn != 0) return 0;
+    const int64_t rounds = tiles / slots, rem = tiles - rounds * slots;
+    if (rounds < 1 || rem == 0 || rem > slots * 4 / 5) return 0;
+    return rounds * (slots / tn) * 128;
+}
+
 // ---- tile-shape selection ------------------------------------------------------------------
 // Candidate block tiles with their measured steady-state efficiency (fraction of the fp32-MFMA
 // peak on a large problem) and resident workgroups per CU.  The launcher picks the shape with the
@@ -211,6 +253,7 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     const bool aligned = (D % 32 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);     // no k tail for BK = 16 or 32
     int best = 0;
     double best_t = 1e300;
+    const int64_t split = (epi == 2) ? gemm_tail_split_rows(M, N) : 0;      // convolutions: 128x128 tiles + 64x64 tail in one grid
     for (int c = 0; c < 4; ++c) {
         const TileCfg& k = kCfgs[c];
         const double tiles = (double)((M + 64 * k.tm - 1) / (64 * k.tm)) * (double)((N + 64 * k.tn - 1) / (64 * k.tn));
@@ -225,6 +268,7 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
         // CU with one tile more than the average is done (50 176 x 512 x 2048: 1568 tiles of 128x128 = 6.1 per CU took 7 tile times)
         const double per_cu = (double)((int64_t)((tiles + 255.0) / 256.0)) / k.wg_per_cu;
         rounds = rounds > per_cu ? rounds : per_cu;
+        if (c == 0 && split > 0) rounds = x + 0.05;                          // the tail runs as small tiles: no round quantisation
         const double t = rounds * k.wg_per_cu * (k.tm * k.tn) / k.eff;
         if (t < best_t) { best_t = t; best = c; }
     }
@@ -233,6 +277,17 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     // wherever the grid fills the chip -- 256->1024 + residual 0.90 -> 0.87 ms, 512->2048 + residual 0.85 -> 0.81, 512->256 1.64 -> 1.58 --
     // and 128x64 for Cout = 64.)
     if (g_force_cfg >= 0 && g_force_cfg < 4) best = g_force_cfg;
+    if (best == 0 && split > 0) {
+        TileMap big, small;
+        big.m_active = small.m_active = nullptr;
+        big.tiles_m = (int)(split / 128); big.tiles_n = (int)((N + 127) / 128);
+        small.tiles_m = (int)((M - split + 63) / 64); small.tiles_n = (int)((N + 63) / 64);
+        const dim3 grid((unsigned)(big.tiles_m * big.tiles_n + small.tiles_m * small.tiles_n)), block(256);
+        if (aligned) hipLaunchKernelGGL((conv1x1_tail_kernel<true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, big, small, split, thr, gmax, relu);
+        else hipLaunchKernelGGL((conv1x1_tail_kernel<false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, big, small, split, thr, gmax, relu);
+        ISX_CHECK_LAUNCH("conv1x1_tail");
+        return ISX_OK;
+    }
     switch (best) {
         case 0: launch_cfg<2, 2, 16>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
         case 1: launch_cfg<1, 2, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;

@@ -20,10 +20,9 @@ struct TileMap {
     const int* m_active;       // optional device scalar: only rows < *m_active are live (fast.hip fallback)
 };
 
-__device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int& tile_n) {
+// b / nwg: block index and block count of the tile range (defaults: the whole grid)
+__device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int& tile_n, int b, int nwg) {
     // bijective XCD remap (blocks b and b+8 share an XCD): XCD x gets a contiguous id range
-    const int nwg = tm.tiles_m * tm.tiles_n;
-    const int b = blockIdx.x;
     const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
     // grouped order: GROUP_N n-tiles wide, all m-tiles tall, n fastest inside a group row
@@ -34,6 +33,10 @@ __device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int
     const int within = wg - gid * per_group;
     tile_m = within / gsz;
     tile_n = first_n + within % gsz;
+}
+
+__device__ __forceinline__ void tile_of_block(const TileMap tm, int& tile_m, int& tile_n) {
+    tile_of_block(tm, tile_m, tile_n, (int)blockIdx.x, tm.tiles_m * tm.tiles_n);
 }
 
 // Raw buffer descriptor over [base, base + nbytes) from WAVE-UNIFORM inputs (readfirstlane makes that provable to hipcc: no waterfall

@@ -19,6 +19,11 @@ int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t
 int launch_conv1x1_gemm(const float* x, int64_t M, const float* w, int64_t N, int D, float* y, const float* bias, const float* residual, int relu,
                         hipStream_t st);
 
+// Tail of a convolution launch in 128x128 tiles: rows covered by whole rounds of 1024 resident workgroups when the rest of the grid is a
+// partial round -- the caller runs the remaining rows as 64x64 tiles in the same grid; 0 = no split.  g_tail_split: debug / A-B switch.
+extern int g_tail_split;
+int64_t gemm_tail_split_rows(int64_t M, int64_t N);
+
 // Streaming variant for the HBM-bound Cin = 64 layers (stream1x1.hip): persistent workgroups, weights in registers, pixel tiles by LDS-DMA.
 bool conv1x1_stream_applicable(int64_t M, int Cin, int Cout, const float* x, const float* res);
 int launch_conv1x1_stream(const float* x, int64_t M, const float* w, int Cin, int Cout, const float* bias, const float* res, int relu, float* y,

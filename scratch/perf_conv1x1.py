@@ -38,12 +38,12 @@ for H, Cin, Cout, res in shapes:
         for cfg, tb in per.items():
             best = (tb, cfg) if best is None or tb < best[0] else best
         lib().isx_debug_set_gemm_cfg(-1)
-        lib().isx_debug_set_conv_cfg(9)
+        lib().isx_debug_set_conv_cfg(7)
         tgen = min(timeit(lambda: ops.conv1x1_nhwc(x, w, b, r, True)) for _ in range(2))
         lib().isx_debug_set_conv_cfg(-1)
     M = B * H * H
     fl = 2.0 * M * Cin * Cout
     byt = 4.0 * (M * Cin + M * Cout * (2 if res else 1))
     tot_a += ta; tot_b += tauto
-    print(f"H={H:3d} {Cin:5d}->{Cout:5d} res={int(res)} | miopen+epi {ta:7.3f} ms (conv {tc:7.3f}) | isx auto {tauto:7.3f} ms best {best[0]:7.3f} (cfg {best[1]}) | {fl/tauto/1e9:6.1f} TF {byt/tauto/1e6:7.1f} GB/s | cfg0..3: " + " ".join("%.3f" % per[c] for c in (0, 1, 2, 3)) + " | tiled GEMM %.3f" % tgen, flush=True)
+    print(f"H={H:3d} {Cin:5d}->{Cout:5d} res={int(res)} | miopen+epi {ta:7.3f} ms (conv {tc:7.3f}) | isx auto {tauto:7.3f} ms best {best[0]:7.3f} (cfg {best[1]}) | {fl/tauto/1e9:6.1f} TF {byt/tauto/1e6:7.1f} GB/s | cfg0..3: " + " ".join("%.3f" % per[c] for c in (0, 1, 2, 3)) + " | no tail %.3f" % tgen, flush=True)
 print(f"total miopen+epi {tot_a:.2f} ms, isx {tot_b:.2f} ms")

@@ -20,7 +20,7 @@ for H, Cin, Cout, s in shapes:
         ta = timeit(lambda: ops.bias_act_(conv(x), b, None, True))
         tc = timeit(lambda: conv(x))
         res = []
-        for cfg in (-1, 0, 2, 3):
+        for cfg in (-1, 0, 2, 3, 7):
             lib().isx_debug_set_conv_cfg(cfg)
             res.append(timeit(lambda: ops.conv3x3_nhwc(x, w, b, s, None, True)))
         lib().isx_debug_set_conv_cfg(-1)
@@ -29,4 +29,4 @@ for H, Cin, Cout, s in shapes:
         err = (y - ref).abs().max().item()
     Ho = (H - 1) // s + 1
     fl = 2.0 * B * Ho * Ho * 9 * Cin * Cout
-    print(f"H={H:3d} {Cin:4d}->{Cout:4d} s={s} | miopen+epi {ta:6.3f} (conv {tc:6.3f}) | isx auto {res[0]:6.3f} cfg0 {res[1]:6.3f} cfg2 {res[2]:6.3f} cfg3 {res[3]:6.3f} | {fl/res[0]/1e9:6.1f} TF | maxerr {err:.2e}", flush=True)
+    print(f"H={H:3d} {Cin:4d}->{Cout:4d} s={s} | miopen+epi {ta:6.3f} (conv {tc:6.3f}) | isx auto {res[0]:6.3f} cfg0 {res[1]:6.3f} cfg2 {res[2]:6.3f} cfg3 {res[3]:6.3f} notail {res[4]:6.3f} | {fl/res[0]/1e9:6.1f} TF | maxerr {err:.2e}", flush=True)

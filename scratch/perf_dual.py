@@ -18,9 +18,9 @@ for H, K1, K2, Cout, s in shapes:
     w = torch.randn(Cout, K1 + K2, device=dev) * (K1 + K2) ** -0.5
     b = torch.randn(Cout, device=dev)
     res = []
-    for cfg in (-1, 0, 2, 3):
+    for cfg in (-1, 0, 2, 3, 7):
         lib().isx_debug_set_conv_cfg(cfg)
         res.append(timeit(lambda: ops.conv1x1_dual_nhwc(t, x, w, b, s, True)))
     lib().isx_debug_set_conv_cfg(-1)
     fl = 2.0 * B * Ho * Ho * (K1 + K2) * Cout
-    print(f"H={H:3d} K={K1}+{K2} -> {Cout} s={s} | auto {res[0]:6.3f} cfg0 {res[1]:6.3f} cfg2 {res[2]:6.3f} cfg3 {res[3]:6.3f} | best {fl/min(res)/1e9:6.1f} TF", flush=True)
+    print(f"H={H:3d} K={K1}+{K2} -> {Cout} s={s} | auto {res[0]:6.3f} cfg0 {res[1]:6.3f} cfg2 {res[2]:6.3f} cfg3 {res[3]:6.3f} notail {res[4]:6.3f} | best {fl/min(res)/1e9:6.1f} TF", flush=True)

@@ -476,6 +476,35 @@ def test_conv3x3_nhwc(ops, B, H, W, Cin, Cout, stride, res, relu):
     np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1)), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("Cout,stride,res", [(128, 1, False), (256, 1, True), (128, 2, True)])
+def test_conv3x3_tail_split(ops, Cout, stride, res):
+    """A launch a little above a whole number of rounds of 128x128 tiles (here 1047 row tiles: one round of 1024 + 23) runs its last rows as
+    64x64 tiles in the same grid (conv3x3_tail_kernel).  Same bits as the plain 128x128 launch (debug cfg 7), as 64x64 tiles everywhere
+    (cfg 3), and as the oracle on the first and the last image (the last one lies in the 64x64 region)."""
+    from isx._lib import lib
+    B, Ho, Cin = 9, 122, 32
+    H = Ho * stride
+    rng = np.random.default_rng(Cout + stride)
+    x = np.maximum(rng.standard_normal((B, H, H, Cin), dtype=np.float32), 0)
+    w = rng.standard_normal((Cout, 3, 3, Cin), dtype=np.float32) * np.float32((9 * Cin) ** -0.5)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    r = rng.standard_normal((B, Ho, Ho, Cout), dtype=np.float32) if res else None
+    xt, rt = dev(x).permute(0, 3, 1, 2), (dev(r).permute(0, 3, 1, 2) if res else None)
+    set_cfg = lib().isx_debug_set_conv_cfg
+    out = {}
+    try:
+        for cfg in (0, 7, 3):
+            set_cfg(cfg)
+            out[cfg] = host(ops.conv3x3_nhwc(xt, dev(w), dev(b), stride, rt, True).permute(0, 2, 3, 1))
+    finally:
+        set_cfg(-1)
+    np.testing.assert_array_equal(out[0].view(np.int32), out[7].view(np.int32))
+    np.testing.assert_array_equal(out[0].view(np.int32), out[3].view(np.int32))
+    for i in (0, B - 1):
+        want = O.conv3x3_nhwc(x[i:i + 1], w, b, stride, r[i:i + 1] if res else None, True)
+        np.testing.assert_array_equal(out[0][i:i + 1], want)
+
+
 @pytest.mark.parametrize("B,H,W", [(1, 224, 224), (3, 224, 224), (2, 50, 36), (1, 8, 4), (5, 100, 224), (2, 230, 200), (1, 1, 4), (300, 32, 32),
                                    (1, 17, 12), (1, 223, 224), (2, 300, 4), (257, 16, 8), (4, 129, 220)])
 def test_stem7x7_pool(ops, B, H, W):
@@ -563,6 +592,59 @@ def test_conv1x1_dual_nhwc(ops, B, H, W, K1, K2, Cout, stride, relu):
     if relu:
         ref = torch.relu(ref)
     np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1)), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("Cin,Cout,res", [(32, 128, False), (64, 200, True), (40, 256, True)])
+def test_conv1x1_tail_split(ops, Cin, Cout, res):
+    """1x1 convolutions whose grid of 128x128 tiles ends in a partial round (133 956 pixels = 1047 row tiles) run the rows past the last
+    whole round as 64x64 tiles in the same launch (conv1x1_tail_kernel): same bits as the plain launch (debug cfg 7) and as the oracle on
+    row windows at the start, across the split at row 131 072 and at the ragged end; aligned and unaligned K, ragged Cout."""
+    from isx._lib import lib
+    M = 133956
+    rng = np.random.default_rng(Cin * 7 + Cout)
+    x = np.maximum(rng.standard_normal((M, Cin), dtype=np.float32), 0)
+    w = rng.standard_normal((Cout, Cin), dtype=np.float32) * np.float32(Cin ** -0.5)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    r = rng.standard_normal((M, Cout), dtype=np.float32) if res else None
+    xt = dev(x).view(1, M, 1, Cin).permute(0, 3, 1, 2)
+    rt = dev(r).view(1, M, 1, Cout).permute(0, 3, 1, 2) if res else None
+    set_cfg = lib().isx_debug_set_conv_cfg
+    try:
+        set_cfg(7)
+        plain = host(ops.conv1x1_nhwc(xt, dev(w), dev(b), rt, True).permute(0, 2, 3, 1).reshape(M, Cout))
+        set_cfg(-1)
+        tail = host(ops.conv1x1_nhwc(xt, dev(w), dev(b), rt, True).permute(0, 2, 3, 1).reshape(M, Cout))
+    finally:
+        set_cfg(-1)
+    np.testing.assert_array_equal(tail.view(np.int32), plain.view(np.int32))
+    rows = np.r_[0:200, 131072 - 150:131072 + 150, M - 200:M]
+    np.testing.assert_array_equal(tail[rows], O.conv1x1_nhwc(x[rows], w, b, r[rows] if res else None, True))
+
+
+@pytest.mark.parametrize("stride,Cout", [(1, 128), (2, 256)])
+def test_conv1x1_dual_tail_split(ops, stride, Cout):
+    """The fused projection GEMM with the 64x64 tail (conv1x1_dual_tail_kernel): same bits as the plain 128x128 launch and as the oracle on
+    the first and the last image."""
+    from isx._lib import lib
+    B, Ho, K1, K2 = 9, 122, 32, 64
+    H = Ho * stride
+    rng = np.random.default_rng(stride + Cout)
+    t = np.maximum(rng.standard_normal((B, Ho, Ho, K1), dtype=np.float32), 0)
+    x = np.maximum(rng.standard_normal((B, H, H, K2), dtype=np.float32), 0)
+    w = rng.standard_normal((Cout, K1 + K2), dtype=np.float32) * np.float32((K1 + K2) ** -0.5)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    tt, xt = dev(t).permute(0, 3, 1, 2), dev(x).permute(0, 3, 1, 2)
+    set_cfg = lib().isx_debug_set_conv_cfg
+    out = {}
+    try:
+        for cfg in (0, 7):
+            set_cfg(cfg)
+            out[cfg] = host(ops.conv1x1_dual_nhwc(tt, xt, dev(w), dev(b), stride, True).permute(0, 2, 3, 1))
+    finally:
+        set_cfg(-1)
+    np.testing.assert_array_equal(out[0].view(np.int32), out[7].view(np.int32))
+    for i in (0, B - 1):
+        np.testing.assert_array_equal(out[0][i:i + 1], O.conv1x1_dual_nhwc(t[i:i + 1], x[i:i + 1], w, b, stride, True))
 
 
 @pytest.mark.gpu
