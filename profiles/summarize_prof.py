@@ -43,11 +43,11 @@ def is_isx(name):
 
 def family(name):
     """bench.py's roofline family of a kernel name (None: not a family the bench reports)."""
-    if "conv1x1_stream_kernel" in name:
+    if "conv1x1_stream_kernel" in name or "conv1x1_tail_kernel" in name:
         return "isx_conv1x1_nhwc"
-    if "conv1x1_dual_nhwc_kernel" in name:
+    if "conv1x1_dual_nhwc_kernel" in name or "conv1x1_dual_tail_kernel" in name:
         return "isx_conv1x1_dual_nhwc"
-    if "conv3x3_nhwc_kernel" in name:
+    if "conv3x3_nhwc_kernel" in name or "conv3x3_tail_kernel" in name:
         return "isx_conv3x3_nhwc"
     if "stem7x7_pool_kernel" in name:
         return "isx_stem7x7_pool_nhwc"
