@@ -394,6 +394,7 @@ def main():
             "isx_conv1x1_nhwc": "conv1x1_tail_kernel / cosine_gemm_kernel<ALIGNED, TM, TN, EPI = 2, BK> + conv1x1_stream_kernel for Cin = 64 (isx_conv1x1_nhwc: 1x1 convolutions as fp32-MFMA GEMMs over the pixels, bias/residual/ReLU fused)",
             "isx_conv1x1_dual_nhwc": "conv1x1_dual_tail_kernel / conv1x1_dual_nhwc_kernel (isx_conv1x1_dual_nhwc: last 1x1 conv + projection shortcut as one GEMM)",
             "isx_conv3x3_nhwc": "conv3x3_tail_kernel / conv3x3_nhwc_kernel (isx_conv3x3_nhwc: implicit GEMM, 128x128 tiles + 64x64 tail, bias/residual/ReLU fused)",
+            "isx_conv3x3_expand_nhwc": "conv3x3_expand_kernel (isx_conv3x3_expand_nhwc: 3x3 convolution to 64 channels + 1x1 expansion + residual + ReLU, mid activation on chip)",
             "isx_stem7x7_pool_nhwc": "stem7x7_pool_kernel (isx_stem7x7_pool_nhwc: conv 7x7/2 + bias + ReLU + maxpool 3/2/1 as one kernel)",
         }
         for name, t in sorted(trunk.items()):

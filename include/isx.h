@@ -88,6 +88,14 @@ int isx_images_u8_to_f32(const uint8_t* img, int64_t B, int H, int W, float mean
  * y: (B,H,W,C), out: (B,Ho,Wo,C), Ho = (H-1)/2 + 1; C % 4 == 0. */
 int isx_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int H, int W, int C, float* out, isx_stream_t stream);
 
+/* conv2 + conv3 of a torchvision Bottleneck with 64 mid channels (the first ResNet stage; BN folded; model/nn_utils.py:56-71) as ONE kernel:
+ *   y = act( W3 . relu(conv3x3(x, W2) + b2) + b3 + (residual ? residual : 0) ),
+ * the 64-channel mid activation stays on chip (registers -> LDS -> second MFMA loop).  Same fma chains as isx_conv3x3_nhwc followed by
+ * isx_conv1x1_nhwc (bit-identical results).  x: (B,H,W,Cin), Cin % 32 == 0; w2_ohwi: (64,3,3,Cin); b2: (64); w3t: (64,256) = the 1x1
+ * weight (256,64) TRANSPOSED; b3: (256); y / residual: (B,Ho,Wo,256); Cout must be 256. */
+int isx_conv3x3_expand_nhwc(const float* x, int64_t B, int H, int W, int Cin, const float* w2_ohwi, const float* b2, int stride,
+                            const float* w3t, int Cout, const float* b3, const float* residual, int relu, float* y, isx_stream_t stream);
+
 /* The whole stem as ONE kernel: conv 7x7 / stride 2 / padding 3 (3 -> 64 channels, bn1 folded into w and bias) + ReLU +
  * MaxPool2d(3, stride 2, padding 1) on a channels-last image batch; the convolution output never reaches memory.  Replaces
  * conv1, bn1, relu, maxpool of the torchvision ResNet `features` trunk (model/ModelDefinition.py, split by model/nn_utils.py:56-71,

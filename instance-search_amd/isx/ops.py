@@ -248,6 +248,34 @@ def conv3x3_nhwc(x, w_ohwi, bias, stride=1, residual=None, relu=True):
     return y
 
 
+def conv3x3_expand_nhwc(x, w2_ohwi, b2, stride, w3t, b3, residual=None, relu=True):
+    """conv2 + conv3 of a Bottleneck with 64 mid channels as ONE kernel: act(W3 . relu(conv3x3(x, W2) + b2) + b3 (+ residual)).
+    x: channels-last (B,Cin,H,W); w2_ohwi: (64,3,3,Cin); w3t: (64,256) = conv3.weight.view(256,64).t().contiguous().
+    Returns channels-last (B,256,Ho,Wo)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)):
+        raise _lib.IsxError("x must be a channels-last float32 CUDA tensor (B,C,H,W)")
+    _on_current_device(x, "x")
+    B, Cin, H, W = x.shape
+    w2 = _f32(w2_ohwi, "w2_ohwi")
+    w3 = _f32(w3t, "w3t")
+    if tuple(w2.shape) != (64, 3, 3, Cin) or w3.dim() != 2 or w3.shape[0] != 64:
+        raise _lib.IsxError("w2_ohwi must be (64, 3, 3, Cin) and w3t (64, Cout)")
+    Cout = w3.shape[1]
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    rp = 0
+    if residual is not None:
+        if residual.shape != y.shape or residual.dtype != torch.float32 or not residual.is_contiguous(memory_format=torch.channels_last):
+            raise _lib.IsxError("residual must be a channels-last float32 tensor of the output's shape")
+        rp = residual.data_ptr()
+    b2p, b3p = _f32(b2, "b2").data_ptr(), _f32(b3, "b3").data_ptr()
+    _timed("isx_conv3x3_expand_nhwc", 2.0 * B * Ho * Wo * (9 * Cin * 64 + 64 * Cout),
+           4.0 * (B * H * W * Cin + B * Ho * Wo * Cout * (2 if rp else 1) + 9 * Cin * 64 + 64 * Cout),
+           lambda: check(lib().isx_conv3x3_expand_nhwc(x.data_ptr(), B, H, W, Cin, w2.data_ptr(), b2p, stride, w3.data_ptr(), Cout, b3p, rp,
+                                                       1 if relu else 0, y.data_ptr(), _stream()), "isx_conv3x3_expand_nhwc"))
+    return y
+
+
 def boxpool_s1(fmap, kh, kw):
     fmap = _f32(fmap, "fmap")
     B, Cc, H, W = fmap.shape

@@ -82,6 +82,7 @@ def extract_layers(net):
 _CONV3X3_MODE = os.environ.get("ISX_CONV3X3", "auto")
 _IMPLICIT_GEMM_3X3 = _CONV3X3_MODE != "0"
 _GEMM_1X1 = os.environ.get("ISX_CONV1X1", "1") != "0"
+_FUSE_EXPAND = os.environ.get("ISX_FUSE_EXPAND", "1") != "0"     # 0: conv2 and conv3 of the 64-channel bottlenecks as two kernels again
 _FUSED_STEM = os.environ.get("ISX_STEM", "1") != "0"       # 0: stem convolution back to MIOpen + the separate bias/ReLU/maxpool pass
 _FUSE_PROJECTION = os.environ.get("ISX_FUSE_PROJECTION", "1") != "0"     # last 1x1 conv + projection shortcut as one GEMM
 
@@ -198,11 +199,22 @@ class _FusedBlock(nn.Module):
             self.downsample = d                                             # projection (its bias lives in the last conv's epilogue)
 
         self._w_cat = None            # [W_last | W_projection] for the fused last-conv + shortcut GEMM, built on first use
+        self._w3t = None              # transposed expansion weight of the fused conv2 + conv3 kernel, built on first use
 
     def _fusable_projection(self, x):
         last, d = self.convs[-1], self.downsample
         return (_GEMM_1X1 and _FUSE_PROJECTION and d is not None and last._pointwise() and d.conv.kernel_size == (1, 1) and d.conv.padding == (0, 0)
                 and d.conv.groups == 1 and d.conv.stride in ((1, 1), (2, 2)) and last.conv.in_channels % 32 == 0 and d.conv.in_channels % 32 == 0
+                and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.dim() == 4
+                and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
+
+    def _fusable_expand(self, x):
+        if not (_FUSE_EXPAND and _GEMM_1X1 and _IMPLICIT_GEMM_3X3 and self.downsample is None and len(self.convs) == 3):
+            return False
+        c2, c3 = self.convs[1].conv, self.convs[2].conv
+        return (c2.kernel_size == (3, 3) and c2.padding == (1, 1) and c2.groups == 1 and c2.dilation == (1, 1) and c2.stride in ((1, 1), (2, 2))
+                and c2.out_channels == 64 and c2.in_channels % 32 == 0 and self.convs[1].relu and self.convs[2]._pointwise() and c3.in_channels == 64
+                and c3.out_channels == 256 and x.shape[1] == 256 and c2.stride == (1, 1)
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
 
@@ -221,6 +233,18 @@ class _FusedBlock(nn.Module):
             if not t.is_contiguous(memory_format=torch.channels_last):
                 t = t.contiguous(memory_format=torch.channels_last)
             return ops.conv1x1_dual_nhwc(t, x, self._w_cat, last.bias, d.conv.stride[0], last.relu)
+        if self._fusable_expand(x):
+            # Bottleneck with 64 mid channels and an identity shortcut (ResNet stage 1): conv2 + conv3 + residual + ReLU as ONE kernel
+            # (libisx isx_conv3x3_expand_nhwc): the mid activation never reaches memory
+            from isx import ops
+            c2, c3 = self.convs[1], self.convs[2]
+            if self._w3t is None or self._w3t.device != x.device:
+                c2._w_ohwi = c2.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+                self._w3t = c3.conv.weight.detach().reshape(c3.conv.out_channels, -1).t().contiguous()
+            t = self.convs[0](x)
+            if not t.is_contiguous(memory_format=torch.channels_last):
+                t = t.contiguous(memory_format=torch.channels_last)
+            return ops.conv3x3_expand_nhwc(t, c2._w_ohwi, c2.bias, c2.conv.stride[0], self._w3t, c3.bias, x, c3.relu)
         idt = x if self.downsample is None else self.downsample(x)
         y = x
         for c in self.convs[:-1]:

@@ -49,6 +49,8 @@ def family(name):
         return "isx_conv1x1_dual_nhwc"
     if "conv3x3_nhwc_kernel" in name or "conv3x3_tail_kernel" in name:
         return "isx_conv3x3_nhwc"
+    if "conv3x3_expand_kernel" in name:
+        return "isx_conv3x3_expand_nhwc"
     if "stem7x7_pool_kernel" in name:
         return "isx_stem7x7_pool_nhwc"
     if "gap_l2_nhwc_kernel" in name or "gap_l2_kernel" in name:

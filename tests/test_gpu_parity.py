@@ -476,6 +476,31 @@ def test_conv3x3_nhwc(ops, B, H, W, Cin, Cout, stride, res, relu):
     np.testing.assert_allclose(got, host(ref.permute(0, 2, 3, 1)), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,stride,res,relu", [(2, 7, 7, 64, 1, True, True), (1, 9, 11, 32, 2, False, True), (3, 56, 56, 64, 1, True, True),
+                                                       (1, 5, 5, 128, 1, True, False), (40, 14, 14, 64, 1, True, True), (1, 1, 1, 32, 1, False, True)])
+def test_conv3x3_expand(ops, B, H, W, Cin, stride, res, relu):
+    """conv2 (3x3 -> 64 channels, ReLU) + conv3 (1x1 -> 256, + residual, ReLU) of a Bottleneck as ONE kernel (conv3x3_expand_kernel: the
+    mid activation goes registers -> LDS -> second MFMA loop): same bits as the two separate libisx kernels and as the oracle's
+    conv3x3_nhwc followed by conv1x1_nhwc."""
+    rng = np.random.default_rng(B * 100 + H + Cin)
+    x = np.maximum(rng.standard_normal((B, H, W, Cin), dtype=np.float32), 0)
+    w2 = rng.standard_normal((64, 3, 3, Cin), dtype=np.float32) * np.float32((9 * Cin) ** -0.5)
+    b2 = rng.standard_normal(64, dtype=np.float32)
+    w3 = rng.standard_normal((256, 64), dtype=np.float32) * np.float32(0.125)
+    b3 = rng.standard_normal(256, dtype=np.float32)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    r = rng.standard_normal((B, Ho, Wo, 256), dtype=np.float32) if res else None
+    xt = dev(x).permute(0, 3, 1, 2)
+    rt = dev(r).permute(0, 3, 1, 2) if res else None
+    got = host(ops.conv3x3_expand_nhwc(xt, dev(w2), dev(b2), stride, dev(np.ascontiguousarray(w3.T)), dev(b3), rt, relu).permute(0, 2, 3, 1))
+    mid = ops.conv3x3_nhwc(xt, dev(w2), dev(b2), stride, None, True)
+    two = host(ops.conv1x1_nhwc(mid, dev(w3), dev(b3), rt, relu).permute(0, 2, 3, 1))
+    np.testing.assert_array_equal(got.view(np.int32), two.view(np.int32))
+    want_mid = O.conv3x3_nhwc(x, w2, b2, stride, None, True)
+    want = O.conv1x1_nhwc(want_mid.reshape(-1, 64), w3, b3, r.reshape(-1, 256) if res else None, relu).reshape(B, Ho, Wo, 256)
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("Cout,stride,res", [(128, 1, False), (256, 1, True), (128, 2, True)])
 def test_conv3x3_tail_split(ops, Cout, stride, res):
     """A launch a little above a whole number of rounds of 128x128 tiles (here 1047 row tiles: one round of 1024 + 23) runs its last rows as
