@@ -96,6 +96,13 @@ int isx_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int
 int isx_conv3x3_expand_nhwc(const float* x, int64_t B, int H, int W, int Cin, const float* w2_ohwi, const float* b2, int stride,
                             const float* w3t, int Cout, const float* b3, const float* residual, int relu, float* y, isx_stream_t stream);
 
+/* The same for the FIRST block of that stage, whose shortcut is a 1x1 projection of the 64-channel block input x2 (stride 1):
+ *   y = act( [W3 | Wd] . [relu(conv3x3(t, W2) + b2) ; x2] + bias )  -- one fma chain per output over the 64 mid channels, then the 64 channels
+ * of x2, as isx_conv3x3_nhwc followed by isx_conv1x1_dual_nhwc.  t: (B,H,W,Cin); x2: (B,H,W,64); wcat_t: (128,256) = [W3 | Wd] TRANSPOSED;
+ * bias: (256) = b3 + bd; y: (B,H,W,256). */
+int isx_conv3x3_expand_dual_nhwc(const float* t, int64_t B, int H, int W, int Cin, const float* w2_ohwi, const float* b2, const float* x2,
+                                 const float* wcat_t, int Cout, const float* bias, int relu, float* y, isx_stream_t stream);
+
 /* The whole stem as ONE kernel: conv 7x7 / stride 2 / padding 3 (3 -> 64 channels, bn1 folded into w and bias) + ReLU +
  * MaxPool2d(3, stride 2, padding 1) on a channels-last image batch; the convolution output never reaches memory.  Replaces
  * conv1, bn1, relu, maxpool of the torchvision ResNet `features` trunk (model/ModelDefinition.py, split by model/nn_utils.py:56-71,

@@ -29,6 +29,7 @@ _SIGNATURES = {
     "isx_conv1x1_dual_nhwc": (C.c_int, [VP, I32, VP, I64, I32, I32, I32, I32, VP, I32, VP, I32, VP, VP]),
     "isx_stem7x7_pool_nhwc": (C.c_int, [VP, I64, I32, I32, VP, VP, VP, VP]),
     "isx_conv3x3_expand_nhwc": (C.c_int, [VP, I64, I32, I32, I32, VP, VP, I32, VP, I32, VP, VP, I32, VP, VP]),
+    "isx_conv3x3_expand_dual_nhwc": (C.c_int, [VP, I64, I32, I32, I32, VP, VP, VP, VP, I32, VP, I32, VP, VP]),
     "isx_conv3x3_nhwc": (C.c_int, [VP, I64, I32, I32, I32, VP, I32, I32, VP, VP, I32, VP, VP]),
     "isx_boxpool_s1": (C.c_int, [VP, I64, I32, I32, I32, I32, I32, VP, VP]),
     "isx_best_location_desc": (C.c_int, [VP, I64, I32, I32, I32, F32, VP, VP, VP]),

@@ -276,6 +276,28 @@ def conv3x3_expand_nhwc(x, w2_ohwi, b2, stride, w3t, b3, residual=None, relu=Tru
     return y
 
 
+def conv3x3_expand_dual_nhwc(t, w2_ohwi, b2, x2, wcat_t, bias, relu=True):
+    """First block of a 64-mid-channel stage as ONE kernel: act([W3 | Wd] . [relu(conv3x3(t, W2) + b2) ; x2] + bias), stride 1.
+    t: channels-last (B,Cin,H,W); x2: channels-last (B,64,H,W); wcat_t: (128,256) = cat([W3, Wd], 1).t().contiguous()."""
+    for a, n in ((t, "t"), (x2, "x2")):
+        if not (a.is_cuda and a.dtype == torch.float32 and a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last)):
+            raise _lib.IsxError("%s must be a channels-last float32 CUDA tensor (B,C,H,W)" % n)
+        _on_current_device(a, n)
+    B, Cin, H, W = t.shape
+    w2 = _f32(w2_ohwi, "w2_ohwi")
+    wc = _f32(wcat_t, "wcat_t")
+    if tuple(w2.shape) != (64, 3, 3, Cin) or tuple(x2.shape) != (B, 64, H, W) or wc.dim() != 2 or wc.shape[0] != 128:
+        raise _lib.IsxError("w2_ohwi must be (64, 3, 3, Cin), x2 (B, 64, H, W) and wcat_t (128, Cout)")
+    Cout = wc.shape[1]
+    y = torch.empty((B, Cout, H, W), device=t.device, dtype=torch.float32, memory_format=torch.channels_last)
+    b2p, bp = _f32(b2, "b2").data_ptr(), _f32(bias, "bias").data_ptr()
+    _timed("isx_conv3x3_expand_nhwc", 2.0 * B * H * W * (9 * Cin * 64 + 128 * Cout),
+           4.0 * (B * H * W * (Cin + 64 + Cout) + 9 * Cin * 64 + 128 * Cout),
+           lambda: check(lib().isx_conv3x3_expand_dual_nhwc(t.data_ptr(), B, H, W, Cin, w2.data_ptr(), b2p, x2.data_ptr(), wc.data_ptr(), Cout, bp,
+                                                            1 if relu else 0, y.data_ptr(), _stream()), "isx_conv3x3_expand_dual_nhwc"))
+    return y
+
+
 def boxpool_s1(fmap, kh, kw):
     fmap = _f32(fmap, "fmap")
     B, Cc, H, W = fmap.shape

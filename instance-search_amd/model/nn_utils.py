@@ -208,6 +208,14 @@ class _FusedBlock(nn.Module):
                 and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and x.dim() == 4
                 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
 
+    def _fusable_expand_dual(self):
+        if not (_FUSE_EXPAND and _IMPLICIT_GEMM_3X3 and len(self.convs) == 3):
+            return False
+        c2, c3, d = self.convs[1].conv, self.convs[2].conv, self.downsample.conv
+        return (c2.kernel_size == (3, 3) and c2.padding == (1, 1) and c2.groups == 1 and c2.dilation == (1, 1) and c2.stride == (1, 1)
+                and c2.out_channels == 64 and c2.in_channels % 32 == 0 and self.convs[1].relu and c3.in_channels == 64 and c3.out_channels == 256
+                and d.in_channels == 64 and d.stride == (1, 1))
+
     def _fusable_expand(self, x):
         if not (_FUSE_EXPAND and _GEMM_1X1 and _IMPLICIT_GEMM_3X3 and self.downsample is None and len(self.convs) == 3):
             return False
@@ -227,6 +235,16 @@ class _FusedBlock(nn.Module):
             if self._w_cat is None or self._w_cat.device != x.device:
                 co = last.conv.out_channels
                 self._w_cat = torch.cat([last.conv.weight.detach().reshape(co, -1), d.conv.weight.detach().reshape(co, -1)], 1).contiguous()
+            if self._fusable_expand_dual():
+                # first block of the 64-channel stage: conv2 + conv3 + projection + ReLU as ONE kernel (isx_conv3x3_expand_dual_nhwc)
+                c2 = self.convs[1]
+                if self._w3t is None or self._w3t.device != x.device:
+                    c2._w_ohwi = c2.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
+                    self._w3t = self._w_cat.t().contiguous()
+                t = self.convs[0](x)
+                if not t.is_contiguous(memory_format=torch.channels_last):
+                    t = t.contiguous(memory_format=torch.channels_last)
+                return ops.conv3x3_expand_dual_nhwc(t, c2._w_ohwi, c2.bias, x, self._w3t, last.bias, last.relu)
             t = x
             for c in self.convs[:-1]:
                 t = c(t)

@@ -28,3 +28,11 @@ for rep in range(2):
 y1 = ops.conv1x1_nhwc(ops.conv3x3_nhwc(x, w2, b2, 1, None, True), w3, b3, r, True)
 y2 = ops.conv3x3_expand_nhwc(x, w2, b2, 1, w3t, b3, r, True)
 print("identical", bool(torch.equal(y1, y2)))
+# first block of the stage: 3x3 + fused projection GEMM vs the DUAL fused kernel
+x2 = torch.relu(torch.randn(B, 64, H, H, device=dev)).contiguous(memory_format=torch.channels_last)
+wc = torch.randn(256, 128, device=dev) * 128 ** -0.5
+wct = wc.t().contiguous()
+for rep in range(2):
+    t_two = timeit(lambda: ops.conv1x1_dual_nhwc(ops.conv3x3_nhwc(x, w2, b2, 1, None, True), x2, wc, b3, 1, True))
+    t_f = timeit(lambda: ops.conv3x3_expand_dual_nhwc(x, w2, b2, x2, wct, b3, True))
+    print(f"dual: back to back {t_two:.3f} ms | fused {t_f:.3f} ms", flush=True)

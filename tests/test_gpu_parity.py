@@ -501,6 +501,26 @@ def test_conv3x3_expand(ops, B, H, W, Cin, stride, res, relu):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,relu", [(2, 7, 7, 64, True), (1, 9, 11, 32, True), (3, 56, 56, 64, True), (1, 5, 5, 128, False), (1, 1, 1, 32, True)])
+def test_conv3x3_expand_dual(ops, B, H, W, Cin, relu):
+    """First block of the 64-channel stage as ONE kernel (conv3x3_expand_kernel<.., DUAL>): conv2 + ReLU, then [W3 | Wd] . [mid ; x2] + bias:
+    same bits as isx_conv3x3_nhwc followed by isx_conv1x1_dual_nhwc and as the oracle's composition."""
+    rng = np.random.default_rng(B * 10 + H + Cin)
+    t = np.maximum(rng.standard_normal((B, H, W, Cin), dtype=np.float32), 0)
+    x2 = np.maximum(rng.standard_normal((B, H, W, 64), dtype=np.float32), 0)
+    w2 = rng.standard_normal((64, 3, 3, Cin), dtype=np.float32) * np.float32((9 * Cin) ** -0.5)
+    b2 = rng.standard_normal(64, dtype=np.float32)
+    wc = rng.standard_normal((256, 128), dtype=np.float32) * np.float32(128 ** -0.5)
+    b = rng.standard_normal(256, dtype=np.float32)
+    tt, xt = dev(t).permute(0, 3, 1, 2), dev(x2).permute(0, 3, 1, 2)
+    got = host(ops.conv3x3_expand_dual_nhwc(tt, dev(w2), dev(b2), xt, dev(np.ascontiguousarray(wc.T)), dev(b), relu).permute(0, 2, 3, 1))
+    mid = ops.conv3x3_nhwc(tt, dev(w2), dev(b2), 1, None, True)
+    two = host(ops.conv1x1_dual_nhwc(mid, xt, dev(wc), dev(b), 1, relu).permute(0, 2, 3, 1))
+    np.testing.assert_array_equal(got.view(np.int32), two.view(np.int32))
+    want = O.conv1x1_dual_nhwc(O.conv3x3_nhwc(t, w2, b2, 1, None, True), x2, wc, b, 1, relu)
+    np.testing.assert_array_equal(got, want)
+
+
 @pytest.mark.parametrize("Cout,stride,res", [(128, 1, False), (256, 1, True), (128, 2, True)])
 def test_conv3x3_tail_split(ops, Cout, stride, res):
     """A launch a little above a whole number of rounds of 128x128 tiles (here 1047 row tiles: one round of 1024 + 23) runs its last rows as
