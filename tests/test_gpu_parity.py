@@ -551,7 +551,7 @@ def test_conv3x3_tail_split(ops, Cout, stride, res):
 
 
 @pytest.mark.parametrize("B,H,W", [(1, 224, 224), (3, 224, 224), (2, 50, 36), (1, 8, 4), (5, 100, 224), (2, 230, 200), (1, 1, 4), (300, 32, 32),
-                                   (1, 17, 12), (1, 223, 224), (2, 300, 4), (257, 16, 8), (4, 129, 220)])
+                                   (1, 17, 12), (1, 223, 224), (2, 300, 4), (257, 16, 8), (4, 129, 220), (100, 64, 64), (37, 100, 60)])
 def test_stem7x7_pool(ops, B, H, W):
     """The fused stem (csrc/stem.hip: conv 7x7/2 + bias + ReLU + maxpool 3/2/1, one kernel, convolution output never stored) against
     the oracle's fma chain bit for bit: full 224 x 224 images (one workgroup per image and, for few images, bands of rows with a
@@ -664,6 +664,32 @@ def test_conv1x1_tail_split(ops, Cin, Cout, res):
     np.testing.assert_array_equal(tail.view(np.int32), plain.view(np.int32))
     rows = np.r_[0:200, 131072 - 150:131072 + 150, M - 200:M]
     np.testing.assert_array_equal(tail[rows], O.conv1x1_nhwc(x[rows], w, b, r[rows] if res else None, True))
+
+
+@pytest.mark.parametrize("tiles_m", [1024 + 819, 1024 + 820, 2048 + 1, 1024])
+def test_conv1x1_tail_split_boundaries(ops, tiles_m):
+    """Around the decision of gemm_tail_split_rows (one whole round + a remainder of at most 80 % of a round is split; a fuller last round,
+    an exact number of rounds are not): whichever way the launch goes, the result equals the plain launch bit for bit and the oracle on
+    windows at the start, at the 1024-tile boundary and at the ragged end."""
+    from isx._lib import lib
+    Cin, Cout = 32, 128
+    M = tiles_m * 128 - (37 if tiles_m % 2 else 0)
+    rng = np.random.default_rng(tiles_m)
+    x = np.maximum(rng.standard_normal((M, Cin), dtype=np.float32), 0)
+    w = rng.standard_normal((Cout, Cin), dtype=np.float32) * np.float32(Cin ** -0.5)
+    b = rng.standard_normal(Cout, dtype=np.float32)
+    xt = dev(x).view(1, M, 1, Cin).permute(0, 3, 1, 2)
+    set_cfg = lib().isx_debug_set_conv_cfg
+    try:
+        set_cfg(7)
+        plain = host(ops.conv1x1_nhwc(xt, dev(w), dev(b), None, True).permute(0, 2, 3, 1).reshape(M, Cout))
+        set_cfg(-1)
+        auto = host(ops.conv1x1_nhwc(xt, dev(w), dev(b), None, True).permute(0, 2, 3, 1).reshape(M, Cout))
+    finally:
+        set_cfg(-1)
+    np.testing.assert_array_equal(auto.view(np.int32), plain.view(np.int32))
+    rows = np.r_[0:100, 131072 - 100:min(M, 131072 + 100), M - 100:M]
+    np.testing.assert_array_equal(auto[rows], O.conv1x1_nhwc(x[rows], w, b, None, True))
 
 
 @pytest.mark.parametrize("stride,Cout", [(1, 128), (2, 256)])
