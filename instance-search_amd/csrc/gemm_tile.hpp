@@ -13,7 +13,10 @@ namespace isx {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int GROUP_N = 16;            // n-tiles per scheduling group
+#ifndef ISX_GROUP_N
+#define ISX_GROUP_N 16
+#endif
+constexpr int GROUP_N = ISX_GROUP_N;            // n-tiles per scheduling group
 
 struct TileMap {
     int tiles_m, tiles_n;
