@@ -12,113 +12,9 @@
 //
 // Reference call sites: the torchvision ResNet `features` trunk built by model/ModelDefinition.py, split by
 // model/nn_utils.py:56-71 and run from model/siamese.py:20,107,151.
-#include "gemm_tile.hpp"
+#include "conv3x3_tile.hpp"
 
 namespace isx {
-
-// ---- 3x3 convolution (padding 1, stride 1 or 2) on NHWC activations as an IMPLICIT GEMM ----------------------
-// Same tile machinery as cosine_gemm_kernel: M = B*Ho*Wo output pixels, N = Cout, K = 9*Cin ordered (kh, kw, ci),
-// weights pre-arranged (Cout, 3, 3, Cin).  A k-tile lies inside one filter tap (Cin % BK == 0), so the A rows of a
-// k-tile are the input pixels shifted by that tap: one base pixel per staged row, kept in registers, plus a
-// bounds test per tap (padding rows load zeros -- fma(0, w, acc) leaves acc unchanged, as skipping the tap would).
-// Epilogue: bias (+ residual) + ReLU fused, wave-uniform row pointers.  Replaces conv2 of the torchvision
-// Bottleneck / both convolutions of BasicBlock inside the `features` trunk.
-struct Conv3x3Geom { int H, W, Cin, Ho, Wo, stride; };
-
-// accumulators of one (64 TM) x (64 TN) output tile at rows m0.., columns n0.. (every wave has left the LDS when this returns);
-// lds: BK * (64 TM + 64 TN + 2 pads) floats
-template <int TM, int TN, int BK>
-__device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
-                                                 const Conv3x3Geom& g, int64_t m0, int64_t n0, f32x16 (&acc)[TM][TN]) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
-    constexpr int CH = BK / 4, NA = BM * CH / 256;
-    float* As = lds;
-    float* Bs = lds + BK * LDA;
-    const int D = 9 * g.Cin;
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, half = lane >> 5;
-
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-
-    // staged A rows of this thread: top-left input pixel of the 3x3 window (may be -1: padding)
-    int pbase[NA], hw0[NA];                       // pixel index of (hi0, wi0); (hi0 + 1) << 16 | (wi0 + 1)
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        const int idx = j * 256 + threadIdx.x;
-        int64_t m = m0 + idx / CH;
-        m = m < M ? m : M - 1;
-        const int hw = g.Ho * g.Wo;
-        const int b = (int)(m / hw), rem = (int)(m - (int64_t)b * hw);
-        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
-        const int hi0 = ho * g.stride - 1, wi0 = wo * g.stride - 1;
-        pbase[j] = (b * g.H + hi0) * g.W + wi0;
-        hw0[j] = ((hi0 + 1) << 16) | (wi0 + 1);
-    }
-    const int c4 = (threadIdx.x % CH) << 2;
-    int kh = 0, kw = 0, ci0 = 0;                  // tap / channel offset of the NEXT k-tile to load (uniform)
-    float4 ra[NA], rb[BN * BK / 1024];
-    // A rows come through BUFFER loads: a wave-uniform descriptor that starts at the first input pixel this tile can touch, one 32-bit
-    // byte offset per staged row (recomputed once per filter tap), the channel offset inside the tap as the SGPR offset.  A padding
-    // tap gets an offset outside the descriptor and loads zeros: no per-k-tile address arithmetic, no select on the loaded values.
-    int64_t mf = m0 < M ? m0 : M - 1;
-    const int hw_ = g.Ho * g.Wo;
-    const int bf = (int)(mf / hw_), remf = (int)(mf - (int64_t)bf * hw_);
-    const int hof = remf / g.Wo, wof = remf - hof * g.Wo;
-    int64_t base_pix = ((int64_t)bf * g.H + (hof * g.stride - 1)) * g.W + (wof * g.stride - 1);      // top-left tap of the tile's first row
-    base_pix = base_pix > 0 ? base_pix : 0;
-    const int64_t left = ((int64_t)(M / hw_) * g.H * g.W - base_pix) * g.Cin * 4;                     // bytes up to the end of the input
-    const auto xr = uniform_rsrc(x + base_pix * g.Cin, left);
-    unsigned voff[NA];                            // byte offset of the current tap's pixel of each staged row (0xFFFFFFFF: padding)
-    auto load_a = [&]() {
-        if (ci0 == 0) {                           // new tap (uniform branch, once per Cin / BK k-tiles)
-#pragma unroll
-            for (int j = 0; j < NA; ++j) {
-                const int hi = (hw0[j] >> 16) - 1 + kh, wi = (hw0[j] & 0xFFFF) - 1 + kw;
-                const bool ok = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-                voff[j] = ok ? (unsigned)(((int64_t)pbase[j] + kh * g.W + kw - base_pix) * g.Cin + c4) * 4u : 0xFFFFFFFFu;
-            }
-        }
-        const unsigned soff = (unsigned)ci0 * 4u;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            // (bit_cast of the whole vector: indexing the builtin's result through `auto` gave element 0 four times with hipcc 7.2)
-            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[j], soff, 0));
-        }
-        ci0 += BK;
-        if (ci0 == g.Cin) { ci0 = 0; if (++kw == 3) { kw = 0; ++kh; } }
-    };
-    const int nk = D / BK;
-    load_a();
-    load_tile<true, BN, BK>(Wt, N, D, n0, 0, rb);
-    store_tile<BM, BK>(As, ra);
-    store_tile<BN, BK>(Bs, rb);
-    __syncthreads();
-
-    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
-    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            load_a();
-            load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
-        }
-        mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
-        __syncthreads();
-        if (more) {
-            store_tile<BM, BK>(As, ra);
-            store_tile<BN, BK>(Bs, rb);
-            __syncthreads();
-        }
-    }
-
-}
 
 // one output tile: main loop + bias / residual / ReLU epilogue
 template <int TM, int TN, int BK>
@@ -130,88 +26,6 @@ __device__ __forceinline__ void conv3x3_tile(float* __restrict__ lds, const floa
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm_u = __builtin_amdgcn_readfirstlane(wave >> 1), wn_u = __builtin_amdgcn_readfirstlane(wave & 1);
     conv_epilogue_buffers<TM, TN>(acc, C, res, bias, relu, m0, M, n0, N, N, 64 * TM, wm_u * (32 * TM), wn_u * (32 * TN), lane & 31, lane >> 5);
-}
-
-// ---- 3x3 convolution to 64 channels + the 1x1 expansion behind it, as ONE kernel ------------------------------
-//   y = act3( W3 . relu(conv3x3(x, W2) + b2) + b3 (+ residual) )        (conv2 + conv3 of a torchvision Bottleneck with 64 mid channels)
-// A 64-pixel tile of the 3x3 convolution holds ALL 64 mid channels of its pixels = a complete A tile of the 1x1 expansion: the wave
-// accumulators get bias + ReLU, go to the LDS (K-major, in place of the operand stages) and feed a second MFMA loop against W3 (given
-// TRANSPOSED, (64, Cout): the B operands are coalesced buffer loads that hit the L2, offsets as SGPRs).  The mid activation (0.8 GB at
-// 56x56, B = 1024) is neither written nor read back, and the HBM-bound expansion (7.4 GB for 105 GFLOP) runs inside an MFMA-bound kernel.
-// Same arithmetic per element as isx_conv3x3_nhwc followed by isx_conv1x1_nhwc: the mid values are the fp32 numbers that path stores.
-// DUAL: the first block of the stage, whose shortcut is a 1x1 projection of the block input x2 (64 channels, same pixels: stride 1):
-//   y = act( [W3 | Wd] . [relu(conv3x3(x, W2) + b2) ; x2] + b ),  W3t = the concatenated weight transposed, (128, Cout);
-// the x2 rows of the tile are fetched at kernel start, wait in registers during the 3x3 loop and go to a second LDS tile.
-template <int TN2, bool DUAL>
-__global__ __launch_bounds__(256, 4) void conv3x3_expand_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ W2, Conv3x3Geom g,
-                                                                const float* __restrict__ b2, const float* __restrict__ W3t, const float* __restrict__ b3,
-                                                                const float* __restrict__ res, int relu, float* __restrict__ y) {
-    constexpr int COUT = 64 * TN2, LDY = 64 + 1, TILE_F = 32 * (64 + 64 + 2 * lds_pad(32));
-    __shared__ float lds[(DUAL ? 2 : 1) * TILE_F];                          // 4160 floats: the 3x3 operand stages, then the 64 x 65 mid tile (+ the x2 tile)
-    static_assert(TILE_F >= 64 * LDY, "mid tile must fit the operand stages");
-    // XCD-aware order: XCD x gets a contiguous range of pixel tiles (neighbouring tiles share their halo rows in its L2)
-    const int nwg = (int)gridDim.x, b = (int)blockIdx.x;
-    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    const int64_t m0 = (int64_t)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3)) * 64;
-
-    float4 x2r[4];
-    if (DUAL) {                                                             // rows m0 .. m0 + 63 of x2 (= res): 16 chunks of 16 B each; rows past M read zeros
-        const int64_t left = M - m0;
-        const auto xr2 = uniform_rsrc(res + m0 * 64, (left < 64 ? left : 64) * 256);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x2r[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr2, (unsigned)((j * 256 + (int)threadIdx.x) * 16), 0, 0));
-    }
-    f32x16 acc[1][1];
-    conv3x3_mainloop<1, 1, 32>(lds, x, M, W2, 64, g, m0, 0, acc);
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
-    if (DUAL) {                                                             // x2 tile -> second LDS tile, K-major X[k][pixel]
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int idx = j * 256 + (int)threadIdx.x, row = idx >> 4, k = (idx & 15) << 2;
-            float* d = lds + TILE_F + k * LDY + row;
-            d[0] = x2r[j].x; d[LDY] = x2r[j].y; d[2 * LDY] = x2r[j].z; d[3 * LDY] = x2r[j].w;
-        }
-    }
-    {   // mid tile -> LDS, K-major: Y[k = mid channel][pixel]; lanes of a half-wave write consecutive k (stride 65: conflict-free)
-        const float bv = b2[wn * 32 + l31];
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-            lds[(wn * 32 + l31) * LDY + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half] = fmaxf(acc[0][0][e] + bv, 0.0f);
-    }
-    __syncthreads();
-
-    // expansion: wave w = all 64 pixels x output channels 16 TN2 w .. (TN2 / 2 column blocks): per k-step (mid channels 2s, 2s + 1) two A reads
-    // from the LDS, TN2 / 2 coalesced B loads from the L2 and TN2 MFMAs; the four waves read disjoint quarters of W3
-    constexpr int NJ = TN2 / 2;
-    f32x16 acc2[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.0f;
-    const float* a_base = lds + half * LDY + l31;
-    const auto wr = uniform_rsrc(W3t, (int64_t)(DUAL ? 128 : 64) * COUT * 4);
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const unsigned wvo = (unsigned)((half * COUT + l31) * 4);
-    const unsigned wso = (unsigned)(wave_u * 32 * NJ * 4);
-#pragma unroll
-    for (int s = 0; s < (DUAL ? 64 : 32); ++s) {
-        const int ao = s < 32 ? 2 * s * LDY : TILE_F + 2 * (s - 32) * LDY;      // mid channels, then the x2 channels
-        const float a0 = a_base[ao], a1 = a_base[ao + 32];
-        float bq[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            bq[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, wvo, wso + (unsigned)((2 * s * COUT + 32 * j) * 4), 0));
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            acc2[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[j], acc2[0][j], 0, 0, 0);
-            acc2[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[j], acc2[1][j], 0, 0, 0);
-        }
-    }
-    conv_epilogue_buffers<2, NJ>(acc2, y, DUAL ? nullptr : res, b3, relu, m0, M, 0, COUT, COUT, 64, 0, wave_u * (32 * NJ), l31, half);
 }
 
 template <int TM, int TN, int BK>
@@ -459,52 +273,6 @@ ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, c
         default: launch_conv3x3<1, 1, 32>(x, M, w_ohwi, N, g, y, bias, residual, relu ? 1 : 0, st); break;
     }
     ISX_CHECK_LAUNCH("isx_conv3x3_nhwc");
-    return ISX_OK;
-}
-
-// 3x3 convolution (padding 1, stride 1 or 2) to 64 channels + ReLU, then the 1x1 expansion to 256 channels + bias (+ residual) (+ ReLU), one kernel
-// (see conv3x3_expand_kernel).  w2_ohwi: (64,3,3,Cin); w3t: (64, 256) = the expansion weight TRANSPOSED; y / residual: (B,Ho,Wo,256).
-ISX_API int isx_conv3x3_expand_nhwc(const float* x, int64_t B, int H, int W, int Cin, const float* w2_ohwi, const float* b2, int stride,
-                                    const float* w3t, int Cout, const float* b3, const float* residual, int relu, float* y, isx_stream_t stream) {
-    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && (stride == 1 || stride == 2),
-                "isx_conv3x3_expand_nhwc: bad shape B=%lld H=%d W=%d Cin=%d stride=%d", (long long)B, H, W, Cin, stride);
-    ISX_REQUIRE(Cin % 32 == 0, "isx_conv3x3_expand_nhwc: Cin=%d must be a multiple of 32", Cin);
-    ISX_REQUIRE(Cout == 256, "isx_conv3x3_expand_nhwc: Cout=%d (this kernel is built for 64 mid channels -> 256)", Cout);
-    ISX_REQUIRE(H < 32767 && W < 32767 && B * H * W < (1ll << 31), "isx_conv3x3_expand_nhwc: input has too many pixels for 32-bit pixel indices");
-    if (B == 0) return ISX_OK;
-    ISX_REQUIRE(x && w2_ohwi && b2 && w3t && b3 && y, "isx_conv3x3_expand_nhwc: null pointer");
-    ISX_REQUIRE((((uintptr_t)x | (uintptr_t)w2_ohwi | (uintptr_t)w3t) % 16) == 0, "isx_conv3x3_expand_nhwc: x, w2 and w3t must be 16-B aligned");
-    ISX_REQUIRE(y != x && y != residual, "isx_conv3x3_expand_nhwc: y must not alias x or residual");
-    Conv3x3Geom g;
-    g.H = H; g.W = W; g.Cin = Cin; g.stride = stride;
-    g.Ho = (H - 1) / stride + 1;
-    g.Wo = (W - 1) / stride + 1;
-    const int64_t M = B * g.Ho * g.Wo;
-    ISX_REQUIRE((M + 63) / 64 < (1ll << 31), "isx_conv3x3_expand_nhwc: too many tiles");
-    hipLaunchKernelGGL((conv3x3_expand_kernel<4, false>), dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, M, w2_ohwi, g, b2, w3t, b3, residual,
-                       relu ? 1 : 0, y);
-    ISX_CHECK_LAUNCH("isx_conv3x3_expand_nhwc");
-    return ISX_OK;
-}
-
-// The same with a 1x1 PROJECTION shortcut of the 64-channel block input x2 (first block of the stage; stride 1 only):
-//   y = act( [W3 | Wd] . [relu(conv3x3(t, W2) + b2) ; x2] + bias ).  wcat_t: (128, 256) = [W3 | Wd] transposed; x2: (B,H,W,64).
-ISX_API int isx_conv3x3_expand_dual_nhwc(const float* t, int64_t B, int H, int W, int Cin, const float* w2_ohwi, const float* b2, const float* x2,
-                                         const float* wcat_t, int Cout, const float* bias, int relu, float* y, isx_stream_t stream) {
-    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0, "isx_conv3x3_expand_dual_nhwc: bad shape B=%lld H=%d W=%d Cin=%d", (long long)B, H, W, Cin);
-    ISX_REQUIRE(Cin % 32 == 0, "isx_conv3x3_expand_dual_nhwc: Cin=%d must be a multiple of 32", Cin);
-    ISX_REQUIRE(Cout == 256, "isx_conv3x3_expand_dual_nhwc: Cout=%d (this kernel is built for 64 mid channels -> 256)", Cout);
-    ISX_REQUIRE(H < 32767 && W < 32767 && B * H * W < (1ll << 31), "isx_conv3x3_expand_dual_nhwc: input has too many pixels for 32-bit pixel indices");
-    if (B == 0) return ISX_OK;
-    ISX_REQUIRE(t && w2_ohwi && b2 && x2 && wcat_t && bias && y, "isx_conv3x3_expand_dual_nhwc: null pointer");
-    ISX_REQUIRE((((uintptr_t)t | (uintptr_t)w2_ohwi | (uintptr_t)wcat_t | (uintptr_t)x2) % 16) == 0, "isx_conv3x3_expand_dual_nhwc: t, x2, w2 and wcat_t must be 16-B aligned");
-    ISX_REQUIRE(y != t && y != x2, "isx_conv3x3_expand_dual_nhwc: y must not alias an input");
-    Conv3x3Geom g;
-    g.H = H; g.W = W; g.Cin = Cin; g.stride = 1; g.Ho = H; g.Wo = W;
-    const int64_t M = B * H * W;
-    hipLaunchKernelGGL((conv3x3_expand_kernel<4, true>), dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, t, M, w2_ohwi, g, b2, wcat_t, bias, x2,
-                       relu ? 1 : 0, y);
-    ISX_CHECK_LAUNCH("isx_conv3x3_expand_dual_nhwc");
     return ISX_OK;
 }
 

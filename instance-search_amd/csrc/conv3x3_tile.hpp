@@ -1,0 +1,111 @@
+// conv3x3_tile.hpp -- the implicit-GEMM main loop of the 3x3 convolution (shared by conv.hip and expand.hip).
+#pragma once
+#include "gemm_tile.hpp"
+
+namespace isx {
+
+// ---- 3x3 convolution (padding 1, stride 1 or 2) on NHWC activations as an IMPLICIT GEMM ----------------------
+// Same tile machinery as cosine_gemm_kernel: M = B*Ho*Wo output pixels, N = Cout, K = 9*Cin ordered (kh, kw, ci),
+// weights pre-arranged (Cout, 3, 3, Cin).  A k-tile lies inside one filter tap (Cin % BK == 0), so the A rows of a
+// k-tile are the input pixels shifted by that tap: one base pixel per staged row, kept in registers, plus a
+// bounds test per tap (padding rows load zeros -- fma(0, w, acc) leaves acc unchanged, as skipping the tap would).
+// Epilogue: bias (+ residual) + ReLU fused, wave-uniform row pointers.  Replaces conv2 of the torchvision
+// Bottleneck / both convolutions of BasicBlock inside the `features` trunk.
+struct Conv3x3Geom { int H, W, Cin, Ho, Wo, stride; };
+
+// accumulators of one (64 TM) x (64 TN) output tile at rows m0.., columns n0.. (every wave has left the LDS when this returns);
+// lds: BK * (64 TM + 64 TN + 2 pads) floats
+template <int TM, int TN, int BK>
+__device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
+                                                 const Conv3x3Geom& g, int64_t m0, int64_t n0, f32x16 (&acc)[TM][TN]) {
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
+    constexpr int CH = BK / 4, NA = BM * CH / 256;
+    float* As = lds;
+    float* Bs = lds + BK * LDA;
+    const int D = 9 * g.Cin;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    // staged A rows of this thread: top-left input pixel of the 3x3 window (may be -1: padding)
+    int pbase[NA], hw0[NA];                       // pixel index of (hi0, wi0); (hi0 + 1) << 16 | (wi0 + 1)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int idx = j * 256 + threadIdx.x;
+        int64_t m = m0 + idx / CH;
+        m = m < M ? m : M - 1;
+        const int hw = g.Ho * g.Wo;
+        const int b = (int)(m / hw), rem = (int)(m - (int64_t)b * hw);
+        const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+        const int hi0 = ho * g.stride - 1, wi0 = wo * g.stride - 1;
+        pbase[j] = (b * g.H + hi0) * g.W + wi0;
+        hw0[j] = ((hi0 + 1) << 16) | (wi0 + 1);
+    }
+    const int c4 = (threadIdx.x % CH) << 2;
+    int kh = 0, kw = 0, ci0 = 0;                  // tap / channel offset of the NEXT k-tile to load (uniform)
+    float4 ra[NA], rb[BN * BK / 1024];
+    // A rows come through BUFFER loads: a wave-uniform descriptor that starts at the first input pixel this tile can touch, one 32-bit
+    // byte offset per staged row (recomputed once per filter tap), the channel offset inside the tap as the SGPR offset.  A padding
+    // tap gets an offset outside the descriptor and loads zeros: no per-k-tile address arithmetic, no select on the loaded values.
+    int64_t mf = m0 < M ? m0 : M - 1;
+    const int hw_ = g.Ho * g.Wo;
+    const int bf = (int)(mf / hw_), remf = (int)(mf - (int64_t)bf * hw_);
+    const int hof = remf / g.Wo, wof = remf - hof * g.Wo;
+    int64_t base_pix = ((int64_t)bf * g.H + (hof * g.stride - 1)) * g.W + (wof * g.stride - 1);      // top-left tap of the tile's first row
+    base_pix = base_pix > 0 ? base_pix : 0;
+    const int64_t left = ((int64_t)(M / hw_) * g.H * g.W - base_pix) * g.Cin * 4;                     // bytes up to the end of the input
+    const auto xr = uniform_rsrc(x + base_pix * g.Cin, left);
+    unsigned voff[NA];                            // byte offset of the current tap's pixel of each staged row (0xFFFFFFFF: padding)
+    auto load_a = [&]() {
+        if (ci0 == 0) {                           // new tap (uniform branch, once per Cin / BK k-tiles)
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const int hi = (hw0[j] >> 16) - 1 + kh, wi = (hw0[j] & 0xFFFF) - 1 + kw;
+                const bool ok = (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+                voff[j] = ok ? (unsigned)(((int64_t)pbase[j] + kh * g.W + kw - base_pix) * g.Cin + c4) * 4u : 0xFFFFFFFFu;
+            }
+        }
+        const unsigned soff = (unsigned)ci0 * 4u;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            // (bit_cast of the whole vector: indexing the builtin's result through `auto` gave element 0 four times with hipcc 7.2)
+            ra[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, voff[j], soff, 0));
+        }
+        ci0 += BK;
+        if (ci0 == g.Cin) { ci0 = 0; if (++kw == 3) { kw = 0; ++kh; } }
+    };
+    const int nk = D / BK;
+    load_a();
+    load_tile<true, BN, BK>(Wt, N, D, n0, 0, rb);
+    store_tile<BM, BK>(As, ra);
+    store_tile<BN, BK>(Bs, rb);
+    __syncthreads();
+
+    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
+    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_a();
+            load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
+        }
+        mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+        __syncthreads();
+        if (more) {
+            store_tile<BM, BK>(As, ra);
+            store_tile<BN, BK>(Bs, rb);
+            __syncthreads();
+        }
+    }
+
+}
+
+}  // namespace isx
