@@ -5,8 +5,8 @@
 //   isx_conv3x3_nhwc        implicit GEMM below (conv3x3_nhwc_kernel)
 //   isx_conv1x1_dual_nhwc   last 1x1 convolution of a bottleneck block + its projection shortcut as ONE GEMM over the
 //                           concatenated K = [t ; x_strided] (conv1x1_dual_nhwc_kernel)
-//   isx_conv3x3_expand_nhwc / isx_conv3x3_expand_dual_nhwc   conv2 + conv3 (+ projection) of the 64-channel bottlenecks as ONE kernel
-//                           (conv3x3_expand_kernel: the mid activation never leaves the chip)
+//   (expand.hip: isx_conv3x3_expand_nhwc / isx_conv3x3_expand_dual_nhwc, conv2 + conv3 (+ projection) of the 64-channel bottlenecks as ONE kernel,
+//    on the main loop of conv3x3_tile.hpp)
 // Launches in 128x128 tiles run the rows past their last whole round of resident workgroups as 64x64 tiles in the same grid
 // (conv3x3_tail_kernel, conv1x1_dual_tail_kernel; conv1x1_tail_kernel in cosine.hip); isx_debug_set_conv_cfg(7) turns that off (A/B).
 //
