@@ -1,4 +1,6 @@
 """Shared pieces of the four per-approach modules: batch staging and net construction."""
+import os
+
 import torch
 
 from isx import backbones
@@ -93,6 +95,24 @@ def stage_batch(batch, trans, device):
     if trans is None:
         return stage_images([im for im, _, _ in batch], device)
     return stage_images([trans(im) for im, _, _ in batch], device)
+
+
+# Images per trunk launch on the GPU.  The reference's test batch size (64, train/global_p.py) sizes a 12 GB card; in eval mode the
+# descriptor of an image does not depend on the batch it rides in, so on an MI355X (288 GB) the get_embeddings functions raise the batch
+# to a multiple of the caller's size holding at least this many pixels -- 512 images of 224 x 224 -- which is where the convolution
+# launches fill the chip (bench.py: 14.8 k images/s at 256 images per launch, 15.6 k at 512).  0 = the caller's size as given.
+_MIN_DEVICE_BATCH_PIXELS = int(os.environ.get("ISX_MIN_DEVICE_BATCH_PIXELS", str(512 * 224 * 224)))
+
+
+def device_batch_size(P, dataset):
+    bs = int(P.test_batch_size)
+    if bs <= 0 or P.cuda_device < 0 or _MIN_DEVICE_BATCH_PIXELS <= 0 or len(dataset) == 0 or not torch.cuda.is_available():
+        return bs
+    shape = tuple(dataset[0][0].shape)
+    if len(shape) != 3:
+        return bs
+    pixels = shape[1] * shape[2] if shape[0] in (1, 3) else shape[0] * shape[1]          # (C,H,W) tensors or raw (H,W,3) uint8 images
+    return bs * max(1, -(-_MIN_DEVICE_BATCH_PIXELS // max(bs * pixels, 1)))
 
 
 def fold_shape_buckets(f, dataset, batch_size):

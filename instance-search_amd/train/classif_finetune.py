@@ -7,7 +7,7 @@ import torch.nn as nn
 from model.custom_modules import l2_normalize_rows
 from model.siamese import TuneClassif
 from utils import fold_batches, move_device, tensor
-from ._common import base_model, load_weights, make_resident, stage_batch, test_transform
+from ._common import base_model, device_batch_size, load_weights, make_resident, stage_batch, test_transform
 from .classif_finetune_p import P
 
 labels = []   # filled by the entry point once the reference set is listed, then constant
@@ -68,7 +68,7 @@ def get_embeddings(net, dataset, device, out_size):
         return slab
 
     try:
-        return fold_batches(run, slab, dataset, P.test_batch_size)
+        return fold_batches(run, slab, dataset, device_batch_size(P, dataset))
     finally:
         if stripped:
             net.classifier = classifier

@@ -6,7 +6,7 @@ import torch
 from model.custom_modules import l2_normalize_rows
 from model.siamese import TuneClassif, TuneClassifSub
 from utils import fold_batches, move_device, tensor
-from ._common import base_model, fold_shape_buckets, load_weights, make_resident, scatter_rows, stage_batch, test_transform
+from ._common import base_model, device_batch_size, fold_shape_buckets, load_weights, make_resident, scatter_rows, stage_batch, test_transform
 from .classif_regions_p import P
 
 labels = []
@@ -57,7 +57,7 @@ def get_embeddings(net, dataset, device, out_size):
 
     # the reference walks one image at a time (images may differ in size); here images are bucketed by shape and every
     # bucket goes through in batches of P.test_batch_size
-    fold_shape_buckets(run, dataset, P.test_batch_size)
+    fold_shape_buckets(run, dataset, device_batch_size(P, dataset))
     return slab
 
 

@@ -13,7 +13,7 @@ from model.siamese import DescriptorNet, TuneClassif
 from model.custom_modules import TripletLoss
 from utils import (choose_rand_neg, embeddings_device_dim, fold_batches, get_pos_couples, get_similarities, log, move_device,
                    tensor, test_print_descriptor, train_gen)
-from ._common import base_model, load_weights, make_resident, stage_batch, stage_images, test_transform
+from ._common import base_model, device_batch_size, load_weights, make_resident, stage_batch, stage_images, test_transform
 from .siamese_descriptor_p import P
 
 labels = []
@@ -30,7 +30,7 @@ def get_embeddings(net, dataset, device, out_size):
             slab[i:i + len(batch)].copy_(net(stage_batch(batch, trans, P.cuda_device)))
         return slab
 
-    return fold_batches(run, slab, dataset, P.test_batch_size)
+    return fold_batches(run, slab, dataset, device_batch_size(P, dataset))
 
 
 def get_siamese_net():

@@ -10,7 +10,7 @@ from model.siamese import RegionDescriptorNet, TuneClassifSub
 from model.custom_modules import TripletLoss
 from utils import (choose_rand_neg, fold_batches, get_pos_couples, get_similarities, log, move_device, tensor,
                    test_print_descriptor, train_gen)
-from ._common import base_model, fold_shape_buckets, load_weights, make_resident, scatter_rows, stage_batch, test_transform
+from ._common import base_model, device_batch_size, fold_shape_buckets, load_weights, make_resident, scatter_rows, stage_batch, test_transform
 from .siamese_descriptor import mine_epoch_negatives, shuffle_couples
 from .siamese_regions_p import P
 
@@ -28,7 +28,7 @@ def get_embeddings(net, dataset, device, out_size):
             scatter_rows(slab, indices, net(stage_batch(batch, trans, P.cuda_device)))
 
     # one image per step in the reference; images bucketed by shape share a backbone pass here
-    fold_shape_buckets(run, dataset, P.test_batch_size)
+    fold_shape_buckets(run, dataset, device_batch_size(P, dataset))
     return slab
 
 

@@ -37,7 +37,9 @@ def test_modules_gpu_vs_oracle():
     assert xr.grad is not None and torch.isfinite(xr.grad).all()
 
 
-def test_global_descriptor_path_kernel_boundary():
+def test_global_descriptor_path_kernel_boundary(monkeypatch):
+    from train import _common as TC
+    monkeypatch.setattr(TC, "_MIN_DEVICE_BATCH_PIXELS", 0)      # the caller's batch size as given (device batching has a test of its own)
     from isx import backbones
     from model.nn_utils import set_net_train
     from model.siamese import TuneClassif
@@ -129,6 +131,43 @@ def test_entry_point_on_gpu_matches_oracle(capsys, monkeypatch):
     assert O.mean_avg_precision(ap) == mAP                          # ranks + AP bit-exact given the same descriptors
     ts, ti = O.topk_rows(sim, 1)
     assert O.precision1(ti, ql, gl)[0] == p1
+
+
+def test_get_embeddings_is_independent_of_the_batch_size(monkeypatch):
+    """train/_common.device_batch_size raises the images per trunk launch on the GPU (the reference's batch of 64 sizes a 12 GB card): the
+    descriptor of an image must not depend on the batch it rides in -- the slab is bit-identical for test_batch_size 3, 16 and 64, with
+    and without the device batching, and the launches really get bigger."""
+    from isx import backbones
+    from model.nn_utils import fold_batch_norm
+    from model.siamese import TuneClassif
+    from train import _common as TC
+    from train import classif_finetune as cf
+    from utils.dataset import synthetic_images
+    torch.manual_seed(0)
+    net = TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5).eval()
+    net.features = fold_batch_norm(net.features)
+    net = net.cuda().to(memory_format=torch.channels_last)
+    imgs = synthetic_images(70, seed=3)
+    data = [(imgs[i], "l%d" % (i % 5), "p%d" % i) for i in range(70)]
+    P = cf.P
+    old = (P.test_batch_size, P.cuda_device, P.embeddings_classify, P.test_pre_proc)
+    sizes = []
+    real = cf.fold_batches
+    monkeypatch.setattr(cf, "fold_batches", lambda f, init, ds, bs: (sizes.append(bs), real(f, init, ds, bs))[1])
+    try:
+        P.cuda_device, P.embeddings_classify, P.test_pre_proc = 0, False, True
+        slabs = {}
+        for pixels, bs in ((0, 3), (0, 64), (512 * 224 * 224, 3), (512 * 224 * 224, 16), (512 * 224 * 224, 64)):
+            monkeypatch.setattr(TC, "_MIN_DEVICE_BATCH_PIXELS", pixels)
+            P.test_batch_size = bs
+            slabs[(pixels, bs)] = cf.get_embeddings(net, list(data), 0, 2048).clone()
+    finally:
+        P.test_batch_size, P.cuda_device, P.embeddings_classify, P.test_pre_proc = old
+    assert sizes == [3, 64, 513, 512, 512]
+    first = slabs[(0, 3)]
+    assert first.is_cuda and first.shape == (70, 2048)
+    for k, v in slabs.items():
+        assert torch.equal(v, first), k
 
 
 def test_bias_act_and_folded_trunk():
