@@ -35,14 +35,49 @@ RESIDENT_BUDGET_BYTES = 48 << 30
 _RESIDENT = []
 
 
+_STACK_POOL = None
+
+
+def _parallel_stack(chunk, out):
+    """out[:len(chunk)] = stack(chunk): the copy is one memcpy per image, spread over a few threads (torch releases the GIL inside)."""
+    global _STACK_POOL
+    k = len(chunk)
+    workers = min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    if workers <= 1 or k < 64:
+        torch.stack(chunk, 0, out=out[:k])
+        return
+    if _STACK_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _STACK_POOL = ThreadPoolExecutor(max_workers=workers)
+    step = -(-k // workers)
+    futs = [_STACK_POOL.submit(torch.stack, chunk[j:j + step], 0, out=out[j:min(j + step, k)]) for j in range(0, k, step)]
+    for f in futs:
+        f.result()
+
+
 class ResidentImages(object):
     def __init__(self, images, device):
         self.images = list(images)                  # strong references: the ids below stay valid
         self.index = dict((id(im), i) for i, im in enumerate(self.images))
         first = self.images[0]
-        self.data = torch.empty((len(self.images),) + tuple(first.shape), dtype=first.dtype, device=torch.device('cuda', device))
-        for i in range(0, len(self.images), 256):
-            self.data[i:i + 256].copy_(torch.stack(self.images[i:i + 256], 0), non_blocking=False)
+        dev = torch.device('cuda', device)
+        self.data = torch.empty((len(self.images),) + tuple(first.shape), dtype=first.dtype, device=dev)
+        # chunks of 256 images are stacked straight into one of two reusable PINNED buffers (a fresh pageable 150 MB tensor per chunk cost
+        # 0.19 s in page faults: 5.8 of the 9.4 s of a 4400-image test run) and copied asynchronously; an event per buffer guards its reuse
+        n = min(256, len(self.images))
+        with torch.cuda.device(dev):
+            stage = [torch.empty((n,) + tuple(first.shape), dtype=first.dtype).pin_memory() for _ in range(2 if len(self.images) > n else 1)]
+            done = [None, None]
+            for c, i in enumerate(range(0, len(self.images), n)):
+                b = c & 1 if len(stage) == 2 else 0
+                if done[b] is not None:
+                    done[b].synchronize()
+                chunk = self.images[i:i + n]
+                _parallel_stack(chunk, stage[b])
+                self.data[i:i + len(chunk)].copy_(stage[b][:len(chunk)], non_blocking=True)
+                done[b] = torch.cuda.Event()
+                done[b].record(torch.cuda.current_stream(dev))
+            torch.cuda.current_stream(dev).synchronize()
 
     def covers(self, ims):
         return all(id(im) in self.index for im in ims)
