@@ -16,6 +16,8 @@ labels = []   # filled by the entry point once the reference set is listed, then
 def test_classif_net(net, test_set):
     """(correct, total) classification accuracy of an eval-mode net."""
     trans = test_transform(P)
+    if trans is None:
+        make_resident(test_set, P.cuda_device)          # get_embeddings needs the set in HBM right after: upload it once, here
 
     def run(acc, i, is_final, batch):
         correct, total = acc
@@ -24,7 +26,7 @@ def test_classif_net(net, test_set):
         correct += sum(1 for (_, lab, _), p in zip(batch, pred) if labels.index(lab) == p)
         return correct, total + len(batch)
 
-    return fold_batches(run, (0, 0), test_set, P.test_batch_size)
+    return fold_batches(run, (0, 0), test_set, device_batch_size(P, test_set))
 
 
 def _full_map_pool(net, fmap):
