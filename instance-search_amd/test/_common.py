@@ -80,9 +80,23 @@ def load_sets(dataset_full, labels, raw=False):
         load = lambda f: to_raw_tensor(imread_rgb(f))
     else:
         load = lambda f: to_normalised_tensor(imread_rgb(f), mean, std)
-    ref = [(load(f), lab, f) for f, lab in ref_files]
-    qry = [(load(f), lab, f) for f, lab in qry_files if lab in labels]
+    ref = [(im, lab, f) for im, (f, lab) in zip(_decode_all(load, [f for f, _ in ref_files]), ref_files)]
+    qry_files = [(f, lab) for f, lab in qry_files if lab in labels]
+    qry = [(im, lab, f) for im, (f, lab) in zip(_decode_all(load, [f for f, _ in qry_files]), qry_files)]
     return qry, ref
+
+
+def _decode_all(load, files):
+    """[load(f) for f in files], file order kept, decoded on a pool of threads (PIL's decoders release the GIL): the reference reads its
+    folders one image at a time (test/classif_finetune_test.py:62-73), which is what a GPU test run then waits for.  ISX_DECODE_THREADS=1
+    restores the sequential read."""
+    import os
+    workers = int(os.environ.get("ISX_DECODE_THREADS", "0")) or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+    if workers <= 1 or len(files) < 2 * workers:
+        return [load(f) for f in files]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        return list(pool.map(load, files))
 
 
 def evaluate_retrieval(test_embeddings, ref_embeddings, test_set, ref_set, device, labels, dba):

@@ -453,3 +453,25 @@ def test_blocked_metrics_equal_the_one_matrix_evaluation(golden):
             assert torch.equal(a, b)
     finally:
         M.SIM_BUDGET_BYTES = old
+
+
+def test_folder_decode_on_threads_keeps_file_order(tmp_path, monkeypatch):
+    """test/_common._decode_all: the folder images of a test run are decoded on a pool of threads; same tensors, same order as the
+    sequential read (ISX_DECODE_THREADS=1)."""
+    from PIL import Image
+    from test import _common as C
+    rng = np.random.default_rng(5)
+    files = []
+    for i in range(24):
+        f = str(tmp_path / ("img_%02d.png" % i))
+        Image.fromarray(rng.integers(0, 255, (9 + i % 3, 11, 3), dtype=np.uint8)).save(f)
+        files.append(f)
+    load = lambda f: C.to_raw_tensor(C.imread_rgb(f))
+    monkeypatch.setenv("ISX_DECODE_THREADS", "1")
+    seq = C._decode_all(load, files)
+    monkeypatch.setenv("ISX_DECODE_THREADS", "4")
+    par = C._decode_all(load, files)
+    assert len(seq) == len(par) == 24
+    for a, b in zip(seq, par):
+        assert a.dtype == torch.uint8 and a.shape == b.shape and torch.equal(a, b)
+
