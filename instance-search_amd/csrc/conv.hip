@@ -263,8 +263,11 @@ ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, c
     ISX_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), "isx_conv3x3_nhwc: too many tiles");
     // measured on the ResNet-50 shapes at B = 1024 (ms, 128x128 / 128x64 / 64x64): 64->64 @56 3.70 / 2.10 / 2.04,
     // 128->128 @28 1.89 / 1.98 / 1.97, 256->256 @14 1.93 / 1.98 / 1.91, 512->512 @7 2.08 / 2.04 / 1.94
-    // 128x128 tiles (+ 64x64 tail) once they fill at least one round of the chip, 64x64 below that and for Cout = 64
-    int best = (N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) >= 1024) ? 0 : 3;
+    // the round / tail model of the GEMMs with this kernel's efficiencies (B = 1024, ms for 128x128 / 128x64 / 64x64: 128->128 at 28x28
+    // 1.71 / 1.78 / 1.76; 64->64 at 56x56 - / 1.89 / 1.85): 128x128 (+ 64x64 tail) wherever the grid fills the chip, the shape with the
+    // fewest idle CUs below that (512->512 at 14x14 with 64 images: 1568 tiles of 64x64 are 1.02 rounds, 784 of 128x64 are 0.77)
+    static const float eff3x3[4] = {0.90f, 0.0f, 0.865f, 0.87f};
+    int best = pick_tile_cfg(M, N, gemm_tail_split_rows(M, N), eff3x3, 0xD);
     if (g_force_conv_cfg == 0 || g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
     hipStream_t st = (hipStream_t)stream;
     switch (best) {
@@ -296,7 +299,8 @@ ISX_API int isx_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_
     ISX_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), "isx_conv1x1_dual_nhwc: too many tiles");
     // measured at B = 1024 (ms, 128x128 / 128x64 / 64x64): layer 1 2.10 / 2.22 / 2.21, layer 2 2.64 / 2.68 / 2.84,
     // layer 3 2.54 / 2.54 / 2.75, layer 4 (50 k pixels) 2.55 / 2.48 / 2.72
-    int best = (N >= 128 && ((M + 127) / 128) * ((N + 127) / 128) >= 1024) ? 0 : 2;      // 128x128 (+ 64x64 tail) from one full round on
+    static const float eff_dual[4] = {0.92f, 0.0f, 0.885f, 0.85f};                         // layer 1-4 at B = 1024: 128x128 best, then 128x64, then 64x64
+    int best = pick_tile_cfg(M, N, gemm_tail_split_rows(M, N), eff_dual, 0xD);
     if (g_force_conv_cfg == 0 || g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
     hipStream_t st = (hipStream_t)stream;
     if (best == 0) launch_dual<2, 2, 16>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);

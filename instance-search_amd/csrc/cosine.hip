@@ -221,6 +221,33 @@ int64_t gemm_tail_split_rows(int64_t M, int64_t N) {
 // problems get 128x128, mid-size ones (bench: 512 x 10k) avoid a half-empty last round.
 struct TileCfg { int tm, tn, wg_per_cu; float eff; };
 static const TileCfg kCfgs[] = { {2, 2, 4, 0.92f}, {1, 2, 4, 0.87f}, {2, 1, 4, 0.89f}, {1, 1, 6, 0.84f} };     // 10 000 x 32 768 x 2048: 145 / 137 / 140 / 132 TFLOP/s
+// The tile shape (index into kCfgs: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64) with the smallest estimated time among those in
+// `mask`; eff[c]: steady-state efficiency of shape c for the calling kernel family; split > 0: shape 0 runs with a 64x64 tail.
+int pick_tile_cfg(int64_t M, int64_t N, int64_t split, const float* eff, unsigned mask) {
+    int best = -1;
+    double best_t = 1e300;
+    for (int c = 0; c < 4; ++c) {
+        if (!((mask >> c) & 1u)) continue;
+        const TileCfg& k = kCfgs[c];
+        const double tiles = (double)((M + 64 * k.tm - 1) / (64 * k.tm)) * (double)((N + 64 * k.tn - 1) / (64 * k.tn));
+        const double slots = 256.0 * k.wg_per_cu;
+        // time in units of "one full round" (= wg_per_cu tiles on every CU).  Workgroups finish unevenly,
+        // so a launch costs its tile count plus a tail that is ~0.2 round for launches below one round and
+        // fades quadratically for longer ones (fitted on MI355X, 256 ... 10k query rows x 10k ... 100k)
+        const double x = tiles / slots;
+        const double t0 = (c == 0 ? 0.22 : c == 3 ? 0.15 : 0.25);
+        double rounds = x + (x <= 0.7 ? t0 : t0 * (0.7 / x) * (0.7 / x));
+        // a CU works its tiles off at the rate of its matrix pipe however many of them are resident: the launch cannot end before the
+        // CU with one tile more than the average is done (50 176 x 512 x 2048: 1568 tiles of 128x128 = 6.1 per CU took 7 tile times)
+        const double per_cu = (double)((int64_t)((tiles + 255.0) / 256.0)) / k.wg_per_cu;
+        rounds = rounds > per_cu ? rounds : per_cu;
+        if (c == 0 && split > 0) rounds = x + 0.05;                          // the tail runs as small tiles: no round quantisation
+        const double t = rounds * k.wg_per_cu * (k.tm * k.tn) / eff[c];
+        if (t < best_t) { best_t = t; best = c; }
+    }
+    return best;
+}
+
 static int g_force_cfg = -1;            // debug / A-B hook
 void set_gemm_cfg(int c) { g_force_cfg = c; }
 
@@ -251,27 +278,9 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     if (M == 0 || N == 0) return ISX_OK;
     if (((M + 63) / 64) * ((N + 63) / 64) >= (1ll << 31)) { isx_set_error("cosine gemm: too many tiles for one grid"); return ISX_ERR_ARG; }
     const bool aligned = (D % 32 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);     // no k tail for BK = 16 or 32
-    int best = 0;
-    double best_t = 1e300;
     const int64_t split = (epi == 2) ? gemm_tail_split_rows(M, N) : 0;      // convolutions: 128x128 tiles + 64x64 tail in one grid
-    for (int c = 0; c < 4; ++c) {
-        const TileCfg& k = kCfgs[c];
-        const double tiles = (double)((M + 64 * k.tm - 1) / (64 * k.tm)) * (double)((N + 64 * k.tn - 1) / (64 * k.tn));
-        const double slots = 256.0 * k.wg_per_cu;
-        // time in units of "one full round" (= wg_per_cu tiles on every CU).  Workgroups finish unevenly,
-        // so a launch costs its tile count plus a tail that is ~0.2 round for launches below one round and
-        // fades quadratically for longer ones (fitted on MI355X, 256 ... 10k query rows x 10k ... 100k)
-        const double x = tiles / slots;
-        const double t0 = (c == 0 ? 0.22 : c == 3 ? 0.15 : 0.25);
-        double rounds = x + (x <= 0.7 ? t0 : t0 * (0.7 / x) * (0.7 / x));
-        // a CU works its tiles off at the rate of its matrix pipe however many of them are resident: the launch cannot end before the
-        // CU with one tile more than the average is done (50 176 x 512 x 2048: 1568 tiles of 128x128 = 6.1 per CU took 7 tile times)
-        const double per_cu = (double)((int64_t)((tiles + 255.0) / 256.0)) / k.wg_per_cu;
-        rounds = rounds > per_cu ? rounds : per_cu;
-        if (c == 0 && split > 0) rounds = x + 0.05;                          // the tail runs as small tiles: no round quantisation
-        const double t = rounds * k.wg_per_cu * (k.tm * k.tn) / k.eff;
-        if (t < best_t) { best_t = t; best = c; }
-    }
+    static const float eff_gemm[4] = {kCfgs[0].eff, kCfgs[1].eff, kCfgs[2].eff, kCfgs[3].eff};
+    int best = pick_tile_cfg(M, N, split, eff_gemm, 0xF);
     // (Round 1 forced 64x64 tiles on residual layers and 128x64 on the others: the per-element epilogue was a visible share of a tile.
     // With the buffer-instruction epilogue the same round / tail model as for the score GEMM picks the convolution tiles: 128x128
     // wherever the grid fills the chip -- 256->1024 + residual 0.90 -> 0.87 ms, 512->2048 + residual 0.85 -> 0.81, 512->256 1.64 -> 1.58 --
