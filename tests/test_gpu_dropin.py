@@ -170,6 +170,35 @@ def test_get_embeddings_is_independent_of_the_batch_size(monkeypatch):
         assert torch.equal(v, first), k
 
 
+def test_bench_size_step_is_batch_independent():
+    """BASELINE configs[1] at its full size (1024 images of 224 x 224 per launch) through the SAME trunk the bench times: at this size every
+    convolution runs in 128x128 tiles with 64x64 tails, the stage-1 blocks in the fused kernels, the stem in four rounds of workgroups --
+    shapes the oracle cannot reach in seconds.  Size-independent property: a descriptor does not depend on the batch it rides in, so the
+    1024-image launch must reproduce, bit for bit, the descriptors of the same images sent as 16 launches of 64 (64x64 tiles, no tails,
+    row bands in the stem: the paths the oracle tests pin) and as 4 launches of 256."""
+    from isx import backbones, ops
+    from model.nn_utils import fold_batch_norm
+    from model.siamese import TuneClassif
+    torch.manual_seed(0)
+    net = TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5).eval()
+    net.features = fold_batch_norm(net.features)
+    net = net.cuda().to(memory_format=torch.channels_last)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(1024, 3, 224, 224, device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+
+    def descriptors(chunk):
+        out = torch.empty(1024, 2048, device="cuda")
+        with torch.no_grad():
+            for i in range(0, 1024, chunk):
+                ops.gap_l2(net.features(x[i:i + chunk]), out=out[i:i + chunk])
+        return out
+
+    full = descriptors(1024)
+    assert torch.isfinite(full).all() and float((full.norm(dim=1) - 1).abs().max()) < 1e-5
+    for chunk in (64, 256):
+        assert torch.equal(descriptors(chunk), full), chunk
+
+
 def test_bias_act_and_folded_trunk():
     from isx import backbones, ops
     from model.nn_utils import extract_layers, fold_batch_norm
