@@ -19,6 +19,17 @@ rank extracts B images and holds a 10k-row gallery shard.
 Rank 0 prints ONE JSON line (metric / value / roofline / cpu_baseline ...).  The K timed steps carry no
 per-kernel instrumentation; the per-kernel HIP-event timings behind the `roofline*` objects come from a
 separate instrumented pass over the same step.
+
+N > 1: the result exchange of step i (all-gather of the per-shard top-k lists + isx_topk_merge) is issued on a second
+HIP stream and rides behind the trunk of step i + 1 (`--no-overlap-exchange` serialises it again); `exchange_ms` is what
+the query all-gather, the two result all-gathers and the merge cost when nothing hides them (HIP events in the
+instrumented pass), `overlap_identical` says that both schedules returned the same bits.  `cpu_baseline` is timed on
+rank 0 at every N (the other ranks wait at the barrier).
+
+Side objects of the same line (each bounded to a few seconds; a failure in one is reported inside it and never costs the
+headline): `retrieval_shard` = BASELINE configs[4]'s per-GPU shard (10k x 125k x 2048) end to end; `extraction_regions` =
+BASELINE configs[2]: ResNet-50 TuneClassifSub on 448 x 448 images -> best-location class-score descriptors (reference
+train/classif_regions.py:107-132) with its own roofline, plus the 1k x 100k retrieval + metrics leg of that config.
 """
 import argparse
 import json
@@ -55,6 +66,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shard-bench", action="store_true", help="skip the 10k x 125k retrieval-shard side measurement")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the instrumented per-kernel pass (roofline objects of the trunk)")
+    ap.add_argument("--no-regions-bench", action="store_true", help="skip the BASELINE configs[2] side measurement (region path at 448 x 448)")
+    ap.add_argument("--regions-batch", type=int, default=128, help="448 x 448 images per launch of the region path")
+    ap.add_argument("--no-overlap-exchange", action="store_true",
+                    help="N > 1: keep the result exchange of a step on the main stream (default: on a second stream behind the next step's trunk)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -220,9 +235,22 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     gemm_ev, gap_ev = [], []
 
-    def step(timed):
-        """One step.  `timed`: the instrumented pass (HIP events around the pool and the GEMM on torch's current stream, which
-        is the stream every libisx launch goes to)."""
+    overlap = world > 1 and not args.no_overlap_exchange
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    exch_ev = []
+
+    def exchange(s, i):
+        """per-shard lists of every rank -> merged global lists (RCCL all-gather x 2 + isx_topk_merge)"""
+        all_s = torch.empty((world, M, k), dtype=s.dtype, device=dev)
+        all_i = torch.empty((world, M, k), dtype=i.dtype, device=dev)
+        dist.all_gather_into_tensor(all_s.view(-1, k), s)
+        dist.all_gather_into_tensor(all_i.view(-1, k), i)
+        return ops.topk_merge(all_s, all_i)
+
+    def step(timed, deferred=False):
+        """One step.  `timed`: the instrumented pass (HIP events around the pool, the GEMM and the exchange legs on torch's current
+        stream, which is the stream every libisx launch goes to).  `deferred` (N > 1): the result exchange is issued on the side stream
+        behind an event; the main stream is free for the next step's trunk."""
         with torch.no_grad():
             if args.backbone_dtype == "bf16":
                 with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -235,30 +263,40 @@ def main():
         ops.gap_l2(fmap, out=q_local)
         if timed:
             b.record(); gap_ev.append((a, b))
+            x0, x1 = ev(), ev(); x0.record()
         Q = retrieval.gather_queries(q_local)
         if timed:
+            x1.record()
             c, d = ev(), ev(); c.record()
         ops.cosine_sim(Q, shard, out=sim)
         if timed:
             d.record(); gemm_ev.append((c, d))
         s, i = ops.topk_rows(sim, k, idx_base=gallery.idx_base)
         if world > 1:
-            all_s = torch.empty((world, M, k), dtype=s.dtype, device=dev)
-            all_i = torch.empty((world, M, k), dtype=i.dtype, device=dev)
-            dist.all_gather_into_tensor(all_s.view(-1, k), s)
-            dist.all_gather_into_tensor(all_i.view(-1, k), i)
-            s, i = ops.topk_merge(all_s, all_i)
+            if deferred:
+                ready = torch.cuda.Event()
+                ready.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ready)
+                    s.record_stream(side); i.record_stream(side)
+                    s, i = exchange(s, i)
+            else:
+                if timed:
+                    x2, x3 = ev(), ev(); x2.record()
+                s, i = exchange(s, i)
+                if timed:
+                    x3.record(); exch_ev.append((x0, x1, x2, x3))
         return s, i
 
     for _ in range(args.warmup):
-        step(False)
+        step(False, overlap)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step(False)
-    torch.cuda.synchronize()
+        out = step(False, overlap)
+    torch.cuda.synchronize()                     # every stream of the device: the deferred exchange of the last step is inside the timed region
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
@@ -267,19 +305,36 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     assert out[1].shape == (M, k) and int(out[1].min()) >= 0
+    overlap_identical = None
+    if world > 1:
+        # both schedules on the same inputs: the deferred exchange must return the bits of the in-line one
+        o1 = step(False, False)
+        o2 = step(False, True)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(o1[1], o2[1]) and torch.equal(o1[0].view(torch.int32), o2[0].view(torch.int32)))
+        flag = torch.tensor([1 if same else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        overlap_identical = bool(int(flag.item()) == 1)
 
     # ---- instrumented pass (outside the timed region): per-launch HIP events of the hand-written kernels ----------
     trunk, ksteps = {}, 0
     gemm_ms = gap_ms = None
-    if not args.no_kernel_pass:
+    exchange_legs = None
+    if not args.no_kernel_pass or world > 1:          # N > 1: the exchange legs are always measured
         ksteps = max(1, min(args.steps, 5))
-        ops.KERNEL_TIMER = []
+        ops.KERNEL_TIMER = [] if not args.no_kernel_pass else None
         for _ in range(ksteps):
             step(True)
         torch.cuda.synchronize()
-        timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+        timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER or [], None
         gemm_ms = sum(a.elapsed_time(b) for a, b in gemm_ev) / len(gemm_ev)
         gap_ms = sum(a.elapsed_time(b) for a, b in gap_ev) / len(gap_ev)
+        if exch_ev:
+            q_ms = sum(e[0].elapsed_time(e[1]) for e in exch_ev) / len(exch_ev)
+            r_ms = sum(e[2].elapsed_time(e[3]) for e in exch_ev) / len(exch_ev)
+            em = torch.tensor([q_ms, r_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(em, op=dist.ReduceOp.MAX)
+            exchange_legs = {"query_allgather_ms": float(em[0]), "result_allgather_merge_ms": float(em[1])}
         for name, flop, nbytes, ea, eb in timer:
             t = trunk.setdefault(name, {"n": 0, "flop": 0.0, "bytes": 0.0, "ms": 0.0, "floor_ms": 0.0})
             ms_ = ea.elapsed_time(eb)
@@ -348,6 +403,106 @@ def main():
             except Exception as e:                   # a failed side measurement must not cost the headline number
                 shard_result = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
+
+    # side measurement: BASELINE configs[2] -- ResNet-50 region-pooled descriptors (classif_regions path) on 448 x 448 images,
+    # then that config's retrieval leg at 1k queries x 100k gallery rows of those (class-score, 464-d) descriptors
+    regions_result = None
+
+    def regions_bench():
+        from isx import backbones
+        from model.nn_utils import fold_batch_norm, set_net_train
+        from model.siamese import TuneClassifSub
+        from train import classif_regions as cr
+        Br, n_cls = args.regions_batch, 464
+        torch.manual_seed(0)
+        sub = TuneClassifSub(backbones.MODELS["resnet50"](pretrained=True, seed=0), n_cls, (7, 7))
+        set_net_train(sub, False)
+        sub.features = fold_batch_norm(sub.features)
+        sub = sub.to(dev).to(memory_format=torch.channels_last)
+        x_cpu = synthetic_images(8, size=(3, 448, 448), seed=4321 + rank)
+        x = x_cpu.to(dev).repeat((Br + 7) // 8, 1, 1, 1)[:Br].contiguous(memory_format=torch.channels_last)
+        slab = torch.empty((Br, n_cls), device=dev)
+
+        def run():
+            with torch.no_grad():
+                slab.copy_(cr._best_location_descriptors(sub(x)[0]))       # features -> box pool -> 1x1 classifier -> best location -> L2 -> slab rows
+
+        run(); run()
+        torch.cuda.synchronize()
+        n_it = 5
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(n_it):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_ = e0.elapsed_time(e1) / n_it              # this rank's launches (no collective in here: a failure on one rank cannot hang the others)
+        # which kernels ran (one instrumented launch): every convolution of the step must be a libisx entry point
+        ops.KERNEL_TIMER = []
+        run()
+        torch.cuda.synchronize()
+        timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+        fams = {}
+        for name, flop, nbytes, ea, eb in timer:
+            f = fams.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0})
+            f["launches"] += 1; f["ms"] += ea.elapsed_time(eb); f["flop"] += flop
+        for f in fams.values():
+            f["tflops"] = f["flop"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else None
+        conv_flop = sum(f["flop"] for f in fams.values())
+        flop_img = 4.0 * RESNET50_GFLOP_PER_IMAGE * 1e9 + 2.0 * 64 * 2048 * n_cls        # every convolution sees 4x the pixels of 224 x 224; + the 1x1 classifier on 8 x 8 locations
+        ips = Br / (ms_ * 1e-3)
+        assert bool(torch.isfinite(slab).all())
+        res = {"workload": "BASELINE configs[2]: ResNet-50 TuneClassifSub (fp32, BN folded, NHWC) on 448x448 synthetic images -> 8x8 map of %d class scores "
+                           "-> best-location descriptor (train/classif_regions.py:107-132), %d images per launch" % (n_cls, Br),
+               "images_per_s": ips, "ms_per_launch": ms_, "images_per_launch": Br,
+               "roofline": {"bound": "mfma", "achieved": flop_img * ips / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": flop_img * ips / 1e12 / PEAK_F32_MFMA_TFLOPS, "algorithmic_flop_per_image": flop_img, "traffic": None},
+               "libisx_convolution_flop_per_image": conv_flop / Br,
+               "all_convolutions_in_libisx": bool(conv_flop / Br > 0.995 * flop_img),
+               "kernel_families": fams}
+        del sub, x
+        torch.cuda.empty_cache()
+        # retrieval leg of the same config: 1k queries x 100k gallery rows, exact scores + top-k + full-rank AP without a sort
+        Mq, Nr = 1000, 100000
+        Qc, Gc, ql, gl = synthetic_descriptors(Nr, Mq, n_cls, seed=7 + rank)
+        Qd, Gd = ops.l2norm_rows(Qc.to(dev)), ops.l2norm_rows(Gc.to(dev))
+        ql, gl = ql.to(dev), gl.to(dev)
+        simr = torch.empty((Mq, Nr), device=dev)
+
+        def leg(f, n=3):
+            f(); torch.cuda.synchronize()
+            a, b = ev(), ev(); a.record()
+            for _ in range(n):
+                f()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / n
+        t_sim = leg(lambda: ops.cosine_sim(Qd, Gd, out=simr))
+        t_topk = leg(lambda: ops.topk_rows(simr, k))
+        t_ap = leg(lambda: ops.average_precision_sim(simr, ql, gl))
+        ap = ops.average_precision_sim(simr, ql, gl)
+        res["retrieval_1000x100000"] = {"descriptor_dim": n_cls, "cosine_sim_ms": t_sim, "topk_rows_ms": t_topk, "average_precision_ms": t_ap,
+                                        "total_ms": t_sim + t_topk + t_ap, "dist_per_s": Mq * Nr / ((t_sim + t_topk + t_ap) * 1e-3),
+                                        "cosine_sim_tflops": 2.0 * Mq * Nr * n_cls / (t_sim * 1e-3) / 1e12,
+                                        "cosine_sim_frac_of_f32_mfma_peak": 2.0 * Mq * Nr * n_cls / (t_sim * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                        "mAP": float(ap[~ap.isnan()].mean())}
+        return res
+
+    if not args.no_regions_bench:
+        try:
+            regions_result = regions_bench()
+        except Exception as e:                       # never costs the headline; every rank catches alike (the collectives inside are bracketed by it)
+            ops.KERNEL_TIMER = None
+            regions_result = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        if world > 1:                                # every rank gets here: slowest rank's launch time, and whether all ranks succeeded
+            ok = "error" not in regions_result
+            tm_ = torch.tensor([regions_result["ms_per_launch"] if ok else 0.0, 0.0 if ok else 1.0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
+            if ok and float(tm_[1]) == 0.0:
+                regions_result["ms_per_launch_max_over_ranks"] = float(tm_[0])
+                regions_result["images_per_s_all_gpus"] = world * regions_result["images_per_launch"] / (float(tm_[0]) * 1e-3)
+            elif ok:
+                regions_result["note"] = "another rank failed this side measurement: rank 0's own numbers only"
 
     if rank == 0:
         images_per_s = world * B * args.steps / dt
@@ -439,7 +594,18 @@ def main():
             line["roofline"] = None
         if shard_result is not None:
             line["retrieval_shard"] = shard_result
-        if world == 1 and not args.no_cpu_baseline:
+        if regions_result is not None:
+            line["extraction_regions"] = regions_result
+        if world > 1:
+            ex = exchange_legs or {}
+            tot = sum(ex.values()) if ex else None
+            line["exchange_ms"] = tot
+            line["exchange"] = dict(ex, exposed_when_serialised_frac_of_step=(tot / ms_per_step if tot is not None else None),
+                                    overlapped=overlap, overlap_identical=overlap_identical,
+                                    legs="query all-gather (on the critical path) | per-shard top-k all-gather x 2 + isx_topk_merge"
+                                         + (" (on a second stream behind the next step's trunk)" if overlap else ""),
+                                    timing="HIP events on the launch stream, max over ranks, %d instrumented steps with the exchange in line" % ksteps)
+        if not args.no_cpu_baseline:                 # rank 0 at every N; the other ranks wait at the barrier below
             try:
                 line["cpu_baseline"] = cpu_baseline(args, shard.cpu(), images_cpu)
             except Exception as e:

@@ -107,7 +107,7 @@ int isx_conv3x3_expand_dual_nhwc(const float* t, int64_t B, int H, int W, int Ci
  * MaxPool2d(3, stride 2, padding 1) on a channels-last image batch; the convolution output never reaches memory.  Replaces
  * conv1, bn1, relu, maxpool of the torchvision ResNet `features` trunk (model/ModelDefinition.py, split by model/nn_utils.py:56-71,
  * run from model/siamese.py:20,107,151).  conv = fp32 fma chain over (kh, kw, c) ascending (bit-exact vs the oracle).
- * x: (B,H,W,3) fp32, 16-B aligned, W % 4 == 0, W <= 224; w_ohwi: (64,7,7,3); bias: (64); out: (B,Hp,Wp,64) with
+ * x: (B,H,W,3) fp32, 16-B aligned, W % 4 == 0, W <= 896 (images wider than 224 are walked in column bands of 224 inside the workgroup); w_ohwi: (64,7,7,3); bias: (64); out: (B,Hp,Wp,64) with
  * Hc = (H-1)/2 + 1, Hp = (Hc-1)/2 + 1 (same for W). */
 int isx_stem7x7_pool_nhwc(const float* x, int64_t B, int H, int W, const float* w_ohwi, const float* bias, float* out,
                           isx_stream_t stream);
@@ -143,6 +143,11 @@ int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, const flo
 int isx_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out,
                    isx_stream_t stream);
 
+/* The same pooling on a channels-last map (what the NHWC trunk produces: no transpose in front of the region path).
+ * fmap: (B,H,W,C); out: (B,H-kh+1,W-kw+1,C); C % 4 == 0, H*W*4 floats <= 64 KB.  Same window sums bit for bit. */
+int isx_boxpool_s1_nhwc(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out,
+                        isx_stream_t stream);
+
 /* ---- region path ----------------------------------------------------------- */
 
 /* train/classif_regions.py:118-128: class-max map, spatial arg-max (smallest column,
@@ -164,6 +169,17 @@ int isx_region_topk(const float* cls, int64_t B, int K, int Hp, int Wp, int k, i
  * (the 100352 x D weight is then streamed once per batch, not once per window as in the reference). */
 int isx_region_gather_l2(const float* fmap, int64_t B, int C, int Hf, int Wf, int kh, int kw, const int64_t* flat_idx, int k,
                          int Wp, const float* shift, float eps, float* rows, isx_stream_t stream);
+
+/* Channels-last variants of the three region entry points above (same reference lines, same selection and tie-break):
+ * cls: (B,Hp,Wp,K) -- the output of the 1x1-convolution classifier on the NHWC trunk --, fmap: (B,Hf,Wf,C).
+ * isx_region_gather_l2_nhwc keeps a window in (h,w,C) order: rows (B,k,kh*kw*C), row[(a*kw + b)*C + c] = x[b, c, row+a, col+b];
+ * shift_hwc is the Shift parameter permuted the same way (the caller permutes the Linear's weight columns once to match). */
+int isx_best_location_desc_nhwc(const float* cls, int64_t B, int K, int Hp, int Wp, float eps, float* desc,
+                                int64_t* loc, isx_stream_t stream);
+int isx_region_topk_nhwc(const float* cls, int64_t B, int K, int Hp, int Wp, int k, int64_t* flat_idx, float* score,
+                         isx_stream_t stream);
+int isx_region_gather_l2_nhwc(const float* fmap, int64_t B, int C, int Hf, int Wf, int kh, int kw, const int64_t* flat_idx, int k,
+                              int Wp, const float* shift_hwc, float eps, float* rows, isx_stream_t stream);
 
 /* ---- retrieval ------------------------------------------------------------- */
 

@@ -72,6 +72,19 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t r
         }
         return;
     }
+    if ((D & 3) == 0 && ((uintptr_t)P & 15) == 0) {
+        // D a multiple of 4 but not of BK (class-score descriptors: D = 464) on 16-B aligned rows: the same buffer loads; in the last
+        // k-tile the chunks past D -- they would read the next row -- are sent outside the descriptor and load zeros (fma(0, 0, acc) = acc)
+        const int64_t left = rows - row0;
+        const auto rs = uniform_rsrc(P + row0 * D, (left < ROWS ? left : ROWS) * (int64_t)D * 4);
+#pragma unroll
+        for (int j = 0; j < ROWS * CH / 256; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            const unsigned vo = k0 + ((idx % CH) << 2) < D ? (unsigned)(idx / CH) * (unsigned)D * 4u + (unsigned)((idx % CH) << 4) : 0x80000000u;
+            reg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)k0 * 4u, 0));
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < ROWS * CH / 256; ++j) {
         const int idx = j * 256 + threadIdx.x;

@@ -263,6 +263,37 @@ __global__ __launch_bounds__(256) void boxpool_s1_direct_kernel(const float* __r
     }
 }
 
+// Channels-last variant: fmap (B,H,W,C), out (B,Ho,Wo,C).  One workgroup per (image, slice of CS channels): the slice of the whole map is
+// staged in LDS with 16-B loads (a pixel's CS channels are contiguous), a thread owns 4 consecutive channels of an output location and walks the
+// window rows-then-columns from +0 exactly as the NCHW kernel does (same values bit for bit).
+__global__ __launch_bounds__(256) void boxpool_s1_nhwc_kernel(const float* __restrict__ fmap, int C, int H, int W, int kh, int kw, int CS,
+                                                              float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int Ho = H - kh + 1, Wo = W - kw + 1, HWi = H * W, HWo = Ho * Wo;
+    const int q = CS >> 2;                                       // float4 per pixel of the slice
+    const int c0 = blockIdx.x * CS;
+    const float* src = fmap + (int64_t)blockIdx.y * HWi * C + c0;
+    float4* l4 = reinterpret_cast<float4*>(lds);
+    for (int i = threadIdx.x; i < HWi * q; i += 256) {
+        const int p = i / q, cq = i - p * q;
+        l4[i] = *reinterpret_cast<const float4*>(src + (int64_t)p * C + cq * 4);
+    }
+    __syncthreads();
+    const float div = (float)(kh * kw);
+    float* dst = out + (int64_t)blockIdx.y * HWo * C + c0;
+    for (int o = threadIdx.x; o < HWo * q; o += 256) {
+        const int p = o / q, cq = o - p * q, i = p / Wo, j = p - i * Wo;
+        const float4* b = l4 + (i * W + j) * q + cq;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int a = 0; a < kh; ++a)
+            for (int c = 0; c < kw; ++c) {
+                const float4 v = b[(a * W + c) * q];
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        *reinterpret_cast<float4*>(dst + (int64_t)p * C + cq * 4) = make_float4(s.x / div, s.y / div, s.z / div, s.w / div);
+    }
+}
+
 }  // namespace isx
 
 using namespace isx;
@@ -366,6 +397,21 @@ ISX_API int isx_boxpool_s1(const float* fmap, int64_t B, int C, int H, int W, in
         hipLaunchKernelGGL(boxpool_s1_direct_kernel, dim3(grid), dim3(256), 0, st, fmap, total, H, W, kh, kw, out);
     }
     ISX_CHECK_LAUNCH("isx_boxpool_s1");
+    return ISX_OK;
+}
+
+ISX_API int isx_boxpool_s1_nhwc(const float* fmap, int64_t B, int C, int H, int W, int kh, int kw, float* out, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && B < 65536 && C > 0 && H > 0 && W > 0 && kh > 0 && kw > 0 && kh <= H && kw <= W,
+                "isx_boxpool_s1_nhwc: bad shape B=%lld C=%d H=%d W=%d k=%dx%d", (long long)B, C, H, W, kh, kw);
+    ISX_REQUIRE(C % 4 == 0 && (((uintptr_t)fmap | (uintptr_t)out) % 16) == 0, "isx_boxpool_s1_nhwc: C=%d must be a multiple of 4 and the pointers 16-B aligned", C);
+    ISX_REQUIRE(fmap && out && fmap != out, "isx_boxpool_s1_nhwc: null or aliased pointer");
+    if (B == 0) return ISX_OK;
+    int CS = 64;                                                  // channels per workgroup: the slice of the whole map must fit 64 KB of LDS
+    while (CS > 4 && (C % CS != 0 || (size_t)H * W * CS * 4 > 64 * 1024)) CS >>= 1;
+    ISX_REQUIRE(C % CS == 0 && (size_t)H * W * CS * 4 <= 64 * 1024, "isx_boxpool_s1_nhwc: a %dx%d map does not fit the LDS staging (use isx_boxpool_s1)", H, W);
+    hipLaunchKernelGGL(boxpool_s1_nhwc_kernel, dim3((unsigned)(C / CS), (unsigned)B), dim3(256), (size_t)H * W * CS * 4, (hipStream_t)stream, fmap, C, H, W,
+                       kh, kw, CS, out);
+    ISX_CHECK_LAUNCH("isx_boxpool_s1_nhwc");
     return ISX_OK;
 }
 

@@ -15,6 +15,10 @@
 //   * an accumulator row block is 4 columns x 8 rows, ordered so that ONE lane holds, for its channel, the 8 rows of two adjacent
 //     columns = four complete 2x2 pooling cells: the 3x3/2 max needs only the row above (carried in registers from the previous
 //     step) and the column to the left (the other half-wave: ds_bpermute; across waves: 4 KB of LDS), then 28 dword stores per lane.
+//   * images wider than 224 (region path: 384 / 448 wide) are walked in COLUMN BANDS of 112 convolution columns INSIDE the workgroup:
+//     unit (step t, band cb) stages the 21 rows x 232 columns under its tile (the 4-pixel border now holds the neighbouring band's
+//     pixels, or zeros at the image edge), the carry row of every band stays in registers, and the right-most pooled partial column of
+//     band cb reaches band cb + 1 through an LDS slot of its own -- nothing is recomputed and nothing but the pooled map is stored.
 // Arithmetic: acc = fp32 fma chain over (kh, kw, c) ascending from +0 (padding taps contribute fma(0, w, acc) = acc), y = max(acc + bias, 0),
 // out = max over the window: bit-identical to oracle/isx_oracle.c::isxo_stem7x7_pool_nhwc (tests/test_gpu_parity.py).
 // Reference: the torchvision ResNet stem (conv1, bn1, relu, maxpool) inside the `features` trunk built by model/ModelDefinition.py and
@@ -30,12 +34,17 @@ constexpr int ST_ROWS = 21;                    // input rows under 8 convolution
 constexpr int ST_BUF_F = ST_ROWS * ST_RSF;     // 58 464 B per buffer
 constexpr int ST_K = 154;                      // 7 filter rows x (21 + 1 zero)
 constexpr int ST_W_F = ST_K * 64;              // 39 424 B
-constexpr int ST_X_F = 4 * 2 * 4 * 32;         // cross-wave column exchange: [column group][channel block][pooled row][channel]
+constexpr int ST_X_F = 5 * 2 * 4 * 32;         // cross-wave column exchange: [column group (+ 2 band hand-over slots)][channel block][pooled row][channel]
 constexpr int ST_NSTORE = 28;                  // output stores per lane and step
-constexpr int ST_MAXW = 224;
+constexpr int ST_BANDW = 224;                  // input columns per column band (112 convolution columns, 56 pooled columns)
+constexpr int ST_MAXCB = 4;                    // column bands per image
+constexpr int ST_MAXW = ST_BANDW * ST_MAXCB;
+constexpr int ST_ROWCHUNKS = ST_RSF / 4;       // 16-B chunks per staged row: 174
 
 struct StemGeom { int H, W, Hc, Wc, Hp, Wp, steps, bands; };
 
+// NCB: column bands per image (1: images up to 224 wide, the tile covers the whole width).
+template <int NCB>
 __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restrict__ x, StemGeom g, const float* __restrict__ w_ohwi,
                                                            const float* __restrict__ bias, float* __restrict__ out) {
     __shared__ __attribute__((aligned(1024))) float lds[2 * ST_BUF_F + ST_W_F + ST_X_F];      // 160 448 B
@@ -62,23 +71,30 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
     for (int e = tid; e < 7 * 64; e += 512) w_lds[((e >> 6) * 22 + 21) * 64 + (e & 63)] = 0.0f;
     __syncthreads();
 
-    // input rows 16 t - 3 .. 16 t + 17 of step t into buffer `buf`: 63 (row, 64-chunk part) items, wave w takes items w, w + 8, ...
-    auto issue_dma = [&](int t, int buf) {
+    // input rows 16 t - 3 .. 16 t + 17, image columns 224 cb - 4 .. 224 cb + 227 of unit (t, cb) into buffer `buf`: 63 (row, 64-chunk part) items,
+    // wave w takes items w, w + 8, ...  LDS chunk lc of a row holds image chunk 168 cb - 3 + lc.  One band: the chunks outside the image are never
+    // written and stay zero from the prologue; several bands: every chunk of the unit is either fetched or zeroed (the buffers change bands).
+    auto issue_dma = [&](int t, int cb, int buf) {
         const int r0 = 16 * t - 3;
+        const int gc0 = 168 * cb - 3;
 #pragma unroll
         for (int i8 = 0; i8 < 8; ++i8) {
             const int item = i8 * 8 + wave;
             if (item < 63) {
                 const int row = item / 3, part = item - row * 3;
                 const int ir = r0 + row;
-                const int chunk = part * 64 + lane;
-                float* dst_row = in_lds + buf * ST_BUF_F + row * ST_RSF + 12;
+                const int lc = part * 64 + lane;
+                const int gc = gc0 + lc;
+                float* dst_row = in_lds + buf * ST_BUF_F + row * ST_RSF;
+                const bool in_cols = (unsigned)gc < (unsigned)nchunk && lc < ST_ROWCHUNKS;
                 if ((unsigned)ir < (unsigned)g.H) {
-                    if (chunk < nchunk)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x_img + (int64_t)ir * g.W * 3 + chunk * 4),
+                    if (in_cols)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x_img + (int64_t)ir * g.W * 3 + gc * 4),
                                                          (__attribute__((address_space(3))) void*)(dst_row + part * 256), 16, 0, 0);
-                } else if (chunk < nchunk) {
-                    reinterpret_cast<float4*>(dst_row)[chunk] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else if (NCB > 1 && lc < ST_ROWCHUNKS)
+                        reinterpret_cast<float4*>(dst_row)[lc] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else if (NCB > 1 ? lc < ST_ROWCHUNKS : in_cols) {
+                    reinterpret_cast<float4*>(dst_row)[lc] = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         }
@@ -91,11 +107,13 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
     const float* const bp = w_lds + h * 64 + 32 * nblk + l31;                   // + (22 kh + 2 s') * 64
 
     const float bias_v = bias[32 * nblk + l31];
-    float carry[7][2];                                                          // convolution row 8 t - 1 of this lane's two columns (after ReLU)
+    float carry_all[NCB][7][2];                                                 // convolution row 8 t - 1 of this lane's two columns (after ReLU), per band
 #pragma unroll
-    for (int b = 0; b < 7; ++b) carry[b][0] = carry[b][1] = 0.0f;
+    for (int j = 0; j < NCB; ++j)
+#pragma unroll
+        for (int b = 0; b < 7; ++b) carry_all[j][b][0] = carry_all[j][b][1] = 0.0f;
 
-    // output: descriptor of the image's pooled rows; lane offset of (column q = 14 cg + 2 b + h, channel); the pooled row is the SGPR offset
+    // output: descriptor of the image's pooled rows; lane offset of (column q = 56 cb + 14 cg + 2 b + h, channel); pooled row and band are the SGPR offset
     const int64_t out_img_bytes = (int64_t)g.Hp * g.Wp * 256;
     const auto out_rs = uniform_rsrc(out + (int64_t)img * g.Hp * g.Wp * 64, out_img_bytes);
     const auto null_rs = uniform_rsrc(out, 0);
@@ -106,15 +124,39 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
         o_off[b] = q < g.Wp ? (unsigned)((q * 64 + 32 * nblk + l31) * 4) : 0x80000000u;
     }
 
-    issue_dma(t_start, 0);
-    int buf = 0;
-    for (int t = t_start; t < t_end; ++t, buf ^= 1) {
-        // this step's rows have landed (everything older than the previous step's stores), and every wave is done with the other buffer
-        if (t == t_start) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    issue_dma(t_start, 0, 0);
+    int buf = 0, t = t_start, cb = 0;
+    bool first = true;
+    for (;;) {
+        // this unit's rows have landed (everything older than the previous unit's stores), and every wave is done with the other buffer
+        if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST_NSTORE) : "memory");
+        first = false;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (t + 1 < t_end) issue_dma(t + 1, buf ^ 1);
+        int tn = t, cbn = cb + 1;
+        if (cbn == NCB) { cbn = 0; ++tn; }
+        if (tn < t_end) issue_dma(tn, cbn, buf ^ 1);
+
+        float carry[7][2];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) {
+            carry[b][0] = carry_all[0][b][0];
+            carry[b][1] = carry_all[0][b][1];
+#pragma unroll
+            for (int j = 1; j < NCB; ++j) {
+                carry[b][0] = cb == j ? carry_all[j][b][0] : carry[b][0];
+                carry[b][1] = cb == j ? carry_all[j][b][1] : carry[b][1];
+            }
+        }
+        if (NCB > 1) {
+#pragma unroll
+            for (int b = 0; b < 7; ++b) {
+                const int q = 56 * cb + 14 * cg + 2 * b + h;
+                o_off[b] = q < g.Wp ? (unsigned)(((14 * cg + 2 * b + h) * 64 + 32 * nblk + l31) * 4) : 0x80000000u;
+            }
+        }
+        const int wc_left = g.Wc - 112 * cb;                                    // convolution columns of the image from this band's first one on
 
         f32x16 acc[7];
 #pragma unroll
@@ -139,14 +181,14 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
             for (int b = 0; b < 7; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][b], bv[s & 1], acc[b], 0, 0, 0);
         }
 
-        // ---- epilogue: bias + ReLU, 3x3 / stride 2 max.  acc[b][4 gg + 2 r + c] = convolution row 8 t + 2 gg + r, column 28 cg + 4 b + 2 h + c
+        // ---- epilogue: bias + ReLU, 3x3 / stride 2 max.  acc[b][4 gg + 2 r + c] = convolution row 8 t + 2 gg + r, column 112 cb + 28 cg + 4 b + 2 h + c
         float own[7][4], rgt[7][4];
 #pragma unroll
         for (int b = 0; b < 7; ++b) {
             float v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const bool ok = (8 * t + 2 * (e >> 2) + ((e >> 1) & 1) < g.Hc) && (28 * cg + 4 * b + 2 * h + (e & 1) < g.Wc);
+                const bool ok = (8 * t + 2 * (e >> 2) + ((e >> 1) & 1) < g.Hc) && (28 * cg + 4 * b + 2 * h + (e & 1) < wc_left);
                 v[e] = ok ? fmaxf(acc[b][e] + bias_v, 0.0f) : 0.0f;            // 0 = identity of the max (values are >= 0 after the ReLU)
             }
 #pragma unroll
@@ -155,13 +197,18 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
                 rgt[b][gg] = fmaxf(fmaxf(top1, v[4 * gg + 1]), v[4 * gg + 3]);
                 own[b][gg] = fmaxf(fmaxf(fmaxf(top0, v[4 * gg]), v[4 * gg + 2]), rgt[b][gg]);
             }
-            carry[b][0] = v[14];
-            carry[b][1] = v[15];
-        }
-        // the column to the left: the other half-wave's right column (same block for h = 1, the previous block for h = 0)
-        if (h) {
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) x_lds[((cg * 2 + nblk) * 4 + gg) * 32 + l31] = rgt[6][gg];
+            for (int j = 0; j < NCB; ++j) {
+                carry_all[j][b][0] = (NCB == 1 || cb == j) ? v[14] : carry_all[j][b][0];
+                carry_all[j][b][1] = (NCB == 1 || cb == j) ? v[15] : carry_all[j][b][1];
+            }
+        }
+        // the column to the left: the other half-wave's right column (same block for h = 1, the previous block for h = 0); the last column group
+        // of a band leaves its right column in slot 3 + (cb & 1) for the first group of the next band
+        if (h) {
+            const int slot = (NCB > 1 && cg == 3) ? 3 + (cb & 1) : cg;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) x_lds[((slot * 2 + nblk) * 4 + gg) * 32 + l31] = rgt[6][gg];
         }
         float swp[7][4];
 #pragma unroll
@@ -172,8 +219,10 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         float left0[4];
+        const int lslot = cg ? cg - 1 : 3 + ((cb - 1) & 1);
+        const bool has_left = cg || (NCB > 1 && cb > 0);
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) left0[gg] = cg ? x_lds[(((cg - 1) * 2 + nblk) * 4 + gg) * 32 + l31] : 0.0f;
+        for (int gg = 0; gg < 4; ++gg) left0[gg] = has_left ? x_lds[((lslot * 2 + nblk) * 4 + gg) * 32 + l31] : 0.0f;
         const auto rs = t >= t_first ? out_rs : null_rs;
 #pragma unroll
         for (int b = 0; b < 7; ++b)
@@ -181,8 +230,10 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
             for (int gg = 0; gg < 4; ++gg) {
                 const float left = h ? swp[b][gg] : (b ? swp[b > 0 ? b - 1 : 0][gg] : left0[gg]);
                 const float y = fmaxf(own[b][gg], left);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs, o_off[b], (unsigned)((4 * t + gg) * g.Wp * 256), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rs, o_off[b], (unsigned)(((4 * t + gg) * g.Wp + 56 * cb) * 256), 0);
             }
+        t = tn; cb = cbn; buf ^= 1;
+        if (t >= t_end) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -207,7 +258,13 @@ ISX_API int isx_stem7x7_pool_nhwc(const float* x, int64_t B, int H, int W, const
     int bands = 1;                                               // few images: split each into bands of steps so that every CU has work
     while (B * bands < 256 && bands * 4 <= g.steps) bands *= 2;
     g.bands = bands;
-    hipLaunchKernelGGL(isx::stem7x7_pool_kernel, dim3((unsigned)(B * bands)), dim3(512), 0, (hipStream_t)stream, x, g, w_ohwi, bias, out);
+    const int ncb = (g.Wc + 111) / 112;                         // column bands, walked inside the workgroup
+    const dim3 grid((unsigned)(B * bands));
+    hipStream_t st = (hipStream_t)stream;
+    if (ncb == 1) hipLaunchKernelGGL(isx::stem7x7_pool_kernel<1>, grid, dim3(512), 0, st, x, g, w_ohwi, bias, out);
+    else if (ncb == 2) hipLaunchKernelGGL(isx::stem7x7_pool_kernel<2>, grid, dim3(512), 0, st, x, g, w_ohwi, bias, out);
+    else if (ncb == 3) hipLaunchKernelGGL(isx::stem7x7_pool_kernel<3>, grid, dim3(512), 0, st, x, g, w_ohwi, bias, out);
+    else hipLaunchKernelGGL(isx::stem7x7_pool_kernel<4>, grid, dim3(512), 0, st, x, g, w_ohwi, bias, out);
     ISX_CHECK_LAUNCH("isx_stem7x7_pool_nhwc");
     return ISX_OK;
 }

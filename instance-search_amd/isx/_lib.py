@@ -32,7 +32,11 @@ _SIGNATURES = {
     "isx_conv3x3_expand_dual_nhwc": (C.c_int, [VP, I64, I32, I32, I32, VP, VP, VP, VP, I32, VP, I32, VP, VP]),
     "isx_conv3x3_nhwc": (C.c_int, [VP, I64, I32, I32, I32, VP, I32, I32, VP, VP, I32, VP, VP]),
     "isx_boxpool_s1": (C.c_int, [VP, I64, I32, I32, I32, I32, I32, VP, VP]),
+    "isx_boxpool_s1_nhwc": (C.c_int, [VP, I64, I32, I32, I32, I32, I32, VP, VP]),
     "isx_best_location_desc": (C.c_int, [VP, I64, I32, I32, I32, F32, VP, VP, VP]),
+    "isx_best_location_desc_nhwc": (C.c_int, [VP, I64, I32, I32, I32, F32, VP, VP, VP]),
+    "isx_region_topk_nhwc": (C.c_int, [VP, I64, I32, I32, I32, I32, VP, VP, VP]),
+    "isx_region_gather_l2_nhwc": (C.c_int, [VP, I64, I32, I32, I32, I32, I32, VP, I32, I32, VP, F32, VP, VP]),
     "isx_region_topk": (C.c_int, [VP, I64, I32, I32, I32, I32, VP, VP, VP]),
     "isx_region_gather_l2": (C.c_int, [VP, I64, I32, I32, I32, I32, I32, VP, I32, I32, VP, F32, VP, VP]),
     "isx_cosine_sim": (C.c_int, [VP, I64, VP, I64, I32, VP, VP]),

@@ -144,7 +144,7 @@ def bias_relu_maxpool(y, bias):
     return out
 
 
-STEM_MAX_W = 224
+STEM_MAX_W = 896      # csrc/stem.hip: up to four column bands of 224 input columns
 
 
 def stem7x7_pool_applicable(x, conv):
@@ -306,11 +306,40 @@ def boxpool_s1(fmap, kh, kw):
     return out
 
 
+def _is_nhwc(t):
+    """A 4-d tensor whose MEMORY is channels-last and not also plain contiguous (sizes where both hold are treated as NCHW)."""
+    return t.dim() == 4 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last)
+
+
+def boxpool_s1_applicable_nhwc(fmap):
+    return (fmap.is_cuda and fmap.dtype == torch.float32 and _is_nhwc(fmap) and fmap.shape[1] % 4 == 0
+            and fmap.shape[2] * fmap.shape[3] * 16 <= 64 * 1024 and fmap.data_ptr() % 16 == 0)
+
+
+def boxpool_s1_nhwc(fmap, kh, kw):
+    """AvgPool2d((kh,kw), stride 1) of a channels-last (B,C,H,W) map, result channels-last: no transpose on the way in or out."""
+    if not boxpool_s1_applicable_nhwc(fmap):
+        raise _lib.IsxError("fmap must be a channels-last float32 CUDA tensor (B,C,H,W) with C % 4 == 0 and H*W <= 1024")
+    _on_current_device(fmap, "fmap")
+    B, Cc, H, W = fmap.shape
+    out = torch.empty((B, Cc, H - kh + 1, W - kw + 1), device=fmap.device, dtype=torch.float32, memory_format=torch.channels_last)
+    check(lib().isx_boxpool_s1_nhwc(fmap.data_ptr(), B, Cc, H, W, kh, kw, out.data_ptr(), _stream()), "isx_boxpool_s1_nhwc")
+    return out
+
+
 def best_location_desc(cls, eps=EPS):
-    cls = _f32(cls, "cls")
+    """cls (B,K,Hp,Wp) class-score maps -> (desc (B,K), loc (B,2)); a channels-last tensor is consumed in place."""
+    if not (isinstance(cls, torch.Tensor) and cls.is_cuda and cls.dtype == torch.float32):
+        raise _lib.IsxError("cls must be a float32 CUDA tensor (libisx has no CPU path)")
+    _on_current_device(cls, "cls")
     B, K, Hp, Wp = cls.shape
     desc = torch.empty((B, K), device=cls.device, dtype=torch.float32)
     loc = torch.empty((B, 2), device=cls.device, dtype=torch.int64)
+    if _is_nhwc(cls):
+        check(lib().isx_best_location_desc_nhwc(cls.data_ptr(), B, K, Hp, Wp, eps, desc.data_ptr(), loc.data_ptr(), _stream()),
+              "isx_best_location_desc_nhwc")
+        return desc, loc
+    cls = cls.contiguous()
     check(lib().isx_best_location_desc(cls.data_ptr(), B, K, Hp, Wp, eps, desc.data_ptr(), loc.data_ptr(), _stream()),
           "isx_best_location_desc")
     return desc, loc
@@ -319,15 +348,42 @@ def best_location_desc(cls, eps=EPS):
 def region_topk(cls, k):
     """Canonical top-k locations of the class-max map.  cls (K,Hp,Wp) -> (idx (k), score (k));
     cls (B,K,Hp,Wp) -> (idx (B,k), score (B,k))."""
-    cls = _f32(cls, "cls")
+    if not (isinstance(cls, torch.Tensor) and cls.is_cuda and cls.dtype == torch.float32):
+        raise _lib.IsxError("cls must be a float32 CUDA tensor (libisx has no CPU path)")
+    _on_current_device(cls, "cls")
     single = cls.dim() == 3
     if single:
         cls = cls.unsqueeze(0)
     B, K, Hp, Wp = cls.shape
     idx = torch.empty((B, k), device=cls.device, dtype=torch.int64)
     sc = torch.empty((B, k), device=cls.device, dtype=torch.float32)
-    check(lib().isx_region_topk(cls.data_ptr(), B, K, Hp, Wp, k, idx.data_ptr(), sc.data_ptr(), _stream()), "isx_region_topk")
+    if _is_nhwc(cls):                  # channels-last score map (1x1-convolution classifier on the NHWC trunk): consumed in place
+        check(lib().isx_region_topk_nhwc(cls.data_ptr(), B, K, Hp, Wp, k, idx.data_ptr(), sc.data_ptr(), _stream()), "isx_region_topk_nhwc")
+    else:
+        cls = cls.contiguous()
+        check(lib().isx_region_topk(cls.data_ptr(), B, K, Hp, Wp, k, idx.data_ptr(), sc.data_ptr(), _stream()), "isx_region_topk")
     return (idx[0], sc[0]) if single else (idx, sc)
+
+
+def region_gather_l2_nhwc(fmap, kh, kw, flat_idx, Wp, shift_hwc=None, eps=EPS):
+    """Window gather + L2 + Shift on a channels-last (B,C,Hf,Wf) map; rows (B,k,kh*kw*C) keep the window in (h,w,C) order
+    (row[(a*kw + b)*C + c]); shift_hwc: the Shift parameter in that order."""
+    if not (fmap.is_cuda and fmap.dtype == torch.float32 and _is_nhwc(fmap) and fmap.shape[1] % 4 == 0):
+        raise _lib.IsxError("fmap must be a channels-last float32 CUDA tensor (B,C,Hf,Wf) with C % 4 == 0")
+    _on_current_device(fmap, "fmap")
+    flat_idx = _typed(flat_idx, torch.int64, "flat_idx")
+    B, Cc, Hf, Wf = fmap.shape
+    k = flat_idx.size(1)
+    assert flat_idx.shape == (B, k)
+    rows = torch.empty((B, k, Cc * kh * kw), device=fmap.device, dtype=torch.float32)
+    sp = 0
+    if shift_hwc is not None:
+        shift_hwc = _f32(shift_hwc, "shift_hwc")
+        assert shift_hwc.numel() == Cc * kh * kw
+        sp = shift_hwc.data_ptr()
+    check(lib().isx_region_gather_l2_nhwc(fmap.data_ptr(), B, Cc, Hf, Wf, kh, kw, flat_idx.data_ptr(), k, Wp, sp, eps, rows.data_ptr(), _stream()),
+          "isx_region_gather_l2_nhwc")
+    return rows
 
 
 def region_gather_l2(fmap, kh, kw, flat_idx, Wp, shift=None, eps=EPS):

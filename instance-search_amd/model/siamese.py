@@ -37,7 +37,24 @@ class BoxPool(nn.AvgPool2d):
         if _fast(x) and self.stride in (1, (1, 1)) and self.padding in (0, (0, 0)):
             from isx import ops
             kh, kw = self.kernel_size if isinstance(self.kernel_size, tuple) else (self.kernel_size,) * 2
+            if ops.boxpool_s1_applicable_nhwc(x):
+                return ops.boxpool_s1_nhwc(x, kh, kw)        # channels-last trunk output: pooled in place, stays channels-last
             return ops.boxpool_s1(x.float(), kh, kw)
+        return super().forward(x)
+
+
+class PointwiseConv(nn.Conv2d):
+    """A convolutionalised Linear with a 1x1 window (reference model/nn_utils.py:26-39 via model/siamese.py:73-80): plain nn.Conv2d
+    (same parameters and state-dict keys); on a channels-last GPU map without autograd it is ONE libisx GEMM over the locations
+    (`isx_conv1x1_nhwc`, bias fused), so the class-score map is born channels-last for the region kernels behind it."""
+
+    def forward(self, x):
+        if (_fast(x, self) and x.dtype == torch.float32 and x.dim() == 4 and not x.is_contiguous()
+                and x.is_contiguous(memory_format=torch.channels_last) and self.kernel_size == (1, 1) and self.stride == (1, 1)
+                and self.padding == (0, 0) and self.dilation == (1, 1) and self.groups == 1 and self.in_channels % 4 == 0):
+            from isx import ops
+            bias = self.bias if self.bias is not None else x.new_zeros(self.out_channels)
+            return ops.conv1x1_nhwc(x, self.weight.detach(), bias.detach(), None, relu=False)
         return super().forward(x)
 
 
@@ -56,7 +73,10 @@ def _convolutionalize_classifier(classifier, feature_size2d, has_reduc):
     for name, m in list(classifier._modules.items()):
         if isinstance(m, nn.Linear):
             size2d = (1, 1) if (has_reduc or seen > 0) else tuple(feature_size2d)
-            classifier._modules[name] = convolutionalize(m, size2d)
+            conv = convolutionalize(m, size2d)
+            if size2d == (1, 1):
+                conv.__class__ = PointwiseConv              # same module, GEMM fast path on channels-last GPU maps
+            classifier._modules[name] = conv
             seen += 1
 
 
@@ -236,12 +256,32 @@ class RegionDescriptorNet(nn.Module):
         kh, kw = self.feature_size2d
         k = min(c.size(2) * c.size(3), self.k)
         flat_idx, _ = ops.region_topk(c.float(), k)                                   # (B, k)
-        rows = ops.region_gather_l2(x.float(), kh, kw, flat_idx, c.size(3), self.feature_reduc1[1].param.detach())
         lin = self.feature_reduc1[2]
-        acc = F.linear(rows.view(B * k, -1), lin.weight, lin.bias).view(B, k, -1).sum(1)
+        if x.dtype == torch.float32 and ops._is_nhwc(x) and x.size(1) % 4 == 0 and x.data_ptr() % 16 == 0:
+            # channels-last trunk output: windows gathered as (h,w,C) runs (no transpose of the map), against the Shift vector and the
+            # Linear weight with their columns permuted once to that order -- the same dot products, summed in another order
+            shift_hwc, w_hwc = self._hwc_head(x.size(1), kh, kw)
+            rows = ops.region_gather_l2_nhwc(x, kh, kw, flat_idx, c.size(3), shift_hwc)
+            acc = F.linear(rows.view(B * k, -1), w_hwc, lin.bias).view(B, k, -1).sum(1)
+        else:
+            rows = ops.region_gather_l2(x.float(), kh, kw, flat_idx, c.size(3), self.feature_reduc1[1].param.detach())
+            acc = F.linear(rows.view(B * k, -1), lin.weight, lin.bias).view(B, k, -1).sum(1)
         cls_out = c.new_zeros(B, c.size(1), self.k)
         cls_out[:, :, :k] = c.flatten(2).gather(2, flat_idx[:, None, :].expand(B, c.size(1), k))
         return self.feature_reduc2(acc), cls_out
+
+    def _hwc_head(self, C, kh, kw):
+        """(Shift parameter, Linear weight) with the C*kh*kw input features re-ordered (C,h,w) -> (h,w,C); cached, rebuilt when either
+        tensor is written in place or replaced (version counters; `.data` surgery needs `self._hwc = None`)."""
+        shift, lin = self.feature_reduc1[1].param, self.feature_reduc1[2]
+        key = (shift.data_ptr(), shift._version, lin.weight.data_ptr(), lin.weight._version, str(lin.weight.device))
+        if getattr(self, "_hwc", None) is None or self._hwc[0] != key:
+            D = lin.weight.size(0)
+            with torch.no_grad():
+                s_hwc = shift.detach().view(C, kh, kw).permute(1, 2, 0).reshape(-1).contiguous()
+                w_hwc = lin.weight.detach().view(D, C, kh, kw).permute(0, 2, 3, 1).reshape(D, -1).contiguous()
+            self._hwc = (key, s_hwc, w_hwc)
+        return self._hwc[1], self._hwc[2]
 
     def forward_single(self, x):
         # the reference handles one image per call (model/siamese.py:184); here a batch of same-sized

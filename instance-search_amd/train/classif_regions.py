@@ -16,7 +16,7 @@ def _best_location_descriptors(score_map):
     """(B, n_cls, H', W') -> (B, n_cls): libisx `isx_best_location_desc` on the GPU."""
     if score_map.is_cuda:
         from isx import ops
-        return ops.best_location_desc(score_map.float())[0]
+        return ops.best_location_desc(score_map.float())[0]      # NCHW or channels-last, consumed in place
     B, K, Hp, Wp = score_map.shape
     mx = score_map.max(1)[0]                                   # class-max map
     # first maximal index: smallest column, then smallest row in that column
