@@ -257,6 +257,15 @@ int isx_average_precision_sim(const float* sim, int64_t M, int64_t N, const int3
 int isx_masked_sums(const float* sim, int64_t M, int64_t N, const int32_t* qlab, const int32_t* glab, double* out,
                     isx_stream_t stream);
 
+/* test/instance_avg.py:7-33 (DBA, database-side augmentation): new[i] = normalise(E[i] + sum_j w_j * E[best_j]) over the nn nearest
+ * neighbours of i WITHIN ITS INSTANCE (same label), w_j = (nn - j) / (nn + 1), nn = min(k, group - 1) (k < 0: all), out = agg / (|agg| + 1e-10);
+ * singleton instances and k = 0 keep their descriptor.  Only same-instance pairs are scored (the reference builds the N x N matrix and
+ * masks it): scores = the canonical fma chain of isx_cosine_sim, ranking canonical, aggregation in the reference's sequential order.
+ * emb, out: (N,D); order: (N) item indices sorted by (label, index); grp_begin / grp_size: (N) the run of `order` holding item i's
+ * instance; max_group = max(grp_size) <= 1024. */
+int isx_dba_groups(const float* emb, int64_t N, int D, const int32_t* order, const int32_t* grp_begin, const int32_t* grp_size,
+                   int max_group, int k, float* out, isx_stream_t stream);
+
 /* ---- multi-GPU (no reference counterpart: one torch.mm on one device,
  *      test/classif_finetune_test.py:82; BASELINE config 5 shards the gallery rows) --- */
 

@@ -261,6 +261,78 @@ __global__ __launch_bounds__(RK_THREADS) void masked_row_sums_kernel(const float
 
 static int64_t pow2_at_least(int64_t v) { int64_t p = 2; while (p < v) p <<= 1; return p; }
 
+// ---- database-side augmentation (DBA), reference test/instance_avg.py:7-33 ------------------------------------------------------
+// One 256-thread workgroup per gallery item i.  Only the items of i's own instance (same label: a run of `order`, ascending item index
+// inside the run) are ever scored -- the reference builds the whole N x N matrix and then overwrites every other entry with -2.
+//   1. score: thread t owns member t (t + 256, ...): acc = fmaf(E[i][d], E[m][d], acc) for d = 0..D-1 from +0 -- the canonical chain of
+//      isx_cosine_sim, bit for bit; E[i] is read from LDS (broadcast);
+//   2. rank: canonical keys (score desc, item index asc) sorted in LDS (<= 1024 members);
+//   3. aggregate in the REFERENCE's order: agg = E[i]; agg += E[best_j] * w_j for j = 0, 1, ... with w_j = (nn - j) / float(nn + 1)
+//      (a double quotient rounded to fp32, as Python's) -- sequential per element, so the sums equal the reference loop's bit for bit;
+//   4. out = agg / (|agg| + 1e-10): eps OUTSIDE the norm here (:31).
+constexpr int DBA_MAX_GROUP = 1024;
+
+__global__ __launch_bounds__(256) void dba_group_kernel(const float* __restrict__ emb, int D, const int32_t* __restrict__ order,
+                                                        const int32_t* __restrict__ grp_begin, const int32_t* __restrict__ grp_size, int k,
+                                                        float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float dba_lds[];            // [D] E[i]  |  keys
+    __shared__ float red[4];
+    const int i = blockIdx.x;
+    const int n = grp_size[i], begin = grp_begin[i];
+    const float* ei = emb + (int64_t)i * D;
+    float* o = out + (int64_t)i * D;
+    int nn = n - 1;
+    if (k >= 0 && k < nn) nn = k;
+    if (nn <= 0) {                                                               // singleton instance or k = 0: kept as is (:21-23)
+        for (int d = threadIdx.x; d < D; d += 256) o[d] = ei[d];
+        return;
+    }
+    float* e_lds = dba_lds;
+    uint64_t* keys = reinterpret_cast<uint64_t*>(dba_lds + ((D + 3) & ~3));
+    int n2 = 2;
+    while (n2 < n) n2 <<= 1;
+    float* wts = reinterpret_cast<float*>(keys + n2);
+    const bool vec4 = (D & 3) == 0 && ((uintptr_t)emb & 15) == 0;
+    for (int d = threadIdx.x; d < D; d += 256) e_lds[d] = ei[d];
+    __syncthreads();
+    for (int t = threadIdx.x; t < n2; t += 256) {
+        uint64_t key = 0;                                                        // padding and the item itself rank last
+        if (t < n) {
+            const int m = order[begin + t];
+            if (m != i) {
+                const float* em = emb + (int64_t)m * D;
+                float acc = 0.0f;
+                if (vec4) {                                                      // 16-B loads, the chain order untouched
+                    const float4* a4 = reinterpret_cast<const float4*>(e_lds);
+                    const float4* b4 = reinterpret_cast<const float4*>(em);
+                    for (int d = 0; d < (D >> 2); ++d) {
+                        const float4 a = a4[d], b = b4[d];
+                        acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+                    }
+                } else {
+                    for (int d = 0; d < D; ++d) acc = fmaf(e_lds[d], em[d], acc);
+                }
+                key = rank_key(acc, (uint32_t)m);
+            }
+        }
+        keys[t] = key;
+    }
+    bitonic_sort_desc<256>(keys, n2);
+    for (int j = threadIdx.x; j < nn; j += 256) wts[j] = (float)((double)(nn - j) / (double)(nn + 1));
+    __syncthreads();
+    float ss = 0.0f;
+    for (int d = threadIdx.x; d < D; d += 256) {
+        float agg = e_lds[d];
+        for (int j = 0; j < nn; ++j) agg = agg + emb[(int64_t)key_idx(keys[j]) * D + d] * wts[j];
+
+        o[d] = agg;
+        ss += agg * agg;
+    }
+    ss = block_sum<256>(ss, red);
+    const float nrm = sqrtf(ss) + 1e-10f;
+    for (int d = threadIdx.x; d < D; d += 256) o[d] = o[d] / nrm;               // each thread re-reads only what it wrote
+}
+
 }  // namespace isx
 
 using namespace isx;
@@ -335,5 +407,22 @@ ISX_API int isx_masked_sums(const float* sim, int64_t M, int64_t N, const int32_
     ISX_REQUIRE(qlab && out && ((sim && glab) || N == 0), "isx_masked_sums: null pointer");
     hipLaunchKernelGGL(masked_row_sums_kernel, dim3((unsigned)M), dim3(RK_THREADS), 0, (hipStream_t)stream, sim, N, qlab, glab, out);
     ISX_CHECK_LAUNCH("isx_masked_sums");
+    return ISX_OK;
+}
+
+// DBA over same-instance groups (reference test/instance_avg.py:7-33).  order: the item indices sorted by (label, index); item i's instance is
+// order[grp_begin[i] .. grp_begin[i] + grp_size[i]).  Groups above 1024 members are refused (the caller walks those label blocks with
+// isx_cosine_sim + isx_rank_full).
+ISX_API int isx_dba_groups(const float* emb, int64_t N, int D, const int32_t* order, const int32_t* grp_begin, const int32_t* grp_size,
+                           int max_group, int k, float* out, isx_stream_t stream) {
+    ISX_REQUIRE(N >= 0 && N < (1ll << 31) && D > 0 && D <= 16384 && max_group >= 0, "isx_dba_groups: bad shape N=%lld D=%d", (long long)N, D);
+    ISX_REQUIRE(max_group <= DBA_MAX_GROUP, "isx_dba_groups: an instance of %d items exceeds the %d the kernel ranks in LDS", max_group, DBA_MAX_GROUP);
+    if (N == 0) return ISX_OK;
+    ISX_REQUIRE(emb && order && grp_begin && grp_size && out && out != emb, "isx_dba_groups: null or aliased pointer");
+    int n2 = 2;
+    while (n2 < max_group) n2 <<= 1;
+    const size_t lds = (size_t)((D + 3) & ~3) * 4 + (size_t)n2 * 12;          // E[i] | keys | weights
+    hipLaunchKernelGGL(dba_group_kernel, dim3((unsigned)N), dim3(256), lds, (hipStream_t)stream, emb, D, order, grp_begin, grp_size, k, out);
+    ISX_CHECK_LAUNCH("isx_dba_groups");
     return ISX_OK;
 }

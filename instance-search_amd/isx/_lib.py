@@ -54,6 +54,7 @@ _SIGNATURES = {
     "isx_average_precision": (C.c_int, [VP, I64, I64, VP, VP, I32, VP, VP]),
     "isx_average_precision_sim": (C.c_int, [VP, I64, I64, VP, VP, I32, VP, VP]),
     "isx_masked_sums": (C.c_int, [VP, I64, I64, VP, VP, VP, VP]),
+    "isx_dba_groups": (C.c_int, [VP, I64, I32, VP, VP, VP, I32, I32, VP, VP]),
     "isx_topk_merge": (C.c_int, [VP, VP, I32, I64, I32, VP, VP, VP]),
     "isx_mine_negatives": (C.c_int, [VP, I64, VP, VP, VP, I64, I32, VP, VP]),
     "isx_mine_negatives_rows": (C.c_int, [VP, I64, I64, I64, VP, VP, VP, I64, I32, VP, VP]),

@@ -31,6 +31,32 @@ def broadcast_module_state(module, src=0, group=None):
             dist.broadcast(t, src=src, group=group)
 
 
+def batch_norm_buffers(module):
+    """Floating-point buffers (running_mean / running_var) of every BatchNorm that is in TRAINING mode under `module`."""
+    out = []
+    for m in module.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.training and m.track_running_stats:
+            out += [b for b in (m.running_mean, m.running_var) if b is not None]
+    return out
+
+
+def average_buffers(buffers, group=None):
+    """Replace each buffer by its mean over the ranks (one flat all-reduce).  Data-parallel training with BatchNorm in training mode
+    (P.train_bn): every rank updates its running statistics from its own slice of the mini-batch; without this the replicas drift apart,
+    mining / evaluation differ per rank and the checkpoint written by rank 0 carries rank 0's statistics only."""
+    if not buffers or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        flat = torch.cat([b.reshape(-1).float() for b in buffers])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= dist.get_world_size(group)
+        off = 0
+        for b in buffers:
+            n = b.numel()
+            b.copy_(flat[off:off + n].view_as(b))
+            off += n
+
+
 class GradAllReducer(object):
     def __init__(self, params, group=None, bucket_mb=256):
         self.params = [p for p in params if p.requires_grad]
@@ -84,7 +110,9 @@ class GradAllReducer(object):
             return
         v = self._view(p)
         if p.grad is not None:
-            v.copy_(p.grad)                 # this step's gradient so far lives in the stray tensor
+            v.copy_(p.grad)                 # this step's gradient so far lives in the stray tensor (whoever detached the view discarded what it held)
+        else:
+            v.zero_()                       # no gradient this step: the slice still holds the PREVIOUS step's summed gradient -- it must not be exchanged and applied again
         p.grad = v
 
     def _attach_all(self):

@@ -544,6 +544,21 @@ def masked_sums(sim, qlab, glab):
     return out
 
 
+DBA_MAX_GROUP = 1024
+
+
+def dba_groups(emb, order, grp_begin, grp_size, max_group, k=-1):
+    """DBA (reference test/instance_avg.py:7-33) over same-instance groups of at most DBA_MAX_GROUP items; see include/isx.h."""
+    emb = _f32(emb, "emb")
+    N, D = emb.shape
+    order, grp_begin, grp_size = (_typed(t, torch.int32, n) for t, n in ((order, "order"), (grp_begin, "grp_begin"), (grp_size, "grp_size")))
+    assert order.numel() == N and grp_begin.numel() == N and grp_size.numel() == N
+    out = torch.empty_like(emb)
+    check(lib().isx_dba_groups(emb.data_ptr(), N, D, order.data_ptr(), grp_begin.data_ptr(), grp_size.data_ptr(), int(max_group), int(k),
+                               out.data_ptr(), _stream()), "isx_dba_groups")
+    return out
+
+
 def topk_merge(scores, idx):
     scores = _f32(scores, "scores")
     idx = _typed(idx, torch.int64, "idx")

@@ -87,6 +87,27 @@ _FUSED_STEM = os.environ.get("ISX_STEM", "1") != "0"       # 0: stem convolution
 _FUSE_PROJECTION = os.environ.get("ISX_FUSE_PROJECTION", "1") != "0"     # last 1x1 conv + projection shortcut as one GEMM
 
 
+def _derived(owner, slot, sources, build):
+    """A tensor derived from weights (`sources`), cached on `owner` under `slot` and rebuilt when a source was written in place
+    (load_state_dict copies into the parameters: the version counter moves), replaced, or moved to another device.  Writes through
+    `.data` bypass the version counter: call `invalidate_derived_weights(module)` after such surgery."""
+    key = tuple((t.data_ptr(), t._version, str(t.device)) for t in sources)
+    hit = owner.__dict__.get(slot)
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = (key, build())
+        owner.__dict__[slot] = hit
+    return hit[1]
+
+
+def invalidate_derived_weights(module):
+    """Drop every cached re-layout of a weight (OHWI copies, concatenated / transposed projection weights) under `module`."""
+    for m in module.modules():
+        for slot in ('_c_w_ohwi', '_c_w_cat', '_c_w3t', '_hwc'):
+            if slot in m.__dict__:
+                m.__dict__[slot] = None
+
+
 class _ConvBiasAct(nn.Module):
     """Bias-free convolution + fused `y = act(y + bias (+ residual))` epilogue (libisx `isx_bias_act_inplace` on
     the GPU, plain torch otherwise)."""
@@ -100,8 +121,12 @@ class _ConvBiasAct(nn.Module):
         self.bias = nn.Parameter(bias, requires_grad=False)
         self.relu = relu
         self.plain = False            # True: no epilogue of its own (projection shortcut, bias merged elsewhere)
-        self._w_ohwi = None           # (Cout,3,3,Cin) copy of a 3x3 weight for the implicit-GEMM kernel, built on first use
         self.in_block = False         # True: a convolution of a BN-folded residual block (_FusedBlock)
+
+    def w_ohwi(self):
+        """(Cout,kh,kw,Cin) copy of the weight for the implicit-GEMM / stem kernels; follows the weight (see _derived)."""
+        w = self.conv.weight
+        return _derived(self, '_c_w_ohwi', (w,), lambda: w.detach().permute(0, 2, 3, 1).contiguous())
 
     def _pointwise(self):
         c = self.conv
@@ -119,11 +144,9 @@ class _ConvBiasAct(nn.Module):
                 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
             # 3x3 convolution on channels-last activations: implicit GEMM on the fp32 matrix cores, epilogue fused
             from isx import ops
-            if self._w_ohwi is None or self._w_ohwi.device != x.device:
-                self._w_ohwi = self.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
             if residual is not None and not residual.is_contiguous(memory_format=torch.channels_last):
                 residual = residual.contiguous(memory_format=torch.channels_last)
-            return ops.conv3x3_nhwc(x, self._w_ohwi, self.bias, self.conv.stride[0], residual, self.relu)
+            return ops.conv3x3_nhwc(x, self.w_ohwi(), self.bias, self.conv.stride[0], residual, self.relu)
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and self._pointwise()
                 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()):
             # 1x1 convolution on channels-last activations: one fp32-MFMA GEMM over the pixels, epilogue fused
@@ -159,10 +182,8 @@ class _StemConvPool(nn.Module):
         if (x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled() and c.conv.out_channels % 4 == 0):
             from isx import ops
             if _FUSED_STEM and ops.stem7x7_pool_applicable(x, c.conv):
-                # 224-wide (or narrower) images: convolution + bias + ReLU + pooling as ONE kernel, nothing in between touches memory
-                if c._w_ohwi is None or c._w_ohwi.device != x.device:
-                    c._w_ohwi = c.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
-                return ops.stem7x7_pool(x, c._w_ohwi, c.bias)
+                # images up to 896 wide: convolution + bias + ReLU + pooling as ONE kernel, nothing in between touches memory
+                return ops.stem7x7_pool(x, c.w_ohwi(), c.bias)
             y = c.conv(x)
             if y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous():
                 return ops.bias_relu_maxpool(y, c.bias)
@@ -198,8 +219,19 @@ class _FusedBlock(nn.Module):
             self.convs[-1].bias = nn.Parameter(self.convs[-1].bias + _ConvBiasAct(downsample, relu=False).bias, requires_grad=False)
             self.downsample = d                                             # projection (its bias lives in the last conv's epilogue)
 
-        self._w_cat = None            # [W_last | W_projection] for the fused last-conv + shortcut GEMM, built on first use
-        self._w3t = None              # transposed expansion weight of the fused conv2 + conv3 kernel, built on first use
+    def w_cat(self):
+        """[W_last | W_projection] (Cout, K1 + K2) for the fused last-conv + shortcut GEMM; follows both weights (see _derived)."""
+        wl, wd = self.convs[-1].conv.weight, self.downsample.conv.weight
+        co = wl.shape[0]
+        return _derived(self, '_c_w_cat', (wl, wd), lambda: torch.cat([wl.detach().reshape(co, -1), wd.detach().reshape(co, -1)], 1).contiguous())
+
+    def w3t(self):
+        """Transposed expansion weight of the fused conv2 + conv3 kernels: [W3 | Wd]^T with a projection shortcut, W3^T without."""
+        wl = self.convs[-1].conv.weight
+        if self.downsample is not None:
+            wd = self.downsample.conv.weight
+            return _derived(self, '_c_w3t', (wl, wd), lambda: self.w_cat().t().contiguous())
+        return _derived(self, '_c_w3t', (wl,), lambda: wl.detach().reshape(wl.shape[0], -1).t().contiguous())
 
     def _fusable_projection(self, x):
         last, d = self.convs[-1], self.downsample
@@ -232,37 +264,28 @@ class _FusedBlock(nn.Module):
             # the shortcut tensor is never materialised
             from isx import ops
             last, d = self.convs[-1], self.downsample
-            if self._w_cat is None or self._w_cat.device != x.device:
-                co = last.conv.out_channels
-                self._w_cat = torch.cat([last.conv.weight.detach().reshape(co, -1), d.conv.weight.detach().reshape(co, -1)], 1).contiguous()
             if self._fusable_expand_dual():
                 # first block of the 64-channel stage: conv2 + conv3 + projection + ReLU as ONE kernel (isx_conv3x3_expand_dual_nhwc)
                 c2 = self.convs[1]
-                if self._w3t is None or self._w3t.device != x.device:
-                    c2._w_ohwi = c2.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
-                    self._w3t = self._w_cat.t().contiguous()
                 t = self.convs[0](x)
                 if not t.is_contiguous(memory_format=torch.channels_last):
                     t = t.contiguous(memory_format=torch.channels_last)
-                return ops.conv3x3_expand_dual_nhwc(t, c2._w_ohwi, c2.bias, x, self._w3t, last.bias, last.relu)
+                return ops.conv3x3_expand_dual_nhwc(t, c2.w_ohwi(), c2.bias, x, self.w3t(), last.bias, last.relu)
             t = x
             for c in self.convs[:-1]:
                 t = c(t)
             if not t.is_contiguous(memory_format=torch.channels_last):
                 t = t.contiguous(memory_format=torch.channels_last)
-            return ops.conv1x1_dual_nhwc(t, x, self._w_cat, last.bias, d.conv.stride[0], last.relu)
+            return ops.conv1x1_dual_nhwc(t, x, self.w_cat(), last.bias, d.conv.stride[0], last.relu)
         if self._fusable_expand(x):
             # Bottleneck with 64 mid channels and an identity shortcut (ResNet stage 1): conv2 + conv3 + residual + ReLU as ONE kernel
             # (libisx isx_conv3x3_expand_nhwc): the mid activation never reaches memory
             from isx import ops
             c2, c3 = self.convs[1], self.convs[2]
-            if self._w3t is None or self._w3t.device != x.device:
-                c2._w_ohwi = c2.conv.weight.detach().permute(0, 2, 3, 1).contiguous()
-                self._w3t = c3.conv.weight.detach().reshape(c3.conv.out_channels, -1).t().contiguous()
             t = self.convs[0](x)
             if not t.is_contiguous(memory_format=torch.channels_last):
                 t = t.contiguous(memory_format=torch.channels_last)
-            return ops.conv3x3_expand_nhwc(t, c2._w_ohwi, c2.bias, c2.conv.stride[0], self._w3t, c3.bias, x, c3.relu)
+            return ops.conv3x3_expand_nhwc(t, c2.w_ohwi(), c2.bias, c2.conv.stride[0], self.w3t(), c3.bias, x, c3.relu)
         idt = x if self.downsample is None else self.downsample(x)
         y = x
         for c in self.convs[:-1]:

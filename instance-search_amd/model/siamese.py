@@ -137,9 +137,11 @@ class _FrozenTrunk(object):
             return features(x)
         if _bn_training(features):
             return features(x)                      # BN statistics are being updated: keep the plain trunk
-        # the folded copy is stale as soon as any weight or BN buffer under `features` is written in place
-        # (load_state_dict, manual surgery): the tensors' version counters are part of the key
-        key = (id(features), str(x.device), tuple(t._version for t in features.state_dict().values()))
+        # the folded copy is stale as soon as any weight or BN buffer under `features` is written in place (load_state_dict, an
+        # optimiser step) or replaced: identity + version counter of every tensor are the key (no state_dict() is built per call;
+        # writes through `.data` bypass the counters -- set `self.folded = None` after such surgery)
+        key = (id(features), str(x.device),
+               tuple((id(t), t._version) for t in features.parameters()), tuple((id(t), t._version) for t in features.buffers()))
         if self.folded is None or self.key != key:
             from .nn_utils import fold_batch_norm
             self.folded = fold_batch_norm(features).to(x.device).to(memory_format=torch.channels_last)

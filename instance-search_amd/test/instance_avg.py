@@ -1,35 +1,85 @@
 """Database-side feature augmentation (DBA), reference test/instance_avg.py:7-33: every
 gallery descriptor is replaced by itself plus a rank-weighted sum of its nearest same-instance
 neighbours, w_j = (n - j) / (n + 1), then renormalised with x / (|x| + 1e-10) (eps OUTSIDE the
-norm here, unlike NormalizeL2).  The reference's per-item Python loop (which no longer runs on
-modern torch: uint8 mask indexing) is restated batched: one similarity matrix, label masking,
-canonical top-k, one gather."""
+norm here, unlike NormalizeL2).
+
+The reference builds the whole N x N similarity matrix and then overwrites every entry of another
+label with -2 (and its per-item Python loop no longer runs on modern torch: uint8 mask indexing).
+Only same-label pairs ever matter, so nothing N x N exists here: the items are grouped by label
+once (one stable sort) and
+  * on the GPU every instance of up to 1024 items goes through ONE launch of libisx `isx_dba_groups`
+    (per item: canonical fma-chain scores against its own instance, canonical ranking, the
+    reference's sequential weighted sum) -- a 100k-row / 10k-label gallery is O(N * D) memory;
+  * larger instances, and the CPU path (--device=-1), walk the label blocks batched BY BLOCK SIZE:
+    the blocks of one size are stacked (G, n, D), scored with one batched product, ranked in
+    canonical order (score descending, index ascending) and aggregated with one gather.
+"""
 import torch
 
-from utils import similarity_matrix
+BLOCK_BUDGET_BYTES = 1 << 30          # scratch of one batch of equally sized label blocks (scores + gathered rows)
+
+
+def _groups(dataset, device):
+    """(lab (N) int64 label ids in first-seen order, order (N) item indices sorted by (label, index), begin (L), count (L))."""
+    table = {}
+    lab = torch.tensor([table.setdefault(l, len(table)) for _, l, _ in dataset], dtype=torch.int64, device=device)
+    order = torch.argsort(lab, stable=True)
+    count = torch.bincount(lab, minlength=len(table))
+    begin = torch.cumsum(count, 0) - count
+    return lab, order, begin, count
+
+
+def _blocks_of_size(emb, out, order, begins, n, k):
+    """Every label block of exactly n items (begins: their starts in `order`): batched scores, canonical ranking, weighted gather."""
+    nn = n - 1 if k < 0 else min(k, n - 1)
+    if nn <= 0:
+        return
+    D = emb.size(1)
+    per_block = (n * n + 2 * n * D) * 4
+    step = max(1, int(BLOCK_BUDGET_BYTES // max(per_block, 1)))
+    ar = torch.arange(n, device=emb.device)
+    j = torch.arange(nn, device=emb.device, dtype=torch.float64)
+    w = ((nn - j) / float(nn + 1)).float()                                     # (nn): the reference's double quotient, rounded to fp32
+    for s in range(0, begins.numel(), step):
+        idx = order[begins[s:s + step, None] + ar[None, :]]                     # (G, n) item indices, ascending inside a block
+        Eg = emb[idx]                                                           # (G, n, D)
+        if Eg.is_cuda:
+            from isx import ops                                                 # the canonical fma-chain scores of isx_cosine_sim, block by block
+            sim = torch.stack([ops.cosine_sim(Eg[b], Eg[b]) for b in range(Eg.size(0))])
+        else:
+            sim = torch.bmm(Eg, Eg.transpose(1, 2))
+        sim.diagonal(dim1=1, dim2=2).fill_(-2.0)                                # the item itself ranks last (reference :24)
+        nb = sim.sort(dim=2, descending=True, stable=True).indices[:, :, :nn]   # local = global index order inside a block: canonical ties
+        agg = Eg.clone()
+        for r in range(nn):                                                     # the reference's order: agg += E[best_r] * w_r
+            agg += torch.gather(Eg, 1, nb[:, :, r, None].expand(-1, -1, D)) * w[r]
+        out[idx.reshape(-1)] = (agg / (agg.norm(dim=2, keepdim=True) + 1e-10)).reshape(-1, D)
 
 
 def instance_avg(device, embeddings, dataset, labels, k=-1):
     n_items = embeddings.size(0)
-    table = {}
-    lab = torch.tensor([table.setdefault(l, len(table)) for _, l, _ in dataset], device=embeddings.device)
-    same = lab[:, None] == lab[None, :]
-    group = same.sum(1) - 1                                        # neighbours available per item
-    n_nb = group if k < 0 else torch.minimum(group, torch.full_like(group, k))
-    kmax = int(n_nb.max().item()) if n_items else 0
-    if kmax <= 0:
+    if n_items == 0 or k == 0:
         return embeddings.clone(), dataset
-    sim = similarity_matrix(embeddings, embeddings).masked_fill(~same, -2.0)
-    sim.fill_diagonal_(-2.0)
-    if sim.is_cuda:
+    lab, order, begin, count = _groups(dataset, embeddings.device)
+    big = 0
+    if embeddings.is_cuda:
         from isx import ops
-        _, nb = ops.topk_rows(sim, min(kmax, 1024))
+        big = ops.DBA_MAX_GROUP
+        small = count <= big
+        gmax = int(count[small].max().item()) if bool(small.any()) else 0
+        if gmax > 1 and bool(small.all()):
+            out = ops.dba_groups(embeddings.float(), order, begin[lab], count[lab], gmax, k)
+            return out.to(embeddings.dtype), dataset
+        if gmax > 1:
+            # mixed: the kernel handles the instances it can rank in LDS (the others see a group of one = kept), the blocks below the rest
+            size_i = torch.where(small[lab], count[lab], torch.ones_like(count[lab]))
+            out = ops.dba_groups(embeddings.float(), order, begin[lab], size_i, gmax, k).to(embeddings.dtype)
+        else:
+            out = embeddings.clone()
     else:
-        nb = sim.sort(dim=1, descending=True, stable=True).indices[:, :kmax]
-    j = torch.arange(nb.size(1), device=embeddings.device)[None, :].float()
-    n = n_nb[:, None].float()
-    w = torch.where(j < n, (n - j) / (n + 1.0), torch.zeros_like(j))           # (N, kmax)
-    agg = embeddings + torch.einsum('nk,nkd->nd', w, embeddings[nb.clamp(min=0)])
-    out = agg / (agg.norm(dim=1, keepdim=True) + 1e-10)
-    keep = (n_nb <= 0)[:, None]
-    return torch.where(keep, embeddings, out), dataset
+        out = embeddings.clone()
+    # label blocks the kernel did not take, batched by block size
+    todo = count > max(big, 1)
+    for n in sorted(set(count[todo].tolist())):
+        _blocks_of_size(embeddings, out, order, begin[(count == n) & todo], int(n), k)
+    return out, dataset

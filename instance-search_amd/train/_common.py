@@ -139,30 +139,52 @@ def stage_batch(batch, trans, device):
 _MIN_DEVICE_BATCH_PIXELS = int(os.environ.get("ISX_MIN_DEVICE_BATCH_PIXELS", str(512 * 224 * 224)))
 
 
-def device_batch_size(P, dataset):
+def _image_pixels(shape):
+    """H * W of an image tensor: (C,H,W) fp32 tensors (C = 1 or 3 leading) or raw (H,W,3) uint8 images (3 trailing)."""
+    if len(shape) != 3:
+        return None
+    if shape[2] == 3 and shape[0] not in (1, 3):
+        return shape[0] * shape[1]
+    return shape[1] * shape[2] if shape[0] in (1, 3) else shape[0] * shape[1]
+
+
+def device_batch_size(P, dataset, shape=None):
+    """Images per trunk launch for images of `shape` (default: the first image's): the caller's P.test_batch_size times the smallest
+    integer that brings the launch to _MIN_DEVICE_BATCH_PIXELS.  Ragged datasets ask per shape bucket (fold_shape_buckets)."""
     bs = int(P.test_batch_size)
     if bs <= 0 or P.cuda_device < 0 or _MIN_DEVICE_BATCH_PIXELS <= 0 or len(dataset) == 0 or not torch.cuda.is_available():
         return bs
-    shape = tuple(dataset[0][0].shape)
-    if len(shape) != 3:
+    pixels = _image_pixels(tuple(dataset[0][0].shape) if shape is None else tuple(shape))
+    if pixels is None:
         return bs
-    pixels = shape[1] * shape[2] if shape[0] in (1, 3) else shape[0] * shape[1]          # (C,H,W) tensors or raw (H,W,3) uint8 images
     return bs * max(1, -(-_MIN_DEVICE_BATCH_PIXELS // max(bs * pixels, 1)))
 
 
 def fold_shape_buckets(f, dataset, batch_size):
     """Call f(indices, items) on batches of SAME-SHAPED images: the dataset is bucketed by image shape (first-seen order,
-    dataset order inside a bucket), every bucket cut into batches of `batch_size`.  The reference walks a ragged region
-    dataset one image per step (train/classif_regions.py:107-132, model/siamese.py:184); bucketing keeps the backbone
-    batched whatever the mix of sizes.  Per-image results are independent, so the order of evaluation does not matter."""
+    dataset order inside a bucket), every bucket cut into batches of `batch_size` -- an int, or a function of the bucket's image
+    shape (device_batch_size per bucket: a small first image must not size the launches of the large ones).  The reference walks a
+    ragged region dataset one image per step (train/classif_regions.py:107-132, model/siamese.py:184); bucketing keeps the backbone
+    batched whatever the mix of sizes.  Per-image results are independent, so the order of evaluation does not matter; a launch the
+    device cannot hold (torch.cuda.OutOfMemoryError) is retried as two halves."""
     buckets = {}
     for i, item in enumerate(dataset):
         buckets.setdefault((tuple(item[0].shape), item[0].dtype), []).append(i)
-    bs = max(int(batch_size), 1)
-    for idx in buckets.values():
-        for s in range(0, len(idx), bs):
-            ii = idx[s:s + bs]
+
+    def run(ii):
+        try:
             f(ii, [dataset[j] for j in ii])
+        except torch.cuda.OutOfMemoryError:
+            if len(ii) == 1:
+                raise
+            torch.cuda.empty_cache()
+            run(ii[:len(ii) // 2])
+            run(ii[len(ii) // 2:])
+
+    for (shape, _), idx in buckets.items():
+        bs = max(int(batch_size(shape) if callable(batch_size) else batch_size), 1)
+        for s in range(0, len(idx), bs):
+            run(idx[s:s + bs])
 
 
 def scatter_rows(slab, indices, rows):

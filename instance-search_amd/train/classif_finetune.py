@@ -39,17 +39,34 @@ def _full_map_pool(net, fmap):
     return tuple(fmap.shape[2:]) == tuple(ks)
 
 
+def fc7_tap(classifier):
+    """classifier[:6] of an AlexNet-style head -- (Dropout, Linear, ReLU, Dropout, Linear, ReLU | Linear(nbClass)), reference
+    model/ModelDefinition.py:31-37 -- i.e. the 4096-d "fc7" activation; raises for heads without that layout (ResNet: one Linear)."""
+    mods = list(classifier)
+    if len(mods) < 7 or not (isinstance(mods[1], nn.Linear) and isinstance(mods[4], nn.Linear) and isinstance(mods[5], nn.ReLU)):
+        raise ValueError('fc7 descriptors need an AlexNet-style classifier (Dropout, Linear, ReLU, Dropout, Linear, ReLU, Linear)')
+    return nn.Sequential(*mods[:6])
+
+
+def fc7_size(classifier):
+    return fc7_tap(classifier)[4].out_features
+
+
 def get_embeddings(net, dataset, device, out_size):
     """(len(dataset), out_size) slab of L2-normalised descriptors on `device`.
     P.embeddings_classify False: pooled convolutional features (classifier stripped for the
-    pass, restored afterwards); True: the class scores.  On the GPU the pool + L2 of a batch is
+    pass, restored afterwards); True: the class scores; P.embeddings_fc7 (extension, AlexNet): classifier[:6].  On the GPU the pool + L2 of a batch is
     one fused kernel (`isx_gap_l2`) writing straight into the slab rows."""
     trans = test_transform(P)
     if trans is None:
         make_resident(dataset, P.cuda_device)           # the set goes to HBM once; batches are device-side row gathers
-    stripped = not P.embeddings_classify
+    fc7 = bool(getattr(P, 'embeddings_fc7', False)) and not P.embeddings_classify
+    stripped = not P.embeddings_classify and not fc7
+    classifier = net.classifier
     if stripped:
-        classifier, net.classifier = net.classifier, nn.Sequential()
+        net.classifier = nn.Sequential()
+    elif fc7:
+        net.classifier = fc7_tap(classifier)                # extension: the 4096-d activation behind the second ReLU (eval mode: Dropout = identity)
     slab = tensor(device, len(dataset), out_size)
 
     def run(slab, i, is_final, batch):
@@ -72,8 +89,7 @@ def get_embeddings(net, dataset, device, out_size):
     try:
         return fold_batches(run, slab, dataset, device_batch_size(P, dataset))
     finally:
-        if stripped:
-            net.classifier = classifier
+        net.classifier = classifier
 
 
 def get_class_net():

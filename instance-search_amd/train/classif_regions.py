@@ -57,7 +57,7 @@ def get_embeddings(net, dataset, device, out_size):
 
     # the reference walks one image at a time (images may differ in size); here images are bucketed by shape and every
     # bucket goes through in batches of P.test_batch_size
-    fold_shape_buckets(run, dataset, device_batch_size(P, dataset))
+    fold_shape_buckets(run, dataset, lambda shape: device_batch_size(P, dataset, shape))
     return slab
 
 

@@ -21,6 +21,9 @@ class Params(object):
         self.test_pre_proc = True
         self.test_trans = None                 # identity when test_pre_proc (images arrive normalised)
         self.embeddings_classify = False
+        # extension (BASELINE configs[0] "AlexNet fc7"): descriptor = classifier[:6], the 4096-d activation behind the second ReLU of the
+        # AlexNet classifier (model/ModelDefinition.py:31-37).  The reference only offers pool5-flat (9216-d) and the class scores.
+        self.embeddings_fc7 = False
         self.feature_dim = 2048
         self.regions_k = 6                     # train/siamese_regions_p.py:98
         # inference entry points fold BatchNorm into the convolutions and fuse the bias/residual/ReLU

@@ -28,7 +28,7 @@ def get_embeddings(net, dataset, device, out_size):
             scatter_rows(slab, indices, net(stage_batch(batch, trans, P.cuda_device)))
 
     # one image per step in the reference; images bucketed by shape share a backbone pass here
-    fold_shape_buckets(run, dataset, device_batch_size(P, dataset))
+    fold_shape_buckets(run, dataset, lambda shape: device_batch_size(P, dataset, shape))
     return slab
 
 

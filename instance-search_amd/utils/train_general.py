@@ -98,6 +98,11 @@ class _Stepper(object):
             dist.all_reduce(t)
             loss = float(t.item())
         optimizer.step()
+        if self.world > 1:
+            # BatchNorm in training mode (P.train_bn): each rank's running statistics saw only its slice -- average them so that the
+            # replicas stay one model (same mining, same evaluation, a checkpoint that is every rank's)
+            from isx.dp import average_buffers, batch_norm_buffers
+            average_buffers(batch_norm_buffers(self.net))
         return loss
 
 

@@ -500,3 +500,50 @@ ISXO_API float isxo_triplet_loss(const float* a, const float* p, const float* n,
     }
     return (float)(size_average ? total / (double)B : total);
 }
+
+
+/* ----------------------------------------------------------------- DBA ---- */
+/* test/instance_avg.py:7-33: every gallery descriptor is replaced by itself plus the rank-weighted sum of its nearest
+ * neighbours WITHIN ITS INSTANCE (same label), renormalised with x / (|x| + 1e-10) -- eps outside the norm here.
+ *   sim = torch.mm(E, E.t())                                  (:11)  canonical fma chain here
+ *   per item i: num_neighbors = #same-label - 1, capped by k when 0 <= k < num_neighbors (:18-20); <= 0 -> kept (:21-23)
+ *   sim[i,i] = -2, other labels = -2, sort descending (:24-26)  -> canonical order (score desc, index asc) over the same-label items
+ *   agg = E[i]; for j < num_neighbors: agg += E[best[j]] * ((num_neighbors - j) / float(num_neighbors + 1))   (:27-30)
+ *   new[i] = agg / (agg.norm() + 1e-10)                        (:31)
+ * emb: (N,D); labels: (N) int32; out: (N,D).  O(N * group) memory: only same-label pairs are ever scored. */
+static int cmp_u64_desc(const void* a, const void* b) {
+    const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return (x < y) - (x > y);
+}
+
+ISXO_API void isxo_dba(const float* emb, int64_t N, int64_t D, const int32_t* labels, int k, float* out) {
+    uint64_t* keys = (uint64_t*)malloc((size_t)(N > 0 ? N : 1) * sizeof(uint64_t));
+    float* agg = (float*)malloc((size_t)(D > 0 ? D : 1) * sizeof(float));
+    for (int64_t i = 0; i < N; ++i) {
+        const float* ei = emb + i * D;
+        int64_t n = 0;
+        for (int64_t m = 0; m < N; ++m) {
+            if (m == i || labels[m] != labels[i]) continue;
+            const float* em = emb + m * D;
+            float acc = 0.0f;
+            for (int64_t d = 0; d < D; ++d) acc = fmaf(ei[d], em[d], acc);
+            keys[n++] = rank_key(acc, (uint64_t)m);
+        }
+        int64_t nn = n;
+        if (k >= 0 && k < nn) nn = k;
+        if (nn <= 0) { memcpy(out + i * D, ei, (size_t)D * sizeof(float)); continue; }
+        qsort(keys, (size_t)n, sizeof(uint64_t), cmp_u64_desc);
+        memcpy(agg, ei, (size_t)D * sizeof(float));
+        for (int64_t j = 0; j < nn; ++j) {
+            const float w = (float)((double)(nn - j) / (double)(nn + 1));
+            const float* eb = emb + (int64_t)(0xFFFFFFFFu - (uint32_t)(keys[j] & 0xFFFFFFFFull)) * D;
+            for (int64_t d = 0; d < D; ++d) agg[d] = agg[d] + eb[d] * w;
+        }
+        double ss = 0.0;
+        for (int64_t d = 0; d < D; ++d) ss += (double)agg[d] * (double)agg[d];
+        const float nrm = (float)sqrt(ss) + 1e-10f;
+        for (int64_t d = 0; d < D; ++d) out[i * D + d] = agg[d] / nrm;
+    }
+    free(keys);
+    free(agg);
+}

@@ -238,3 +238,12 @@ def triplet_loss(a, p, n, margin, normalized=True, size_average=True):
     loss = lib().isxo_triplet_loss(_p(a, F32P), _p(p, F32P), _p(n, F32P), C.c_int64(B), D, C.c_float(margin),
                                    1 if normalized else 0, 1 if size_average else 0, _p(rows, F32P), _p(ga, F32P), _p(gp, F32P), _p(gn, F32P))
     return float(loss), rows, ga, gp, gn
+
+
+def dba(emb, labels, k=-1):
+    """test/instance_avg.py:7-33 restated: (N,D) descriptors, (N) int labels -> (N,D)."""
+    emb = _f32(emb); N, D = emb.shape
+    lab = np.ascontiguousarray(labels, dtype=np.int32)
+    out = np.empty_like(emb)
+    lib().isxo_dba(_p(emb, F32P), C.c_int64(N), C.c_int64(D), _p(lab, I32P), int(k), _p(out, F32P))
+    return out

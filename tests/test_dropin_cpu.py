@@ -336,6 +336,36 @@ def test_entry_points_cpu_plumbing(capsys):
     assert siamese_regions_test.main("synthetic:CLICIDE_video_224sq:n=6:q=3:labels=2:size=288", "alexnet", "", -1, 16, 3, 0) is not None
 
 
+def test_fc7_tap_is_classifier_prefix_pinned_against_torch(capsys):
+    """BASELINE configs[0] "AlexNet fc7" (extension, SURVEY 8 a17 note): descriptor = classifier[:6] of the reference's AlexNet topology
+    (model/ModelDefinition.py:31-37) -- 4096-d, through the second ReLU -- L2-normalised.  Pinned against plain torch on the same net:
+    features -> flatten -> Dropout(eval) -> Linear -> ReLU -> Dropout(eval) -> Linear -> ReLU -> x / sqrt(sum x^2 + 1e-10)."""
+    from test import classif_finetune_test
+    from test._common import load_sets
+    from train import classif_finetune as cf
+    torch.manual_seed(0)
+    spec = "synthetic:CLICIDE_video_224sq:n=12:q=4:labels=3"
+    p1, mAP = classif_finetune_test.main(spec, "alexnet", "", -1, False, 8, 0, fc7=True)
+    assert cf.P.feature_dim == 4096 and cf.P.embeddings_fc7
+    assert "Descriptor (TEST): " in capsys.readouterr().out
+    net = cf.get_class_net().eval()
+    labs = []
+    qs, _ = load_sets(spec, labs)
+    E = cf.get_embeddings(net, qs, -1, 4096)
+    assert tuple(E.shape) == (len(qs), 4096) and len(net.classifier) == 7            # classifier restored after the pass
+    x = torch.stack([im for im, _, _ in qs])
+    with torch.no_grad():
+        f = net.features(x).reshape(len(qs), -1)
+        h = torch.relu(torch.nn.functional.linear(f, net.classifier[1].weight, net.classifier[1].bias))
+        h = torch.relu(torch.nn.functional.linear(h, net.classifier[4].weight, net.classifier[4].bias))
+        want = h / (h.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()
+    assert torch.equal(E, want)
+    # a ResNet head has no fc7: refused loudly, not silently pooled
+    with pytest.raises(ValueError):
+        classif_finetune_test.main("synthetic:CLICIDE_video_224sq:n=4:q=2:labels=2", "resnet50", "", -1, False, 4, 0, fc7=True)
+    cf.P.embeddings_fc7 = False
+
+
 def test_instance_avg_matches_reference_loop():
     """DBA restated batched == the reference's per-item loop (test/instance_avg.py:7-33) replayed here."""
     from test.instance_avg import instance_avg
@@ -362,6 +392,21 @@ def test_instance_avg_matches_reference_loop():
                 agg += E[best[j]] * ((nn_ - j) / float(nn_ + 1))
             want[i] = agg / (agg.norm() + 1e-10)
         np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_instance_avg_blocks_match_oracle_without_nxn():
+    """The CPU path of DBA walks the label blocks batched by block size (no N x N matrix): equal to the oracle's restatement of the
+    reference loop on ragged instance sizes, k below / above the instance sizes, singletons."""
+    from test.instance_avg import instance_avg
+    rng = np.random.default_rng(5)
+    E = rng.standard_normal((120, 24)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    labs = rng.integers(0, 17, 120).astype(np.int32)
+    labs[3] = 99
+    ds = [(None, int(l), None) for l in labs]
+    for k in (-1, 1, 4, 50):
+        got, _ = instance_avg(-1, torch.from_numpy(E), ds, None, k)
+        np.testing.assert_allclose(got.numpy(), O.dba(E, labs, k), rtol=1e-5, atol=1e-6)
 
 
 def test_instance_avg_matches_reference_fixture(golden):

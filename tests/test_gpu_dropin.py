@@ -354,3 +354,79 @@ def test_instance_avg_on_gpu_matches_reference_fixture(golden):
         got, _ = instance_avg(0, E, ds, sorted(set(labs)), k)
         assert got.is_cuda
         np.testing.assert_allclose(host(got), g[key], rtol=1e-5, atol=1e-6, err_msg=key)
+
+
+@pytest.mark.parametrize("N,D,L,k", [(300, 64, 40, -1), (300, 64, 40, 3), (700, 2048, 5, -1), (257, 9, 1, 2), (1500, 32, 1, 4), (2600, 16, 2, -1)])
+def test_instance_avg_groups_kernel_vs_oracle(N, D, L, k):
+    """DBA without the N x N matrix (round-2 VERDICT): one `isx_dba_groups` launch over the same-label groups against the oracle's restatement
+    of the reference loop (test/instance_avg.py:7-33) -- same neighbours (canonical fma-chain scores, canonical ranking), the reference's
+    sequential weighted sum; only the final norm's summation order differs (2e-6).  Groups above 256 items (several members per thread),
+    one item per label, and instances above the kernel's 1024-item limit (label blocks batched by size) are covered."""
+    import oracle as O
+    from test.instance_avg import instance_avg
+    rng = np.random.default_rng(N + D)
+    E = rng.standard_normal((N, D)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    labs = rng.integers(0, L, N).astype(np.int32)
+    labs[0] = L + 7                                                  # a singleton instance: kept as is
+    ds = [(None, "L%d" % l, None) for l in labs]
+    got, _ = instance_avg(0, torch.from_numpy(E).cuda(), ds, None, k)
+    want = O.dba(E, labs, k)
+    np.testing.assert_allclose(host(got), want, rtol=2e-6, atol=2e-7)
+    np.testing.assert_array_equal(host(got)[0], E[0])
+
+
+def test_instance_avg_at_gallery_scale():
+    """100 000 descriptors x 2048, 10 000 instances: nothing N x N is built (the reference's torch.mm(E, E.t()) alone would be 40 GB) --
+    under 1 s and under 2 GB of scratch; spot rows against the oracle restricted to their own instances."""
+    import time
+    import oracle as O
+    from isx import ops
+    from test.instance_avg import instance_avg
+    N, D, L = 100000, 2048, 10000
+    g = torch.Generator(device="cuda").manual_seed(0)
+    E = ops.l2norm_rows(torch.randn(N, D, device="cuda", generator=g))
+    labs = (torch.arange(N) * 7919 % L).tolist()
+    ds = [(None, l, None) for l in labs]
+    instance_avg(0, E[:1000], ds[:1000], None, -1)                   # warm-up
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    t0 = time.perf_counter()
+    out, _ = instance_avg(0, E, ds, None, -1)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    peak = torch.cuda.max_memory_allocated() - base
+    print("DBA 100k x 2048 / 10k labels: %.3f s, %.2f GB peak" % (dt, peak / 2 ** 30))
+    assert dt < 1.0 and peak < 2 * 2 ** 30
+    lab_t = torch.tensor(labs)
+    for l in (0, 1234, L - 1):
+        idx = (lab_t == l).nonzero().flatten()
+        want = O.dba(host(E[idx.cuda()]), np.zeros(len(idx), np.int32), -1)
+        np.testing.assert_allclose(host(out[idx.cuda()]), want, rtol=2e-6, atol=2e-7)
+
+
+def test_folded_trunk_follows_load_state_dict():
+    """Round-2 VERDICT: the re-laid-out weight copies of the folded trunk (OHWI 3x3 / stem weights, [W3 | Wd] of the fused projection
+    GEMMs, transposed expansion weights) were cached on first use and went stale under load_state_dict.  They now follow their source
+    weights: after loading another net's weights into a trunk that has already run, the output is that other net's, bit for bit."""
+    from isx import backbones
+    from model.nn_utils import extract_layers, fold_batch_norm, invalidate_derived_weights
+
+    def folded(seed):
+        f = fold_batch_norm(extract_layers(backbones.resnet50(pretrained=True, seed=seed).eval())[0])
+        return f.cuda().to(memory_format=torch.channels_last)
+    fa, fb = folded(0), folded(1)
+    x = torch.randn(4, 3, 224, 224, device="cuda").contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y0 = fa(x)
+        yb = fb(x)
+        assert not torch.equal(y0, yb)
+        fa.load_state_dict(fb.state_dict())
+        y1 = fa(x)
+        assert torch.equal(y1, yb)
+        # surgery through .data bypasses the version counters: the documented explicit invalidation
+        for p, q in zip(fa.parameters(), folded(2).parameters()):
+            p.data.copy_(q.data)
+        invalidate_derived_weights(fa)
+        assert torch.equal(fa(x), folded(2)(x))

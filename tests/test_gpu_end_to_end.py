@@ -30,7 +30,7 @@ def _restore_global_params():
         m.labels[:] = labs
 
 
-def _calibrated_weights(kind, n_labels, path, feature_dim=0, regions_k=6):
+def _calibrated_weights(kind, n_labels, path, feature_dim=0, regions_k=6, arch="resnet50"):
     """A state dict for `--weights=`: seeded ResNet-50 whose BatchNorm running statistics are CALIBRATED on a batch of the
     synthetic images (one training-mode pass, cumulative average).  With the default identity statistics a random-init
     ResNet-50 maps every image to almost the same descriptor (score spread 1e-4, ranks decided by fp32 rounding): a
@@ -39,7 +39,7 @@ def _calibrated_weights(kind, n_labels, path, feature_dim=0, regions_k=6):
     from model.siamese import DescriptorNet, RegionDescriptorNet, TuneClassif, TuneClassifSub
     from utils.dataset import synthetic_image_set
     torch.manual_seed(0)
-    base = backbones.resnet50(pretrained=True)
+    base = backbones.MODELS[arch](pretrained=True)
     if kind == "classif":
         net = TuneClassif(base, n_labels)
     elif kind == "classif_sub":
@@ -84,7 +84,7 @@ def _run(main, args_gpu, args_cpu, monkeypatch):
     return res_gpu, res_cpu, (qg, gg), (qc, gc), (ql, gl)
 
 
-def _check(res_gpu, res_cpu, emb_gpu, emb_cpu, labs, what):
+def _check(res_gpu, res_cpu, emb_gpu, emb_cpu, labs, what, cos_tol=COS_TOL):
     from isx import ops
     (qg, gg), (qc, gc) = emb_gpu, emb_cpu
     ql, gl = labs
@@ -97,7 +97,7 @@ def _check(res_gpu, res_cpu, emb_gpu, emb_cpu, labs, what):
     print("%s: max|dcos| = %.3g, max|ddesc| = %.3g, score spread %.3g, P@1 %.4f / %.4f, mAP %.6f / %.6f"
           % (what, dcos, ddesc, spread, res_gpu[0], res_cpu[0], res_gpu[1], res_cpu[1]))
     assert spread > 5e-3, "degenerate score matrix (spread %.3g): the comparison would be vacuous" % spread
-    assert dcos <= COS_TOL, "%s: cosine scores differ by %.3g" % (what, dcos)
+    assert dcos <= cos_tol, "%s: cosine scores differ by %.3g (tolerance %.3g)" % (what, dcos, cos_tol)
     # ranked lists: the top-1 gallery item must be the same, except where the CPU path's own two best scores lie closer
     # together than the measured score error (a tie within the arithmetic's resolution; both answers are then the
     # reference's answer under a different summation order)
@@ -107,6 +107,18 @@ def _check(res_gpu, res_cpu, emb_gpu, emb_cpu, labs, what):
         if float(sim_cpu[q, top_c[q]] - sim_cpu[q, top_g[q]]) > 2 * dcos:
             unexplained += 1
     assert unexplained == 0, "%s: %d queries rank a different gallery item first" % (what, unexplained)
+    # the whole head of every ranked list (top 10 of each query, canonical order): position by position the same gallery item,
+    # except where the CPU path's own scores of the two items are closer than the measured score error
+    kk = min(10, sim_cpu.size(1))
+    rank_g = sim_gpu.sort(dim=1, descending=True, stable=True).indices[:, :kk]
+    rank_c = sim_cpu.sort(dim=1, descending=True, stable=True).indices[:, :kk]
+    swaps = bad = 0
+    for q, j in (rank_g != rank_c).nonzero().tolist():
+        swaps += 1
+        if abs(float(sim_cpu[q, rank_c[q, j]] - sim_cpu[q, rank_g[q, j]])) > 2 * dcos:
+            bad += 1
+    print("%s: %d of %d top-%d positions differ, %d beyond 2 x max|dcos|" % (what, swaps, rank_c.numel(), kk, bad))
+    assert bad == 0, "%s: %d ranked positions differ beyond the arithmetic's resolution" % (what, bad)
     if bool((top_g == top_c).all()):
         assert res_gpu[0] == res_cpu[0], "%s: P@1 %r vs %r" % (what, res_gpu[0], res_cpu[0])
     assert abs(res_gpu[1] - res_cpu[1]) <= MAP_TOL, "%s: mAP %r vs %r" % (what, res_gpu[1], res_cpu[1])
@@ -162,3 +174,60 @@ def test_siamese_regions_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
     r = _run(T.main, (spec, "resnet50", w, 0, 128, 6, 0), (spec, "resnet50", w, -1, 128, 6, 0), monkeypatch)
     with capsys.disabled():
         _check(*r, what="siamese_regions_test resnet50 @448 k=6")
+
+
+def _fp64_descriptors(arch, weights, n_labels, spec):
+    """The same net evaluated in float64 (plain torch on the GPU, MIOpen off: im2col + dgemm) on the query and gallery images of `spec`:
+    the arbiter between two fp32 evaluations that disagree by more than the tolerance."""
+    from isx import backbones
+    from model.siamese import TuneClassif
+    from test import _common as C
+    net = TuneClassif(backbones.MODELS[arch](pretrained=True), n_labels)
+    net.load_state_dict(torch.load(weights))
+    net = net.eval().double().cuda()
+    qs, rs = C.load_sets(spec, [])
+    was = torch.backends.cudnn.enabled
+    torch.backends.cudnn.enabled = False
+    try:
+        out = []
+        with torch.no_grad():
+            for ds in (qs, rs):
+                p = net.features(torch.stack([t for t, _, _ in ds]).double().cuda()).mean((2, 3))
+                out.append((p / (p.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()).cpu())
+    finally:
+        torch.backends.cudnn.enabled = was
+    return out
+
+
+def test_classif_finetune_main_resnet152_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
+    """The reference's own backbone (utils/general.py:39-44 admits alexnet | resnet152 only; tables train/global_p.py:47-55): ResNet-152
+    global descriptors through `--device=0` (36-block stage 3: the tile picker / tail split decide most launches) against `--device=-1`.
+    P@1, ranked lists and mAP (1e-4) are held to the same asserts as ResNet-50.  Cosine scores: on this seeded random-init network
+    (50 residual blocks amplify every rounding) the reference's OWN fp32 CPU path is ~1.3e-5 away from a float64 evaluation of the same
+    weights, so no fp32 implementation can be held to 1e-5 against it; the assert is instead that the HIP path stays within twice the
+    CPU path's own distance from the float64 result (measured: 2.0e-5 vs 1.3e-5; ResNet-50: 7.5e-7 vs 5.0e-7, under 1e-5 as asserted
+    in the ResNet-50 tests)."""
+    from test import classif_finetune_test as T
+    w = _calibrated_weights("classif", 10, str(tmp_path / "w.pth"), arch="resnet152")
+    spec = "synthetic:CLICIDE_video_224sq:n=60:q=20:labels=10:struct=70"
+    r = _run(T.main, (spec, "resnet152", w, 0, False, 64, 0), (spec, "resnet152", w, -1, False, 64, 0), monkeypatch)
+    (qg, gg), (qc, gc) = r[2], r[3]
+    q64, g64 = _fp64_descriptors("resnet152", w, 10, spec)
+    cos64 = q64 @ g64.t()
+    e_gpu = float(((qg.double() @ gg.double().t()) - cos64).abs().max())
+    e_cpu = float(((qc.double() @ gc.double().t()) - cos64).abs().max())
+    with capsys.disabled():
+        print("resnet152: max|cos - cos_f64|: HIP path %.3g, torch-CPU fp32 path %.3g" % (e_gpu, e_cpu))
+        _check(*r, what="classif_finetune_test resnet152", cos_tol=max(COS_TOL, e_gpu + e_cpu))
+    assert e_gpu <= max(COS_TOL, 2.0 * e_cpu), "HIP path is %.3g from the float64 result, the CPU fp32 path %.3g" % (e_gpu, e_cpu)
+
+
+def test_classif_finetune_main_fc7_gpu_vs_cpu(monkeypatch, capsys):
+    """BASELINE configs[0] names "AlexNet fc7 descriptors": the fc7 tap (extension: classifier[:6], model/ModelDefinition.py:31-37)
+    on the GPU against the CPU path."""
+    from test import classif_finetune_test as T
+    spec = "synthetic:CLICIDE_video_224sq:n=100:q=30:labels=10:struct=50"
+    r = _run(T.main, (spec, "alexnet", "", 0, False, 32, 0, True), (spec, "alexnet", "", -1, False, 32, 0, True), monkeypatch)
+    assert r[2][0].shape[1] == 4096
+    with capsys.disabled():
+        _check(*r, what="classif_finetune_test alexnet --fc7")

@@ -207,3 +207,12 @@ def test_images_u8_to_f32_matches_torch():
     x = torch.from_numpy(img).permute(0, 3, 1, 2).float().div(255.0)
     ref = (x - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)
     np.testing.assert_array_equal(O.images_u8_to_f32(img, mean, std), ref.numpy())
+
+
+def test_dba_oracle_matches_reference_fixture(golden):
+    """The oracle's restatement of test/instance_avg.py:7-33 against the output of the reference's own function (dba.npz: singleton labels
+    kept, k = -1 / 0 / 1 / 2 / 5)."""
+    g = golden("dba.npz")
+    for key, k in (("kall", -1), ("k0", 0), ("k1", 1), ("k2", 2), ("k5", 5)):
+        np.testing.assert_allclose(O.dba(g["emb"], g["labels"], k), g[key], rtol=2e-6, atol=2e-7, err_msg=key)
+    np.testing.assert_array_equal(O.dba(g["emb"], g["labels"], 0), g["emb"])

@@ -95,7 +95,7 @@ class _TinyNet(nn.Module):
         return (self.one(a), self.one(p), self.one(n)) if self.training and n is not None else self.one(a)
 
 
-def _run_training(rank, world, port, out):
+def _run_training(rank, world, port, out, train_bn=False, save_all=False):
     sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -111,6 +111,7 @@ def _run_training(rank, world, port, out):
     P.cuda_device, P.train_epochs, P.train_batch_size, P.train_micro_batch = -1, 2, 8, 2
     P.train_loss_int, P.train_test_int, P.test_batch_size, P.feature_dim, P.train_seed = 1000, 1000, 8, 8, 5
     P.train_epoch_switch, P.train_pre_proc, P.train_loss_avg = 1, True, False
+    P.train_bn = bool(train_bn)
     g = torch.Generator().manual_seed(1)
     ds = [(torch.randn(3, 8, 8, generator=g), "l%d" % (i % 4), "p%d" % i) for i in range(16)]
     del sd.labels[:]
@@ -134,8 +135,8 @@ def _run_training(rank, world, port, out):
             return real_train_gen(*a2, **k)
         sd.train_gen = seeded_train_gen
     sd.train_siam_triplets_pos_couples(net, ds, (ds[:4], ds), TripletLoss(P.triplet_margin, False), opt)
-    if rank == 0:
-        torch.save({k: v.clone() for k, v in net.state_dict().items()}, out)
+    if rank == 0 or save_all:
+        torch.save({k: v.clone() for k, v in net.state_dict().items()}, out + (".%d" % rank if save_all else ""))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -162,6 +163,22 @@ def test_data_parallel_training_matches_single_process(tmp_path):
         moved += float((a[k].float() - init[k].float()).abs().sum())
     assert moved > 1e-3                                          # training really changed the weights
     assert torch.equal(a["features.1.running_mean"], init["features.1.running_mean"])     # BN frozen (train_bn False)
+
+
+def test_data_parallel_train_bn_keeps_replicas_identical(tmp_path):
+    """P.train_bn under data parallelism (round-2 ADVICE): every rank updates its BatchNorm running statistics from its own slice of
+    the mini-batch; they are averaged after every optimizer step, so the replicas remain ONE model -- identical state_dict on both
+    ranks (weights AND running statistics), statistics that really moved."""
+    out = str(tmp_path / "bn.pt")
+    mp.spawn(_run_training, args=(2, _free_port(), out, True, True), nprocs=2, join=True)
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    torch.manual_seed(0)
+    init = _TinyNet().state_dict()
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert not torch.equal(a["features.1.running_mean"], init["features.1.running_mean"])
+    assert not torch.equal(a["features.1.running_var"], init["features.1.running_var"])
 
 
 def _run_uneven_reducer(rank, world, port, out):
@@ -194,6 +211,18 @@ def _run_uneven_reducer(rank, world, port, out):
     r.finish()
     res["step2"] = r.flat.clone()
     res["views"] = all(r._is_view(p) for p in r.params)
+    # step 3: gradients dropped again, NO reducer.zero_grad(), and the head takes no part in this backward: its slice of the flat
+    # buffer still holds step 2's summed gradient -- it must be exchanged (and handed to the optimizer) as zeros, not once more
+    for p in net.parameters():
+        p.grad = None
+    r.arm()
+    net.features(x).sum().backward()
+    r.finish()
+    lo, hi = r.slices[net.head.weight]
+    res["step3_head"] = r.flat[lo:hi].clone()
+    lo, hi = r.slices[net.features[0].weight]
+    res["step3_conv"] = r.flat[lo:hi].clone()
+    res["views3"] = all(r._is_view(p) for p in r.params)
     res["w0"] = net.head.weight.detach().clone()
     torch.save(res, out + ".%d" % rank)
     dist.barrier()
@@ -209,6 +238,8 @@ def test_grad_all_reducer_uneven_ranks_and_detached_grads(tmp_path):
     assert torch.equal(a["step2"], b["step2"]) and a["views"] and b["views"]
     # step 2 = both ranks' (identical) gradients summed = 2 x step 1's single contribution
     np.testing.assert_allclose(a["step2"].numpy(), 2 * a["step1"].numpy(), rtol=1e-6, atol=1e-7)
+    assert float(a["step3_head"].abs().sum()) == 0.0 and float(b["step3_head"].abs().sum()) == 0.0      # unused parameter: no stale gradient
+    assert torch.equal(a["step3_conv"], b["step3_conv"]) and float(a["step3_conv"].abs().sum()) > 0 and a["views3"] and b["views3"]
 
 
 def test_region_training_runs_and_learns_on_cpu():

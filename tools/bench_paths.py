@@ -35,7 +35,7 @@ def main():
     with torch.no_grad():
         # ---- extraction (fp32, channels-last activations, synthetic images)
         x224 = torch.randn(256, 3, 224, 224, device=dev).to(memory_format=torch.channels_last)
-        x448 = torch.randn(64, 3, 448, 448, device=dev).to(memory_format=torch.channels_last)
+        x448 = torch.randn(128, 3, 448, 448, device=dev).to(memory_format=torch.channels_last)
         from model.nn_utils import fold_batch_norm
 
         def cl(m):
@@ -47,20 +47,30 @@ def main():
         slab = torch.empty(256, 2048, device=dev)
         t = timed(lambda: ops.gap_l2(g.features(x224), out=slab))
         out["extract_global_resnet50_224"] = {"images_per_s": 256 / t}
+        # the reference's own ResNet (utils/general.py:39-44 admits alexnet | resnet152): 23.1 GFLOP of convolutions per 224 x 224 image
+        del g
+        x512 = torch.randn(512, 3, 224, 224, device=dev).to(memory_format=torch.channels_last)
+        g152 = cl(TuneClassif(backbones.resnet152(pretrained=True), 464))
+        slab512 = torch.empty(512, 2048, device=dev)
+        t = timed(lambda: ops.gap_l2(g152.features(x512), out=slab512))
+        out["extract_global_resnet152_224"] = {"images_per_s": 512 / t, "images_per_launch": 512, "gflop_per_image": 23.1,
+                                               "frac_of_f32_mfma_peak": 23.1e9 * 512 / t / 157.3e12}
+        del g152, x512, slab512
         sub = cl(TuneClassifSub(backbones.resnet50(pretrained=True), 464, (7, 7)))
         t = timed(lambda: cr._best_location_descriptors(sub(x448)[0]))
-        out["extract_classif_regions_resnet50_448"] = {"images_per_s": 64 / t, "map": "8x8 locations, 464 classes"}
+        out["extract_classif_regions_resnet50_448"] = {"images_per_s": 128 / t, "images_per_launch": 128, "map": "8x8 locations, 464 classes",
+                                                       "frac_of_f32_mfma_peak": 32.8e9 * 128 / t / 157.3e12}
         dn = cl(DescriptorNet(backbones.resnet50(pretrained=True), 2048, (7, 7)))
         t = timed(lambda: dn(x224))
         out["extract_siamese_descriptor_resnet50_224"] = {"images_per_s": 256 / t, "head": "Linear(100352->2048)"}
         rd = cl(RegionDescriptorNet(backbones.resnet50(pretrained=True), 6, 2048, (7, 7)))
         t = timed(lambda: rd(x448))
-        out["extract_siamese_regions_resnet50_448"] = {"images_per_s": 64 / t, "k": 6}
+        out["extract_siamese_regions_resnet50_448"] = {"images_per_s": 128 / t, "images_per_launch": 128, "k": 6}
         a = cl(TuneClassif(backbones.alexnet(pretrained=True), 464))
         a.classifier = torch.nn.Sequential()
         t = timed(lambda: ops.l2norm_rows(a(x224)))
         out["extract_global_alexnet_224"] = {"images_per_s": 256 / t}
-        del g, sub, dn, rd, a, x224, x448
+        del sub, dn, rd, a, x224, x448
         torch.cuda.empty_cache()
         # ---- retrieval + metrics
         for (M, N) in ((1000, 10000),) + (() if quick else ((1000, 100000),)):
