@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-shard-bench", action="store_true", help="skip the 10k x 125k retrieval-shard side measurement")
     ap.add_argument("--no-kernel-pass", action="store_true", help="skip the instrumented per-kernel pass (roofline objects of the trunk)")
     ap.add_argument("--no-regions-bench", action="store_true", help="skip the BASELINE configs[2] side measurement (region path at 448 x 448)")
+    ap.add_argument("--only-regions", action="store_true", help="run the configs[2] side measurement alone and print it (profiling aid; single GPU)")
     ap.add_argument("--regions-batch", type=int, default=128, help="448 x 448 images per launch of the region path")
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1: keep the result exchange of a step on the main stream (default: on a second stream behind the next step's trunk)")
@@ -235,6 +236,94 @@ def main():
     ev = lambda: torch.cuda.Event(enable_timing=True)
     gemm_ev, gap_ev = [], []
 
+    # side measurement: BASELINE configs[2] -- ResNet-50 region-pooled descriptors (classif_regions path) on 448 x 448 images,
+    # then that config's retrieval leg at 1k queries x 100k gallery rows of those (class-score, 464-d) descriptors
+    def regions_bench():
+        from isx import backbones
+        from model.nn_utils import fold_batch_norm, set_net_train
+        from model.siamese import TuneClassifSub
+        from train import classif_regions as cr
+        Br, n_cls = args.regions_batch, 464
+        torch.manual_seed(0)
+        sub = TuneClassifSub(backbones.MODELS["resnet50"](pretrained=True, seed=0), n_cls, (7, 7))
+        set_net_train(sub, False)
+        sub.features = fold_batch_norm(sub.features)
+        sub = sub.to(dev).to(memory_format=torch.channels_last)
+        x_cpu = synthetic_images(8, size=(3, 448, 448), seed=4321 + rank)
+        x = x_cpu.to(dev).repeat((Br + 7) // 8, 1, 1, 1)[:Br].contiguous(memory_format=torch.channels_last)
+        slab = torch.empty((Br, n_cls), device=dev)
+
+        def run():
+            with torch.no_grad():
+                slab.copy_(cr._best_location_descriptors(sub(x)[0]))       # features -> box pool -> 1x1 classifier -> best location -> L2 -> slab rows
+
+        run(); run()
+        torch.cuda.synchronize()
+        n_it = 5
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(n_it):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms_ = e0.elapsed_time(e1) / n_it              # this rank's launches (no collective in here: a failure on one rank cannot hang the others)
+        # which kernels ran (one instrumented launch): every convolution of the step must be a libisx entry point
+        ops.KERNEL_TIMER = []
+        run()
+        torch.cuda.synchronize()
+        timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
+        fams = {}
+        for name, flop, nbytes, ea, eb in timer:
+            f = fams.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0})
+            f["launches"] += 1; f["ms"] += ea.elapsed_time(eb); f["flop"] += flop
+        for f in fams.values():
+            f["tflops"] = f["flop"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else None
+        conv_flop = sum(f["flop"] for f in fams.values())
+        flop_img = 4.0 * RESNET50_GFLOP_PER_IMAGE * 1e9 + 2.0 * 64 * 2048 * n_cls        # every convolution sees 4x the pixels of 224 x 224; + the 1x1 classifier on 8 x 8 locations
+        ips = Br / (ms_ * 1e-3)
+        assert bool(torch.isfinite(slab).all())
+        res = {"workload": "BASELINE configs[2]: ResNet-50 TuneClassifSub (fp32, BN folded, NHWC) on 448x448 synthetic images -> 8x8 map of %d class scores "
+                           "-> best-location descriptor (train/classif_regions.py:107-132), %d images per launch" % (n_cls, Br),
+               "images_per_s": ips, "ms_per_launch": ms_, "images_per_launch": Br,
+               "roofline": {"bound": "mfma", "achieved": flop_img * ips / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": flop_img * ips / 1e12 / PEAK_F32_MFMA_TFLOPS, "algorithmic_flop_per_image": flop_img, "traffic": None},
+               "libisx_convolution_flop_per_image": conv_flop / Br,
+               "all_convolutions_in_libisx": bool(conv_flop / Br > 0.995 * flop_img),
+               "kernel_families": fams}
+        del sub, x
+        torch.cuda.empty_cache()
+        # retrieval leg of the same config: 1k queries x 100k gallery rows, exact scores + top-k + full-rank AP without a sort
+        Mq, Nr = 1000, 100000
+        Qc, Gc, ql, gl = synthetic_descriptors(Nr, Mq, n_cls, seed=7 + rank)
+        Qd, Gd = ops.l2norm_rows(Qc.to(dev)), ops.l2norm_rows(Gc.to(dev))
+        ql, gl = ql.to(dev), gl.to(dev)
+        simr = torch.empty((Mq, Nr), device=dev)
+
+        def leg(f, n=3):
+            f(); torch.cuda.synchronize()
+            a, b = ev(), ev(); a.record()
+            for _ in range(n):
+                f()
+            b.record(); torch.cuda.synchronize()
+            return a.elapsed_time(b) / n
+        t_sim = leg(lambda: ops.cosine_sim(Qd, Gd, out=simr))
+        t_topk = leg(lambda: ops.topk_rows(simr, k))
+        t_ap = leg(lambda: ops.average_precision_sim(simr, ql, gl))
+        ap = ops.average_precision_sim(simr, ql, gl)
+        res["retrieval_1000x100000"] = {"descriptor_dim": n_cls, "cosine_sim_ms": t_sim, "topk_rows_ms": t_topk, "average_precision_ms": t_ap,
+                                        "total_ms": t_sim + t_topk + t_ap, "dist_per_s": Mq * Nr / ((t_sim + t_topk + t_ap) * 1e-3),
+                                        "cosine_sim_tflops": 2.0 * Mq * Nr * n_cls / (t_sim * 1e-3) / 1e12,
+                                        "cosine_sim_frac_of_f32_mfma_peak": 2.0 * Mq * Nr * n_cls / (t_sim * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                        "mAP": float(ap[~ap.isnan()].mean())}
+        return res
+
+    if args.only_regions:                            # profiling aid: `rocprofv3 --kernel-trace -- python3 bench.py --only-regions` traces this leg alone
+        out_r = regions_bench()
+        if rank == 0:
+            print(json.dumps({"extraction_regions": out_r}), flush=True)
+        return
+
+
     overlap = world > 1 and not args.no_overlap_exchange
     side = torch.cuda.Stream(device=dev) if world > 1 else None
     exch_ev = []
@@ -336,9 +425,11 @@ def main():
             dist.all_reduce(em, op=dist.ReduceOp.MAX)
             exchange_legs = {"query_allgather_ms": float(em[0]), "result_allgather_merge_ms": float(em[1])}
         for name, flop, nbytes, ea, eb in timer:
-            t = trunk.setdefault(name, {"n": 0, "flop": 0.0, "bytes": 0.0, "ms": 0.0, "floor_ms": 0.0})
+            t = trunk.setdefault(name, {"n": 0, "flop": 0.0, "bytes": 0.0, "ms": 0.0, "floor_ms": 0.0, "shapes": {}})
             ms_ = ea.elapsed_time(eb)
             t["n"] += 1; t["flop"] += flop; t["bytes"] += nbytes; t["ms"] += ms_
+            sh = t["shapes"].setdefault((flop, nbytes), [0, 0.0])            # launches of one layer shape share (FLOP, bytes)
+            sh[0] += 1; sh[1] += ms_
             # per-launch roofline floor: the slower of the MFMA time and the HBM time of that launch's algorithmic work
             t["floor_ms"] += max(flop / (PEAK_F32_MFMA_TFLOPS * 1e9), nbytes / (PEAK_HBM_GBS * 1e6))
         if world > 1:
@@ -404,89 +495,7 @@ def main():
                 shard_result = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
 
-    # side measurement: BASELINE configs[2] -- ResNet-50 region-pooled descriptors (classif_regions path) on 448 x 448 images,
-    # then that config's retrieval leg at 1k queries x 100k gallery rows of those (class-score, 464-d) descriptors
     regions_result = None
-
-    def regions_bench():
-        from isx import backbones
-        from model.nn_utils import fold_batch_norm, set_net_train
-        from model.siamese import TuneClassifSub
-        from train import classif_regions as cr
-        Br, n_cls = args.regions_batch, 464
-        torch.manual_seed(0)
-        sub = TuneClassifSub(backbones.MODELS["resnet50"](pretrained=True, seed=0), n_cls, (7, 7))
-        set_net_train(sub, False)
-        sub.features = fold_batch_norm(sub.features)
-        sub = sub.to(dev).to(memory_format=torch.channels_last)
-        x_cpu = synthetic_images(8, size=(3, 448, 448), seed=4321 + rank)
-        x = x_cpu.to(dev).repeat((Br + 7) // 8, 1, 1, 1)[:Br].contiguous(memory_format=torch.channels_last)
-        slab = torch.empty((Br, n_cls), device=dev)
-
-        def run():
-            with torch.no_grad():
-                slab.copy_(cr._best_location_descriptors(sub(x)[0]))       # features -> box pool -> 1x1 classifier -> best location -> L2 -> slab rows
-
-        run(); run()
-        torch.cuda.synchronize()
-        n_it = 5
-        e0, e1 = ev(), ev()
-        e0.record()
-        for _ in range(n_it):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        ms_ = e0.elapsed_time(e1) / n_it              # this rank's launches (no collective in here: a failure on one rank cannot hang the others)
-        # which kernels ran (one instrumented launch): every convolution of the step must be a libisx entry point
-        ops.KERNEL_TIMER = []
-        run()
-        torch.cuda.synchronize()
-        timer, ops.KERNEL_TIMER = ops.KERNEL_TIMER, None
-        fams = {}
-        for name, flop, nbytes, ea, eb in timer:
-            f = fams.setdefault(name, {"launches": 0, "ms": 0.0, "flop": 0.0})
-            f["launches"] += 1; f["ms"] += ea.elapsed_time(eb); f["flop"] += flop
-        for f in fams.values():
-            f["tflops"] = f["flop"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else None
-        conv_flop = sum(f["flop"] for f in fams.values())
-        flop_img = 4.0 * RESNET50_GFLOP_PER_IMAGE * 1e9 + 2.0 * 64 * 2048 * n_cls        # every convolution sees 4x the pixels of 224 x 224; + the 1x1 classifier on 8 x 8 locations
-        ips = Br / (ms_ * 1e-3)
-        assert bool(torch.isfinite(slab).all())
-        res = {"workload": "BASELINE configs[2]: ResNet-50 TuneClassifSub (fp32, BN folded, NHWC) on 448x448 synthetic images -> 8x8 map of %d class scores "
-                           "-> best-location descriptor (train/classif_regions.py:107-132), %d images per launch" % (n_cls, Br),
-               "images_per_s": ips, "ms_per_launch": ms_, "images_per_launch": Br,
-               "roofline": {"bound": "mfma", "achieved": flop_img * ips / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": flop_img * ips / 1e12 / PEAK_F32_MFMA_TFLOPS, "algorithmic_flop_per_image": flop_img, "traffic": None},
-               "libisx_convolution_flop_per_image": conv_flop / Br,
-               "all_convolutions_in_libisx": bool(conv_flop / Br > 0.995 * flop_img),
-               "kernel_families": fams}
-        del sub, x
-        torch.cuda.empty_cache()
-        # retrieval leg of the same config: 1k queries x 100k gallery rows, exact scores + top-k + full-rank AP without a sort
-        Mq, Nr = 1000, 100000
-        Qc, Gc, ql, gl = synthetic_descriptors(Nr, Mq, n_cls, seed=7 + rank)
-        Qd, Gd = ops.l2norm_rows(Qc.to(dev)), ops.l2norm_rows(Gc.to(dev))
-        ql, gl = ql.to(dev), gl.to(dev)
-        simr = torch.empty((Mq, Nr), device=dev)
-
-        def leg(f, n=3):
-            f(); torch.cuda.synchronize()
-            a, b = ev(), ev(); a.record()
-            for _ in range(n):
-                f()
-            b.record(); torch.cuda.synchronize()
-            return a.elapsed_time(b) / n
-        t_sim = leg(lambda: ops.cosine_sim(Qd, Gd, out=simr))
-        t_topk = leg(lambda: ops.topk_rows(simr, k))
-        t_ap = leg(lambda: ops.average_precision_sim(simr, ql, gl))
-        ap = ops.average_precision_sim(simr, ql, gl)
-        res["retrieval_1000x100000"] = {"descriptor_dim": n_cls, "cosine_sim_ms": t_sim, "topk_rows_ms": t_topk, "average_precision_ms": t_ap,
-                                        "total_ms": t_sim + t_topk + t_ap, "dist_per_s": Mq * Nr / ((t_sim + t_topk + t_ap) * 1e-3),
-                                        "cosine_sim_tflops": 2.0 * Mq * Nr * n_cls / (t_sim * 1e-3) / 1e12,
-                                        "cosine_sim_frac_of_f32_mfma_peak": 2.0 * Mq * Nr * n_cls / (t_sim * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                        "mAP": float(ap[~ap.isnan()].mean())}
-        return res
-
     if not args.no_regions_bench:
         try:
             regions_result = regions_bench()
@@ -568,6 +577,12 @@ def main():
                  "achieved_tflops": mf, "algorithmic_GBps": hb,
                  # sum over launches of max(MFMA time, HBM time) / measured time: counts the HBM-bound layers of the family honestly
                  "frac_of_per_launch_rooflines": t["floor_ms"] / t["ms"],
+                 # per layer shape (launches with the same algorithmic FLOP and bytes): which shapes sit furthest below their own roofline
+                 "shapes": sorted(({"launches_per_step": n_ // ksteps, "ms_per_launch": ms_sum / n_, "gflop": fl / 1e9, "mbytes": by / 1e6,
+                                    "tflops": fl / (ms_sum / n_ * 1e-3) / 1e12, "GBps": by / (ms_sum / n_ * 1e-3) / 1e9,
+                                    "frac_of_own_roofline": max(fl / (PEAK_F32_MFMA_TFLOPS * 1e9), by / (PEAK_HBM_GBS * 1e6)) / (ms_sum / n_),
+                                    "ms_above_roofline_per_step": (ms_sum / n_ - max(fl / (PEAK_F32_MFMA_TFLOPS * 1e9), by / (PEAK_HBM_GBS * 1e6))) * (n_ // ksteps)}
+                                   for (fl, by), (n_, ms_sum) in t["shapes"].items()), key=lambda e: -e["ms_above_roofline_per_step"]),
                  "timing": "HIP events on the launch stream, %d instrumented steps after the timed region" % ksteps}
             fam[name] = o
         if gemm_ms is not None:
