@@ -15,7 +15,9 @@ struct Conv3x3Geom { int H, W, Cin, Ho, Wo, stride; };
 
 // accumulators of one (64 TM) x (64 TN) output tile at rows m0.., columns n0.. (every wave has left the LDS when this returns);
 // lds: BK * (64 TM + 64 TN + 2 pads) floats
-template <int TM, int TN, int BK>
+// AHEAD2 (64x64 tiles only): operands requested two k-tiles ahead instead of one (16 more VGPRs: the fused expand kernel has them, the plain
+// 64x64 kernel at six workgroups per CU does not).
+template <int TM, int TN, int BK, bool AHEAD2 = false>
 __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
                                                  const Conv3x3Geom& g, int64_t m0, int64_t n0, f32x16 (&acc)[TM][TN]) {
     constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
@@ -83,14 +85,66 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
         if (ci0 == g.Cin) { ci0 = 0; if (++kw == 3) { kw = 0; ++kh; } }
     };
     const int nk = D / BK;
+    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
+    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+    if (AHEAD2 && TM * TN == 1) {
+        // 64x64 tiles: a k-tile is 16 MFMAs per wave -- 1024 matrix-pipe cycles, ~4000 when four waves share the SIMD -- while a loaded HBM / L2
+        // round trip can take longer (scratch/lab/expand_lab.hip: 6200 -> 5800 cycles per k-tile, fused kernel 2.98 -> 2.95 ms): the operands are
+        // requested TWO k-tiles ahead, in two staging register sets (+16 VGPRs; the LDS stays single-staged)
+        float4 ra2[NA], rb2[BN * BK / 1024];
+        auto stage = [&](float4 (&qa)[NA], float4 (&qb)[BN * BK / 1024], int kt) {
+            load_a();
+#pragma unroll
+            for (int j = 0; j < NA; ++j) qa[j] = ra[j];
+            load_tile<true, BN, BK>(Wt, N, D, n0, kt * BK, qb);
+        };
+        // tile 0 -> LDS; an odd k-tile count runs one k-tile in the plain one-ahead scheme first, so that an even number is left
+        load_a();
+        load_tile<true, BN, BK>(Wt, N, D, n0, 0, rb);
+        store_tile<BM, BK>(As, ra);
+        store_tile<BN, BK>(Bs, rb);
+        __syncthreads();
+        int kt = 0;
+        float4 ra1[NA];
+        if (nk & 1) {
+            if (nk > 1) stage(ra1, rb, 1);
+            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+            __syncthreads();
+            if (nk > 1) {
+                store_tile<BM, BK>(As, ra1);
+                store_tile<BN, BK>(Bs, rb);
+                __syncthreads();
+            }
+            kt = 1;
+        }
+        if (kt < nk) stage(ra1, rb, kt + 1);
+        // steady state, two k-tiles per trip: tile kt is in the LDS, tile kt + 1 on its way to (ra1, rb), tile kt + 2 is requested into (ra2, rb2).
+        // The requests inside the loop are UNCONDITIONAL (hipcc's wait-count pass falls back to vmcnt(0) behind a conditional load, which would
+        // undo the prefetch); those of the last trip point past the last tap / weight column -- range-checked buffer loads, values never used.
+        for (; kt < nk; kt += 2) {
+            stage(ra2, rb2, kt + 2);
+            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+            __syncthreads();
+            store_tile<BM, BK>(As, ra1);
+            store_tile<BN, BK>(Bs, rb);
+            __syncthreads();
+            stage(ra1, rb, kt + 3);
+            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+            __syncthreads();
+            if (kt + 2 < nk) {
+                store_tile<BM, BK>(As, ra2);
+                store_tile<BN, BK>(Bs, rb2);
+                __syncthreads();
+            }
+        }
+        return;
+    }
     load_a();
     load_tile<true, BN, BK>(Wt, N, D, n0, 0, rb);
     store_tile<BM, BK>(As, ra);
     store_tile<BN, BK>(Bs, rb);
     __syncthreads();
 
-    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
-    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk);
         if (more) {
