@@ -148,13 +148,14 @@ def cpu_baseline(args, gallery_cpu, images_cpu):
             return q, sim.topk(min(args.k, G.size(0)), dim=1)
 
     run(2)                                                  # warm caches / thread pool
-    t0 = time.time(); run(4); per = (time.time() - t0) / 4
     nb = images_cpu.size(0)
-    passes = int(max(1, min(16, round((args.cpu_seconds - 6 * per) / max(per * nb, 1e-3)))))   # ~cpu_seconds of work
-    t0 = time.time()
-    for _ in range(passes):
+    passes, t0 = 0, time.time()
+    while True:                                             # whole passes over the sample until ~cpu_seconds of work are done (1 .. 16 passes)
         q, (ts, ti) = run(nb)
-    dt = time.time() - t0
+        passes += 1
+        dt = time.time() - t0
+        if passes >= 16 or dt + dt / passes > args.cpu_seconds:
+            break
     n = passes * nb
     checked = None
     try:                                                    # checker only, outside the timing

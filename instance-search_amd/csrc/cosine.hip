@@ -286,6 +286,21 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     // wherever the grid fills the chip -- 256->1024 + residual 0.90 -> 0.87 ms, 512->2048 + residual 0.85 -> 0.81, 512->256 1.64 -> 1.58 --
     // and 128x64 for Cout = 64.)
     if (g_force_cfg >= 0 && g_force_cfg < 4) best = g_force_cfg;
+    if (epi == 0 && best == 0 && g_force_cfg < 0 && g_tail_split && !m_active) {
+        // Score matrix of FEW query rows against a long gallery (configs[1] / [2] retrieval: 1 000 x 100 000): 8 x 782 tiles of 128x128 are
+        // 6.1 rounds of the 1024 resident workgroups and cost 7 -- the last 112 tiles run alone.  The gallery columns covered by whole rounds
+        // go out as 128x128 tiles, the remaining columns as a second launch of 64x64 tiles (a quarter of the work each, 1536 resident).
+        // Every score is the same k-ordered chain in either tile shape.
+        const int64_t tm_ = (M + 127) / 128, tn_ = (N + 127) / 128, slots = 1024;
+        const int64_t rounds = tm_ * tn_ / slots, rem = tm_ * tn_ - rounds * slots;
+        const int64_t n_big = rounds * slots / tm_ * 128;                  // columns of the whole rounds
+        if (rounds >= 1 && rem > 0 && rem <= slots * 3 / 5 && n_big > 0 && n_big < N && (n_big * D * 4) % 16 == 0) {
+            launch_cfg<2, 2, 16>(aligned, Q, M, G, n_big, D, C, ldc, thr, gmax, st, m_active, epi, relu);
+            launch_cfg<1, 1, 32>(aligned, Q, M, G + n_big * D, N - n_big, D, C + n_big, ldc, thr, gmax, st, m_active, epi, relu);
+            ISX_CHECK_LAUNCH("cosine_gemm");
+            return ISX_OK;
+        }
+    }
     if (best == 0 && split > 0) {
         TileMap big, small;
         big.m_active = small.m_active = nullptr;
