@@ -18,7 +18,9 @@
  *     process-global A/B hooks -- isx_debug_set_gemm_cfg, isx_debug_set_conv_cfg,
  *     isx_debug_set_f16_tile, isx_debug_fast_fallback_rows -- for tests and
  *     scratch/ timing scripts: they force a tile shape for every later call of
- *     the process, never change a result, and are not part of this ABI.)
+ *     the process (relaxed atomics: flipping one while another host thread
+ *     launches is a data-race-free way to get either tile shape), never change a
+ *     result, and are not part of this ABI.)
  *   - return 0 = ISX_OK, <0 = error; isx_last_error() gives a thread-local message
  *   - canonical ranking order everywhere: (score DESCENDING, index ASCENDING),
  *     -0.0 == +0.0; gallery indices must be < 2^32

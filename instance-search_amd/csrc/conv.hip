@@ -223,7 +223,7 @@ static void launch_dual(const float* t, const float* x, int64_t M, const float* 
                        bias, relu);
 }
 
-static int g_force_conv_cfg = -1;
+static std::atomic<int> g_force_conv_cfg{-1};
 
 }  // namespace isx
 
@@ -268,7 +268,7 @@ ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, c
     // fewest idle CUs below that (512->512 at 14x14 with 64 images: 1568 tiles of 64x64 are 1.02 rounds, 784 of 128x64 are 0.77)
     static const float eff3x3[4] = {0.90f, 0.0f, 0.865f, 0.87f};
     int best = pick_tile_cfg(M, N, gemm_tail_split_rows(M, N), eff3x3, 0xD);
-    if (g_force_conv_cfg == 0 || g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
+    { const int fc_ = g_force_conv_cfg; if (fc_ == 0 || fc_ == 2 || fc_ == 3) best = fc_; }
     hipStream_t st = (hipStream_t)stream;
     switch (best) {
         case 0: launch_conv3x3<2, 2, 16>(x, M, w_ohwi, N, g, y, bias, residual, relu ? 1 : 0, st); break;
@@ -301,7 +301,7 @@ ISX_API int isx_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_
     // layer 3 2.54 / 2.54 / 2.75, layer 4 (50 k pixels) 2.55 / 2.48 / 2.72
     static const float eff_dual[4] = {0.92f, 0.0f, 0.885f, 0.85f};                         // layer 1-4 at B = 1024: 128x128 best, then 128x64, then 64x64
     int best = pick_tile_cfg(M, N, gemm_tail_split_rows(M, N), eff_dual, 0xD);
-    if (g_force_conv_cfg == 0 || g_force_conv_cfg == 2 || g_force_conv_cfg == 3) best = g_force_conv_cfg;
+    { const int fc_ = g_force_conv_cfg; if (fc_ == 0 || fc_ == 2 || fc_ == 3) best = fc_; }
     hipStream_t st = (hipStream_t)stream;
     if (best == 0) launch_dual<2, 2, 16>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);
     else if (best == 2) launch_dual<2, 1, 32>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);

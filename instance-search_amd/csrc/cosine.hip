@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 4) void conv1x1_tail_kernel(const float* __res
 }
 
 // rows covered by whole rounds of 128x128 tiles when the rest of the grid is a partial round (0: no split)
-int g_tail_split = 1;
+std::atomic<int> g_tail_split{1};
 int64_t gemm_tail_split_rows(int64_t M, int64_t N) {
     static const bool env_off = [] { const char* e = getenv("ISX_TAIL_SPLIT"); return e && e[0] == '0'; }();      // A/B from the environment
     if (env_off) return 0;
@@ -248,7 +248,7 @@ int pick_tile_cfg(int64_t M, int64_t N, int64_t split, const float* eff, unsigne
     return best;
 }
 
-static int g_force_cfg = -1;            // debug / A-B hook
+static std::atomic<int> g_force_cfg{-1};            // debug / A-B hook
 void set_gemm_cfg(int c) { g_force_cfg = c; }
 
 template <int TM, int TN, int BK>

@@ -617,7 +617,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __rest
     }
 }
 
-static int g_force_f16_tile = -1;        // debug / A-B hook: 0 = 128x128, 1 = 256x256, 2 = 256x256 register-staged (2b), -1 = automatic
+static std::atomic<int> g_force_f16_tile{-1};        // debug / A-B hook: 0 = 128x128, 1 = 256x256, 2 = 256x256 register-staged (2b), -1 = automatic
 
 int launch_gemm_f16(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C, int64_t ldc, const float* thr,
                            uint8_t* gflag, hipStream_t st) {

@@ -1,5 +1,7 @@
 // isx_internal.hpp -- launchers shared between translation units of libisx.
 #pragma once
+#include <atomic>
+
 #include "isx_common.hpp"
 
 namespace isx {
@@ -21,7 +23,7 @@ int launch_conv1x1_gemm(const float* x, int64_t M, const float* w, int64_t N, in
 
 // Tail of a convolution launch in 128x128 tiles: rows covered by whole rounds of 1024 resident workgroups when the rest of the grid is a
 // partial round -- the caller runs the remaining rows as 64x64 tiles in the same grid; 0 = no split.  g_tail_split: debug / A-B switch.
-extern int g_tail_split;
+extern std::atomic<int> g_tail_split;      // (the debug / A-B knobs are relaxed atomics: a test thread may flip them while another thread launches)
 int64_t gemm_tail_split_rows(int64_t M, int64_t N);
 // Tile shape (0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64) with the smallest estimated launch time among those in `mask` (rounds of resident
 // workgroups + tail + per-CU quantisation, cosine.hip); eff[4]: steady-state efficiency per shape of the calling kernel family.

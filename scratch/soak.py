@@ -7,10 +7,10 @@ import oracle as O
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(time.time()))
 g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
-t0 = time.time(); n = {"fast": 0, "conv1": 0, "conv3": 0, "dual": 0, "topk": 0, "sel": 0}
+t0 = time.time(); n = {"fast": 0, "conv1": 0, "conv3": 0, "dual": 0, "topk": 0, "sel": 0, "stem": 0, "pool": 0, "region": 0, "dba": 0, "gemm": 0}
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 while time.time() - t0 < budget:
-    kind = rng.integers(0, 6)
+    kind = rng.integers(0, 11)
     if kind == 0:      # fast vs fp32 search
         M = int(rng.integers(1, 3000)); N = int(rng.integers(300, 200000)); D = int(rng.choice([8, 16, 64, 96, 256, 512, 1024, 2048])); k = int(rng.integers(1, 129))
         if M * N * D > 4e11: continue
@@ -52,11 +52,59 @@ while time.time() - t0 < budget:
         a = ops.cosine_topk(Q, G, k); sim = ops.cosine_sim(Q, G); b = ops.topk_rows(sim, k)
         assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), ("topk", M, N, D, k)
         n["topk"] += 1
-    else:              # topk_rows vs torch (values; ties only by equal scores)
+    elif kind == 5:    # topk_rows vs torch (values; ties only by equal scores)
         M = int(rng.integers(1, 300)); N = int(rng.integers(1, 50000)); k = int(rng.integers(1, min(N, 256) + 1))
         sim = torch.randn(M, N, device="cuda", generator=g)
         s_, i_ = ops.topk_rows(sim, k); ts = torch.topk(sim, k, dim=1).values
         assert torch.equal(s_, ts) and torch.equal(sim.gather(1, i_), s_), ("sel", M, N, k)
         n["sel"] += 1
+    elif kind == 6:    # fused stem incl. column bands (W up to 896) vs oracle
+        B = int(rng.integers(1, 4)); H = int(rng.integers(1, 120)); W = 4 * int(rng.integers(1, 225))
+        x = rng.standard_normal((B, H, W, 3), dtype=np.float32); w = rng.standard_normal((64, 7, 7, 3), dtype=np.float32) * np.float32(147 ** -0.5); b = rng.standard_normal(64, dtype=np.float32)
+        y = ops.stem7x7_pool(dev(x).permute(0, 3, 1, 2), dev(w), dev(b))
+        assert np.array_equal(y.permute(0, 2, 3, 1).cpu().numpy(), O.stem7x7_pool_nhwc(x, w, b)), ("stem", B, H, W)
+        n["stem"] += 1
+    elif kind == 7:    # channels-last box pooling vs oracle
+        B = int(rng.integers(1, 4)); C = 4 * int(rng.integers(1, 80)); kh = int(rng.integers(1, 8)); kw = int(rng.integers(1, 8)); H = kh + int(rng.integers(0, 12)); W = kw + int(rng.integers(0, 12))
+        f = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        ft = dev(f).contiguous(memory_format=torch.channels_last)
+        if not ops.boxpool_s1_applicable_nhwc(ft): continue
+        assert np.array_equal(ops.boxpool_s1_nhwc(ft, kh, kw).cpu().numpy(), O.boxpool_s1(f, kh, kw)), ("pool", B, C, H, W, kh, kw)
+        n["pool"] += 1
+    elif kind == 8:    # channels-last best location / top-k / gather vs the NCHW kernels (themselves pinned against the oracle)
+        B = int(rng.integers(1, 5)); K = int(rng.integers(1, 500)); Hp = int(rng.integers(1, 12)); Wp = int(rng.integers(1, 12)); k = int(rng.integers(1, 9)); C = 4 * int(rng.integers(1, 20)); fs = int(rng.integers(1, 5))
+        cls = rng.standard_normal((B, K, Hp, Wp), dtype=np.float32)
+        if Hp * Wp > 3: cls[:, :, Hp - 1, Wp - 1] = cls[:, :, 0, 0]
+        ct = dev(cls).contiguous(memory_format=torch.channels_last)
+        if not ops._is_nhwc(ct): continue
+        d1, l1 = ops.best_location_desc(ct); d0, l0 = ops.best_location_desc(dev(cls))
+        assert torch.equal(l1, l0) and torch.equal(d1, d0), ("bestloc", B, K, Hp, Wp)
+        i1, s1 = ops.region_topk(ct, k); i0, s0 = ops.region_topk(dev(cls), k)
+        assert torch.equal(i1, i0) and torch.equal(s1, s0), ("region_topk", B, K, Hp, Wp, k)
+        fm = rng.standard_normal((B, C, Hp + fs - 1, Wp + fs - 1), dtype=np.float32); sh = rng.standard_normal(C * fs * fs).astype(np.float32) * 0.05
+        fmt = dev(fm).contiguous(memory_format=torch.channels_last)
+        if ops._is_nhwc(fmt):
+            r1 = ops.region_gather_l2_nhwc(fmt, fs, fs, i1, Wp, dev(np.ascontiguousarray(sh.reshape(C, fs, fs).transpose(1, 2, 0)).reshape(-1)))
+            r0 = ops.region_gather_l2(dev(fm), fs, fs, i0, Wp, dev(sh)).view(B, k, C, fs, fs).permute(0, 1, 3, 4, 2).reshape(B, k, -1)
+            assert torch.allclose(r1, r0, rtol=2e-6, atol=1e-7), ("gather", B, C, Hp, Wp, fs, k)
+        n["region"] += 1
+    elif kind == 9:    # DBA groups kernel vs oracle
+        N = int(rng.integers(1, 1500)); D = int(rng.choice([3, 8, 30, 64, 256])); L = int(rng.integers(1, 60)); k = int(rng.integers(-1, 8))
+        E = rng.standard_normal((N, D)).astype(np.float32); E /= np.linalg.norm(E, axis=1, keepdims=True); labs = rng.integers(0, L, N).astype(np.int32)
+        sys.path.insert(0, "/root/repo/instance-search_amd")
+        from test.instance_avg import instance_avg
+        got, _ = instance_avg(0, dev(E), [(None, int(l), None) for l in labs], None, k)
+        assert np.allclose(got.cpu().numpy(), O.dba(E, labs, k), rtol=2e-6, atol=2e-7), ("dba", N, D, L, k)
+        n["dba"] += 1
+    else:              # score GEMM incl. the few-row split along the gallery and D % 32 != 0, vs the oracle on sampled rows
+        M = int(rng.integers(1, 1200)); N = int(rng.integers(1000, 150000)); D = 4 * int(rng.integers(1, 130))
+        if M * N * D > 3e11: continue
+        Q = torch.randn(M, D, device="cuda", generator=g); G = torch.randn(N, D, device="cuda", generator=g)
+        sim = ops.cosine_sim(Q, G)
+        rows = rng.integers(0, M, 2); cols = np.r_[0:50, N - 200:N]
+        want = O.cosine_sim(Q[rows].cpu().numpy(), G[cols].cpu().numpy()) if hasattr(O, "cosine_sim") else None
+        if want is not None:
+            assert np.array_equal(sim[rows][:, cols].cpu().numpy(), want), ("gemm", M, N, D)
+        n["gemm"] += 1
 torch.cuda.synchronize()
 print("soak OK", n, "in %.0f s" % (time.time() - t0))
