@@ -422,6 +422,13 @@ ISX_API int isx_dba_groups(const float* emb, int64_t N, int D, const int32_t* or
     int n2 = 2;
     while (n2 < max_group) n2 <<= 1;
     const size_t lds = (size_t)((D + 3) & ~3) * 4 + (size_t)n2 * 12;          // E[i] | keys | weights
+    if (lds > 48 * 1024) {                                                        // wide descriptors: raise the dynamic-LDS limit of this kernel (160 KB per CU)
+        ISX_REQUIRE(lds <= 150 * 1024, "isx_dba_groups: D=%d with instances of %d items needs %zu B of LDS", D, max_group, lds);
+        if (hipFuncSetAttribute((const void*)dba_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            isx_set_error("isx_dba_groups: cannot raise the dynamic LDS limit to %zu B", lds);
+            return ISX_ERR_HIP;
+        }
+    }
     hipLaunchKernelGGL(dba_group_kernel, dim3((unsigned)N), dim3(256), lds, (hipStream_t)stream, emb, D, order, grp_begin, grp_size, k, out);
     ISX_CHECK_LAUNCH("isx_dba_groups");
     return ISX_OK;

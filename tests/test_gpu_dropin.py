@@ -356,7 +356,7 @@ def test_instance_avg_on_gpu_matches_reference_fixture(golden):
         np.testing.assert_allclose(host(got), g[key], rtol=1e-5, atol=1e-6, err_msg=key)
 
 
-@pytest.mark.parametrize("N,D,L,k", [(300, 64, 40, -1), (300, 64, 40, 3), (700, 2048, 5, -1), (257, 9, 1, 2), (1500, 32, 1, 4), (2600, 16, 2, -1)])
+@pytest.mark.parametrize("N,D,L,k", [(300, 64, 40, -1), (300, 64, 40, 3), (700, 2048, 5, -1), (257, 9, 1, 2), (1500, 32, 1, 4), (2600, 16, 2, -1), (400, 16384, 3, 2)])
 def test_instance_avg_groups_kernel_vs_oracle(N, D, L, k):
     """DBA without the N x N matrix (round-2 VERDICT): one `isx_dba_groups` launch over the same-label groups against the oracle's restatement
     of the reference loop (test/instance_avg.py:7-33) -- same neighbours (canonical fma-chain scores, canonical ranking), the reference's
