@@ -47,7 +47,7 @@ struct StemGeom { int H, W, Hc, Wc, Hp, Wp, steps, bands; };
 template <int NCB>
 __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restrict__ x, StemGeom g, const float* __restrict__ w_ohwi,
                                                            const float* __restrict__ bias, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(1024))) float lds[2 * ST_BUF_F + ST_W_F + ST_X_F];      // 160 448 B
+    __shared__ __attribute__((aligned(1024))) float lds[2 * ST_BUF_F + ST_W_F + ST_X_F];      // 161 472 B
     float* const in_lds = lds;
     float* const w_lds = lds + 2 * ST_BUF_F;
     float* const x_lds = w_lds + ST_W_F;
