@@ -10,6 +10,8 @@
 // canonical (score desc, index asc) order with no ties left.  Rows up to 4096 columns
 // are sorted entirely in LDS by one workgroup; longer rows sort 4096-key tiles in LDS
 // and finish the large strides with coalesced global compare-exchange passes.
+#include <type_traits>
+
 #include "isx_common.hpp"
 
 namespace isx {
@@ -171,10 +173,14 @@ __global__ __launch_bounds__(RK_THREADS) void average_precision_kernel(const int
 // order by one thread -> bit-identical to the sorted path and to the reference.
 constexpr int AP_MAXP = 32;
 
-__global__ __launch_bounds__(RK_THREADS) void average_precision_sim_kernel(const float* __restrict__ sim, int64_t N,
-                                                                           const int32_t* __restrict__ qlab,
-                                                                           const int32_t* __restrict__ glab, int kth,
-                                                                           double* __restrict__ ap_out) {
+// NT threads per query row; VEC: 16-B loads of the score row and the label array (N % 4 == 0, both 16-B aligned).  One workgroup per row is
+// latency-bound when there are few rows (1 000 queries x 100 000 gallery rows: 256 threads walked 390 dependent load -> compare steps twice,
+// 0.54 ms): few-row launches run 1024 threads per row with four elements per load (25 steps).
+template <int NT, bool VEC>
+__global__ __launch_bounds__(NT) void average_precision_sim_kernel(const float* __restrict__ sim, int64_t N,
+                                                                   const int32_t* __restrict__ qlab,
+                                                                   const int32_t* __restrict__ glab, int kth,
+                                                                   double* __restrict__ ap_out) {
     __shared__ uint64_t pkey[AP_MAXP];
     __shared__ int pcnt[AP_MAXP];
     __shared__ int rk[AP_MAXP];              // thread 0's sort buffer (LDS: runtime-indexed, keeps it out of scratch)
@@ -186,32 +192,66 @@ __global__ __launch_bounds__(RK_THREADS) void average_precision_sim_kernel(const
     if (tid == 0) npos_s = 0;
     if (tid < AP_MAXP) { pcnt[tid] = 0; pkey[tid] = ~0ull; }
     __syncthreads();
-    for (int64_t j = tid; j < N; j += RK_THREADS) {
-        if (glab[j] == q) {
-            const int slot = atomicAdd(&npos_s, 1);
-            if (slot < AP_MAXP) pkey[slot] = rank_key(r[j], (uint32_t)j);
+    auto found = [&](int64_t j, float v) {
+        const int slot = atomicAdd(&npos_s, 1);
+        if (slot < AP_MAXP) pkey[slot] = rank_key(v, (uint32_t)j);
+    };
+    if (VEC) {
+        const int4* g4 = reinterpret_cast<const int4*>(glab);
+        const float4* r4 = reinterpret_cast<const float4*>(r);
+        for (int64_t j4 = tid; j4 < (N >> 2); j4 += NT) {
+            const int4 l = g4[j4];
+            if (l.x == q || l.y == q || l.z == q || l.w == q) {          // rare: the scores are fetched only then
+                const float4 v = r4[j4];
+                if (l.x == q) found(4 * j4, v.x);
+                if (l.y == q) found(4 * j4 + 1, v.y);
+                if (l.z == q) found(4 * j4 + 2, v.z);
+                if (l.w == q) found(4 * j4 + 3, v.w);
+            }
         }
+    } else {
+        for (int64_t j = tid; j < N; j += NT)
+            if (glab[j] == q) found(j, r[j]);
     }
     __syncthreads();
     const int n_lab = npos_s;
     const int64_t n_pos = (int64_t)n_lab - (kth - 1);
     if (n_pos <= 0) { if (tid == 0) ap_out[row] = __longlong_as_double(0x7FF8000000000000ll); return; }
     if (n_lab > AP_MAXP) { if (tid == 0) ap_out[row] = -1.0; return; }
-    // ranks: count, for every positive, the gallery keys above it (unused slots hold ~0: never exceeded)
-    uint64_t pk[AP_MAXP];
-    int cnt[AP_MAXP];
+    // ranks: count, for every positive, the gallery keys above it.  The pass is bound by its 64-bit compares (N x positives per row), so it is
+    // instantiated for 8 / 16 / 32 slots and the row takes the smallest that holds its positives (unused slots hold ~0: never exceeded)
+    auto count_pass = [&](auto np_tag) {
+        constexpr int NP = decltype(np_tag)::value;
+        uint64_t pk[NP];
+        int cnt[NP];
 #pragma unroll
-    for (int p = 0; p < AP_MAXP; ++p) { pk[p] = pkey[p]; cnt[p] = 0; }
-    for (int64_t j = tid; j < N; j += RK_THREADS) {
-        const uint64_t x = rank_key(r[j], (uint32_t)j);
+        for (int p = 0; p < NP; ++p) { pk[p] = pkey[p]; cnt[p] = 0; }
+        if (VEC) {
+            const float4* r4 = reinterpret_cast<const float4*>(r);
+            for (int64_t j4 = tid; j4 < (N >> 2); j4 += NT) {
+                const float4 v = r4[j4];
+                const uint64_t x0 = rank_key(v.x, (uint32_t)(4 * j4)), x1 = rank_key(v.y, (uint32_t)(4 * j4 + 1));
+                const uint64_t x2 = rank_key(v.z, (uint32_t)(4 * j4 + 2)), x3 = rank_key(v.w, (uint32_t)(4 * j4 + 3));
 #pragma unroll
-        for (int p = 0; p < AP_MAXP; ++p) cnt[p] += (x > pk[p]) ? 1 : 0;
-    }
+                for (int p = 0; p < NP; ++p)
+                    cnt[p] += ((x0 > pk[p]) ? 1 : 0) + ((x1 > pk[p]) ? 1 : 0) + ((x2 > pk[p]) ? 1 : 0) + ((x3 > pk[p]) ? 1 : 0);
+            }
+        } else {
+            for (int64_t j = tid; j < N; j += NT) {
+                const uint64_t x = rank_key(r[j], (uint32_t)j);
 #pragma unroll
-    for (int p = 0; p < AP_MAXP; ++p) {
-        const int c = wave_sum(cnt[p]);
-        if (lane == 0 && c) atomicAdd(&pcnt[p], c);
-    }
+                for (int p = 0; p < NP; ++p) cnt[p] += (x > pk[p]) ? 1 : 0;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int c = wave_sum(cnt[p]);
+            if (lane == 0 && c) atomicAdd(&pcnt[p], c);
+        }
+    };
+    if (n_lab <= 8) count_pass(std::integral_constant<int, 8>{});
+    else if (n_lab <= 16) count_pass(std::integral_constant<int, 16>{});
+    else count_pass(std::integral_constant<int, AP_MAXP>{});
     __syncthreads();
     if (tid == 0) {
         // positives in rank order (insertion sort of <= 32 distinct ranks)
@@ -395,7 +435,13 @@ ISX_API int isx_average_precision_sim(const float* sim, int64_t M, int64_t N, co
     ISX_REQUIRE(M >= 0 && N >= 0 && kth >= 1 && M < (1ll << 31) && N <= 0xFFFFFFFFll, "isx_average_precision_sim: bad shape M=%lld N=%lld kth=%d", (long long)M, (long long)N, kth);
     if (M == 0) return ISX_OK;
     ISX_REQUIRE(qlab && ap && ((sim && glab) || N == 0), "isx_average_precision_sim: null pointer");
-    hipLaunchKernelGGL(average_precision_sim_kernel, dim3((unsigned)M), dim3(RK_THREADS), 0, (hipStream_t)stream, sim, N, qlab, glab, kth, ap);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (N % 4 == 0) && ((((uintptr_t)sim | (uintptr_t)glab) % 16) == 0);
+    const bool few_rows = M < 8192 && N >= 32768;                // fewer workgroups than the chip holds AND long rows: more threads per row
+    if (few_rows && vec) hipLaunchKernelGGL((average_precision_sim_kernel<1024, true>), dim3((unsigned)M), dim3(1024), 0, st, sim, N, qlab, glab, kth, ap);
+    else if (few_rows) hipLaunchKernelGGL((average_precision_sim_kernel<1024, false>), dim3((unsigned)M), dim3(1024), 0, st, sim, N, qlab, glab, kth, ap);
+    else if (vec) hipLaunchKernelGGL((average_precision_sim_kernel<RK_THREADS, true>), dim3((unsigned)M), dim3(RK_THREADS), 0, st, sim, N, qlab, glab, kth, ap);
+    else hipLaunchKernelGGL((average_precision_sim_kernel<RK_THREADS, false>), dim3((unsigned)M), dim3(RK_THREADS), 0, st, sim, N, qlab, glab, kth, ap);
     ISX_CHECK_LAUNCH("isx_average_precision_sim");
     return ISX_OK;
 }

@@ -243,6 +243,25 @@ def test_cosine_topk_filtered_chunks(ops, k, order):
         np.testing.assert_array_equal(host(ts), want_s)
 
 
+@pytest.mark.parametrize("M,N,k", [(100, 100000, 100), (37, 65536, 1), (5, 16384 * 3, 256), (1000, 20000, 10), (3, 100003, 7)])
+def test_topk_rows_few_rows_by_segments(ops, M, N, k):
+    """Few query rows against a long gallery (configs[1] / [2] evaluation: 1 000 x 100 000): ops.topk_rows selects per row SEGMENT (the (M, N)
+    matrix viewed as (M S, N / S)) and merges the segment lists with the canonical comparator -- the same lists, bit for bit, as the one-workgroup-
+    per-row launch, ties included."""
+    from isx._lib import check, lib
+    g = torch.Generator(device="cuda").manual_seed(M + k)
+    sim = torch.randn(M, N, device="cuda", generator=g)
+    sim[:, N // 3] = sim[:, 5]                       # ties across segments: the smaller column index ranks first
+    sim[0, :] = 0.25                                 # a whole row of equal scores
+    s1, i1 = ops.topk_rows(sim, k, idx_base=17)
+    s0 = torch.empty((M, k), device="cuda"); i0 = torch.empty((M, k), device="cuda", dtype=torch.int64)
+    check(lib().isx_topk_rows(sim.data_ptr(), M, N, k, 17, s0.data_ptr(), i0.data_ptr(), torch.cuda.current_stream().cuda_stream), "isx_topk_rows")
+    assert torch.equal(i1, i0) and torch.equal(s1.view(torch.int32), s0.view(torch.int32))
+    assert torch.equal(i1[0], torch.arange(k, device="cuda") + 17)
+    assert torch.equal(s1, torch.topk(sim, k, dim=1).values)
+    assert (ops._row_segments(M, N, k) > 0) == (N % 2 == 0 or N % 3 == 0 or N % 5 == 0 or N % 7 == 0)
+
+
 def test_topk_rows_adversarial(ops):
     # ascending scores: every element beats the running threshold (worst case for the filter)
     M, N, k = 3, 10000, 100
@@ -274,7 +293,7 @@ def test_rank_full_and_ap(ops, M, N):
         np.testing.assert_array_equal(ap[~np.isnan(ap)], want[~np.isnan(want)])     # float64, bit-exact
 
 
-@pytest.mark.parametrize("M,N,L", [(12, 40, 6), (9, 1000, 100), (5, 5000, 50), (4, 3000, 3), (20, 10000, 1000)])
+@pytest.mark.parametrize("M,N,L", [(12, 40, 6), (9, 1000, 100), (5, 5000, 50), (4, 3000, 3), (20, 10000, 1000), (7, 40001, 50), (12, 100000, 5000), (3, 16384, 600), (6, 32768, 40), (5, 65536, 8192), (4, 65537, 6000), (9, 10000, 2000)])
 def test_average_precision_sim_equals_sorted_path(ops, M, N, L):
     """Sort-free AP == rank_full + average_precision == oracle, bit for bit (incl. kth > 1, skipped
     queries, tied scores, and rows with > 32 positives that take the fallback)."""
