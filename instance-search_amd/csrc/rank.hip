@@ -171,7 +171,7 @@ __global__ __launch_bounds__(RK_THREADS) void average_precision_kernel(const int
 // positive keys held in registers replaces the full sort.  Per query: <= AP_MAXP positives (more ->
 // ap = -1, the caller uses rank_full + average_precision).  Same float64 terms, summed in rank
 // order by one thread -> bit-identical to the sorted path and to the reference.
-constexpr int AP_MAXP = 32;
+constexpr int AP_MAXP = 256;             // positives per query the sort-free kernel handles (more -> ap = -1: the caller sorts that row)
 
 // NT threads per query row; VEC: 16-B loads of the score row and the label array (N % 4 == 0, both 16-B aligned).  One workgroup per row is
 // latency-bound when there are few rows (1 000 queries x 100 000 gallery rows: 256 threads walked 390 dependent load -> compare steps twice,
@@ -183,14 +183,14 @@ __global__ __launch_bounds__(NT) void average_precision_sim_kernel(const float* 
                                                                    double* __restrict__ ap_out) {
     __shared__ uint64_t pkey[AP_MAXP];
     __shared__ int pcnt[AP_MAXP];
-    __shared__ int rk[AP_MAXP];              // thread 0's sort buffer (LDS: runtime-indexed, keeps it out of scratch)
+    __shared__ double terms[AP_MAXP];        // AP term of the positive that is h-th in rank order (among the counted ones)
     __shared__ int npos_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t row = blockIdx.x;
     const int32_t q = qlab[row];
     const float* r = sim + row * N;
     if (tid == 0) npos_s = 0;
-    if (tid < AP_MAXP) { pcnt[tid] = 0; pkey[tid] = ~0ull; }
+    for (int p = tid; p < AP_MAXP; p += NT) { pcnt[p] = 0; pkey[p] = ~0ull; }
     __syncthreads();
     auto found = [&](int64_t j, float v) {
         const int slot = atomicAdd(&npos_s, 1);
@@ -219,13 +219,14 @@ __global__ __launch_bounds__(NT) void average_precision_sim_kernel(const float* 
     if (n_pos <= 0) { if (tid == 0) ap_out[row] = __longlong_as_double(0x7FF8000000000000ll); return; }
     if (n_lab > AP_MAXP) { if (tid == 0) ap_out[row] = -1.0; return; }
     // ranks: count, for every positive, the gallery keys above it.  The pass is bound by its 64-bit compares (N x positives per row), so it is
-    // instantiated for 8 / 16 / 32 slots and the row takes the smallest that holds its positives (unused slots hold ~0: never exceeded)
-    auto count_pass = [&](auto np_tag) {
+    // instantiated for 8 / 16 / 32 register slots; a row walks its positives in chunks of 32 (one more pass over the L2-resident score row per
+    // chunk) and the last chunk takes the smallest instantiation that holds it (unused slots hold ~0: never exceeded)
+    auto count_pass = [&](auto np_tag, int base) {
         constexpr int NP = decltype(np_tag)::value;
         uint64_t pk[NP];
         int cnt[NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) { pk[p] = pkey[p]; cnt[p] = 0; }
+        for (int p = 0; p < NP; ++p) { pk[p] = (base + p < AP_MAXP) ? pkey[base + p] : ~0ull; cnt[p] = 0; }
         if (VEC) {
             const float4* r4 = reinterpret_cast<const float4*>(r);
             for (int64_t j4 = tid; j4 < (N >> 2); j4 += NT) {
@@ -246,32 +247,39 @@ __global__ __launch_bounds__(NT) void average_precision_sim_kernel(const float* 
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             const int c = wave_sum(cnt[p]);
-            if (lane == 0 && c) atomicAdd(&pcnt[p], c);
+            if (lane == 0 && c && base + p < AP_MAXP) atomicAdd(&pcnt[base + p], c);
         }
     };
-    if (n_lab <= 8) count_pass(std::integral_constant<int, 8>{});
-    else if (n_lab <= 16) count_pass(std::integral_constant<int, 16>{});
-    else count_pass(std::integral_constant<int, AP_MAXP>{});
+    for (int base = 0; base < n_lab; base += 32) {
+        const int left = n_lab - base;
+        if (left <= 8) count_pass(std::integral_constant<int, 8>{}, base);
+        else if (left <= 16) count_pass(std::integral_constant<int, 16>{}, base);
+        else count_pass(std::integral_constant<int, 32>{}, base);
+    }
+    __syncthreads();
+    // every positive p knows its rank pcnt[p] (distinct: canonical keys never tie).  h = the counted positives ranked before it; its term goes
+    // to terms[h] and ONE thread adds the terms in rank order -- the order of the reference's loop, hence the same float64 bits
+    const double dn = (double)n_pos;
+    for (int p = tid; p < n_lab; p += NT) {
+        const int rp = pcnt[p];
+        if (rp < kth - 1) continue;                              // the first kth-1 ranks are skipped entirely
+        int h = 0;
+        for (int o = 0; o < n_lab; ++o) {
+            const int ro = pcnt[o];
+            h += (ro >= kth - 1 && ro < rp) ? 1 : 0;
+        }
+        const int64_t j = rp - (kth - 1);
+        const double recall = (double)(h + 1) / dn, old_recall = (double)h / dn;
+        const double precision = (double)(h + 1) / ((double)j + 1.0);
+        const double old_precision = (j == 0) ? 1.0 : (double)h / (double)j;
+        terms[h] = (recall - old_recall) * ((old_precision + precision) / 2.0);
+    }
     __syncthreads();
     if (tid == 0) {
-        // positives in rank order (insertion sort of <= 32 distinct ranks)
-        for (int p = 0; p < n_lab; ++p) {
-            int v = pcnt[p], i = p;
-            while (i > 0 && rk[i - 1] > v) { rk[i] = rk[i - 1]; --i; }
-            rk[i] = v;
-        }
-        const double dn = (double)n_pos;
+        int counted = 0;
+        for (int p = 0; p < n_lab; ++p) counted += (pcnt[p] >= kth - 1) ? 1 : 0;
         double ap = 0.0;
-        int64_t h = 0;
-        for (int p = 0; p < n_lab; ++p) {
-            if (rk[p] < kth - 1) continue;                       // the first kth-1 ranks are skipped entirely
-            const int64_t j = rk[p] - (kth - 1);
-            const double recall = (double)(h + 1) / dn, old_recall = (double)h / dn;
-            const double precision = (double)(h + 1) / ((double)j + 1.0);
-            const double old_precision = (j == 0) ? 1.0 : (double)h / (double)j;
-            ap += (recall - old_recall) * ((old_precision + precision) / 2.0);
-            ++h;
-        }
+        for (int h = 0; h < counted; ++h) ap += terms[h];
         ap_out[row] = ap;
     }
 }
