@@ -70,6 +70,13 @@ def main():
         a.classifier = torch.nn.Sequential()
         t = timed(lambda: ops.l2norm_rows(a(x224)))
         out["extract_global_alexnet_224"] = {"images_per_s": 256 / t}
+        # BASELINE configs[0]'s descriptor on the GPU (extension): AlexNet fc7 = classifier[:6], 4096-d
+        from train.classif_finetune import fc7_tap
+        a7 = cl(TuneClassif(backbones.alexnet(pretrained=True), 464))
+        a7.classifier = fc7_tap(a7.classifier)
+        t = timed(lambda: ops.l2norm_rows(a7(x224)))
+        out["extract_fc7_alexnet_224"] = {"images_per_s": 256 / t, "descriptor_dim": 4096}
+        del a7
         del sub, dn, rd, a, x224, x448
         torch.cuda.empty_cache()
         # ---- retrieval + metrics
@@ -86,6 +93,18 @@ def main():
                 "cosine_sim_ms": t_sim * 1e3, "tflops": 2.0 * M * N * 2048 / t_sim / 1e12, "dist_per_s": M * N / t_sim,
                 "ap_sort_free_ms": t_ap * 1e3, "p_at_1_ms": t_p1 * 1e3, "rank_full_plus_ap_ms": t_rank * 1e3,
                 "mAP": float(ap[~ap.isnan()].mean())}
+    # DBA (test/instance_avg.py) at gallery scale: 100 000 descriptors, 10 000 instances -- no N x N matrix (isx_dba_groups)
+    if not quick:
+        from test.instance_avg import instance_avg
+        N, L = 100000, 10000
+        E = ops.l2norm_rows(torch.randn(N, 2048, device=dev))
+        ds = [(None, i * 7919 % L, None) for i in range(N)]
+        instance_avg(0, E, ds, None, -1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        instance_avg(0, E, ds, None, -1)
+        torch.cuda.synchronize()
+        out["dba_100000x2048_10000_instances"] = {"seconds": time.perf_counter() - t0, "includes": "label grouping on the host + isx_dba_groups"}
     print(json.dumps(out))
 
 
