@@ -194,6 +194,34 @@ class DescriptorNet(nn.Module):
         x = x.reshape(x.size(0), -1)
         return self.feature_reduc2(_apply_head(self.feature_reduc1, x))
 
+    def _head_only(self, f):
+        """descriptor head + final L2 on trunk features (B, C, h, w) that were computed elsewhere"""
+        return self.feature_reduc2(_apply_head(self.feature_reduc1, f.reshape(f.size(0), -1)))
+
+    def trunk_precomputable(self):
+        """True when precompute_trunk can serve training steps: training mode, every trunk parameter frozen, BatchNorm not learning, GPU."""
+        p = next(self.features.parameters(), None)
+        return bool(self.training and p is not None and p.is_cuda and _frozen(self.features) and not _bn_training(self.features))
+
+    def precompute_trunk(self, *xs):
+        """Training with a FROZEN trunk and frozen BatchNorm (the reference's default, untrained = -1): the trunk output of an image does not
+        depend on the batch it rides in and needs no autograd graph, so the trunk of a whole mini-batch can run as ONE launch of the folded
+        inference trunk instead of once per micro-batch of 8 triplets (24 images: far too few to fill the chip).  Returns the feature tensors
+        of the given image batches (same split), or None when the trunk has to run inside the step (trainable blocks, BatchNorm learning,
+        CPU tensors, eval mode)."""
+        if not self.training or not xs or not all(x.is_cuda and x.dtype == torch.float32 for x in xs):
+            return None
+        if not _frozen(self.features) or _bn_training(self.features) or len(set(tuple(x.shape[1:]) for x in xs)) != 1:
+            return None
+        sizes = [x.size(0) for x in xs]
+        f = self._trunk(self.features, torch.cat(xs, 0))
+        return tuple(f.split(sizes, 0))
+
+    def forward_features(self, f1, f2=None, f3=None):
+        """forward() of training mode on precomputed trunk features: the branches go through the head together, exactly as forward() sends them
+        through trunk + head together (same rows in the same (3 B, F) matrix: same bits)."""
+        return _many(self._head_only, [f for f in (f1, f2, f3) if f is not None])
+
     def forward(self, x1, x2=None, x3=None):
         # the reference runs one trunk pass per branch (model/siamese.py:124-130); the branches share the weights, so with
         # BN in eval mode (samples independent) they go through together here

@@ -67,11 +67,23 @@ class _Stepper(object):
         self.P, self.net, self.make_batch, self.make_loss, self.reducer = P, net, make_batch, make_loss, reducer
         self.rank, self.world = _dp()
 
-    def _accumulate(self, total, start, is_last, triplets, mini_size, batch_args):
+    def _accumulate(self, total, start, is_last, triplets, mini_size, batch_args, pre=None):
         P = self.P
-        inputs, targets = self.make_batch(triplets, len(triplets), **batch_args)
-        loss, loss2 = self.make_loss(self.net(*inputs), targets)
-        share = len(triplets) / float(mini_size)
+        if pre is not None:
+            # trunk features of the whole slice were computed in one launch (frozen trunk): this micro-batch takes its rows
+            feats, targets_all = pre
+            n = len(triplets)
+            out = self.net.forward_features(*[f[start:start + n] for f in feats])
+            targets = [t[start:start + n] if torch.is_tensor(t) and t.dim() > 0 and t.size(0) == feats[0].size(0) else t for t in targets_all]
+            loss, loss2 = self.make_loss(out, targets)
+        else:
+            inputs, targets = self.make_batch(triplets, len(triplets), **batch_args)
+            loss, loss2 = self.make_loss(self.net(*inputs), targets)
+        return self._backward(total, is_last, loss, loss2, len(triplets), mini_size)
+
+    def _backward(self, total, is_last, loss, loss2, k, mini_size):
+        P = self.P
+        share = k / float(mini_size)
         obj = loss * share if P.train_loss_avg else loss
         if loss2 is not None:
             obj = obj + P.train_loss2_alpha * (loss2 * share if P.train_loss2_avg else loss2)
@@ -89,8 +101,21 @@ class _Stepper(object):
         mine = mini_batch[(n * self.rank) // self.world:(n * (self.rank + 1)) // self.world]
         loss = 0.0
         if mine:
+            pre = None
+            if (getattr(self.P, 'train_trunk_per_minibatch', True) and 0 < self.P.train_micro_batch < len(mine)
+                    and getattr(self.net, 'trunk_precomputable', lambda: False)()):
+                # frozen trunk: ONE batch construction for the whole slice (same image / random-negative order as micro-batch by micro-batch)
+                # and one trunk launch; the micro-batches below run the head on their rows of the features
+                rng_state = random.getstate()
+                inputs, targets = self.make_batch(mine, len(mine), **batch_args)
+                feats = self.net.precompute_trunk(*inputs)
+                if feats is not None:
+                    pre = (feats, targets)
+                else:                                # (CPU tensors, ragged shapes): the batch is built again per micro-batch, from the same random state
+                    del inputs, targets
+                    random.setstate(rng_state)
             loss = fold_batches(self._accumulate, 0.0, mine, self.P.train_micro_batch,
-                                add_args={'mini_size': n, 'batch_args': batch_args})
+                                add_args={'mini_size': n, 'batch_args': batch_args, 'pre': pre})
         if self.reducer is not None:
             self.reducer.finish()
         if self.world > 1:

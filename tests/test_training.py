@@ -383,3 +383,39 @@ def test_resident_images_and_frozen_trunk_training_step():
     ref = net.forward_single(xs[0])
     plain = net.feature_reduc2(net.feature_reduc1(net.features(xs[0]).reshape(4, -1)))
     torch.testing.assert_close(ref, plain, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_minibatch_trunk_precompute_is_bit_identical():
+    """Frozen-trunk siamese training (round 3): the trunk of a whole mini-batch runs as ONE launch and the micro-batches run the head on their
+    rows of the features -- the same weights, bit for bit, as one trunk launch per micro-batch (P.train_trunk_per_minibatch = False), after two
+    epochs of SGD with gradient accumulation, semi-hard then hard mining and random fall-back negatives.  (ResNet-50: the whole trunk runs in
+    libisx, whose outputs do not depend on the launch size; a trunk with MIOpen-run layers -- ResNet-18's strided 1x1 shortcuts, AlexNet --
+    is only equal up to MIOpen's per-size algorithm choice.)"""
+    import copy
+    from train import siamese_descriptor as sd
+    from utils.dataset import synthetic_image_set
+    saved = copy.copy(sd.P.__dict__)
+    tr = synthetic_image_set(32, 4, seed=1, structure=0.5)
+    te = synthetic_image_set(8, 4, seed=2, structure=0.5)
+    out = {}
+    try:
+        for per_minibatch in (True, False):
+            torch.manual_seed(0); random.seed(0)
+            P = sd.P
+            P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), 32      # every convolution in libisx: batch-invariant bits
+            P.train_epochs, P.train_batch_size, P.train_micro_batch, P.test_batch_size = 2, 12, 4, 16
+            P.train_loss_int, P.untrained_blocks, P.train_epoch_switch, P.train_lr, P.train_pre_proc = 1000, -1, 1, 1e-2, True
+            P.train_trunk_per_minibatch = per_minibatch
+            net, _ = sd.main(tr, tr, te)
+            assert net.trunk_precomputable() or not net.training
+            out[per_minibatch] = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    finally:
+        sd.P.__dict__.clear(); sd.P.__dict__.update(saved)
+    a, b = out[True], out[False]
+    assert set(a) == set(b)
+    moved = 0.0
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    torch.manual_seed(0)
+    assert any("feature_reduc1" in k for k in a)
