@@ -316,6 +316,10 @@ int isx_triplet_loss_fwd(const float* anchor, const float* pos, const float* neg
  * on rows with loss_rows > 0, zero elsewhere, times `scale`. */
 int isx_triplet_loss_bwd(const float* anchor, const float* pos, const float* neg, const float* loss_rows, int64_t B, int D,
                          float scale, int normalized, float* g_anchor, float* g_pos, float* g_neg, isx_stream_t stream);
+/* The same with the incoming gradient as a device scalar: gradients times scale * scale_dev[0] (no host read-back of grad_output). */
+int isx_triplet_loss_bwd_dev(const float* anchor, const float* pos, const float* neg, const float* loss_rows, int64_t B, int D,
+                             float scale, const float* scale_dev, int normalized, float* g_anchor, float* g_pos, float* g_neg,
+                             isx_stream_t stream);
 
 #ifdef __cplusplus
 }

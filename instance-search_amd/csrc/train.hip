@@ -62,8 +62,9 @@ __global__ __launch_bounds__(256) void triplet_fwd_kernel(const float* __restric
 // `scale` (= grad_output [/ B when size_average]).
 __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restrict__ A, const float* __restrict__ P,
                                                           const float* __restrict__ Ng, const float* __restrict__ loss_rows,
-                                                          int64_t B, int D, float scale, int normalized,
+                                                          int64_t B, int D, float scale, const float* __restrict__ scale_dev, int normalized,
                                                           float* __restrict__ gA, float* __restrict__ gP, float* __restrict__ gN) {
+    if (scale_dev) scale = scale * scale_dev[0];          // grad_output left on the device: no host read-back in the backward pass
     const int64_t total = B * D;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / D;
@@ -121,7 +122,22 @@ ISX_API int isx_triplet_loss_bwd(const float* anchor, const float* pos, const fl
     ISX_REQUIRE(anchor && pos && neg && loss_rows && g_anchor && g_pos && g_neg, "isx_triplet_loss_bwd: null pointer");
     const int64_t total = B * D;
     const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(triplet_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, anchor, pos, neg, loss_rows, B, D, scale, normalized, g_anchor, g_pos, g_neg);
+    hipLaunchKernelGGL(triplet_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, anchor, pos, neg, loss_rows, B, D, scale, (const float*)nullptr, normalized, g_anchor, g_pos, g_neg);
     ISX_CHECK_LAUNCH("isx_triplet_loss_bwd");
+    return ISX_OK;
+}
+
+// The same with the incoming gradient as a DEVICE scalar: every gradient is multiplied by scale * scale_dev[0].  autograd hands grad_output over as
+// a device tensor; reading it on the host costs a synchronisation per micro-batch of the training step.
+ISX_API int isx_triplet_loss_bwd_dev(const float* anchor, const float* pos, const float* neg, const float* loss_rows, int64_t B, int D,
+                                     float scale, const float* scale_dev, int normalized, float* g_anchor, float* g_pos, float* g_neg,
+                                     isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && D > 0, "isx_triplet_loss_bwd_dev: bad shape B=%lld D=%d", (long long)B, D);
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(anchor && pos && neg && loss_rows && scale_dev && g_anchor && g_pos && g_neg, "isx_triplet_loss_bwd_dev: null pointer");
+    const int64_t total = B * D;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(triplet_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, anchor, pos, neg, loss_rows, B, D, scale, scale_dev, normalized, g_anchor, g_pos, g_neg);
+    ISX_CHECK_LAUNCH("isx_triplet_loss_bwd_dev");
     return ISX_OK;
 }

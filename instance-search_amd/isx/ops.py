@@ -658,10 +658,17 @@ def triplet_loss_rows(anchor, pos, neg, margin, normalized=True):
     return rows
 
 
-def triplet_loss_grads(anchor, pos, neg, loss_rows, scale, normalized=True):
+def triplet_loss_grads(anchor, pos, neg, loss_rows, scale, normalized=True, scale_dev=None):
+    """scale_dev: optional 1-element float32 CUDA tensor (autograd's grad_output) multiplied in on the device -- no host synchronisation."""
     anchor, pos, neg = _f32(anchor, "anchor"), _f32(pos, "pos"), _f32(neg, "neg")
     B, D = anchor.shape
     ga, gp, gn = torch.empty_like(anchor), torch.empty_like(anchor), torch.empty_like(anchor)
+    if scale_dev is not None:
+        sd_ = _f32(scale_dev.reshape(-1), "scale_dev")
+        check(lib().isx_triplet_loss_bwd_dev(anchor.data_ptr(), pos.data_ptr(), neg.data_ptr(), _f32(loss_rows, "loss_rows").data_ptr(), B, D,
+                                             float(scale), sd_.data_ptr(), 1 if normalized else 0, ga.data_ptr(), gp.data_ptr(), gn.data_ptr(), _stream()),
+              "isx_triplet_loss_bwd_dev")
+        return ga, gp, gn
     check(lib().isx_triplet_loss_bwd(anchor.data_ptr(), pos.data_ptr(), neg.data_ptr(), _f32(loss_rows, "loss_rows").data_ptr(), B, D,
                                      float(scale), 1 if normalized else 0, ga.data_ptr(), gp.data_ptr(), gn.data_ptr(), _stream()),
           "isx_triplet_loss_bwd")

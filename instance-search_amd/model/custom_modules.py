@@ -122,6 +122,12 @@ class _Triplet(Function):
     def backward(ctx, grad_output):
         a, p, n, rows = ctx.saved_tensors
         size_average, normalized = ctx.cfg
+        if a.is_cuda and grad_output.is_cuda:
+            # grad_output stays on the device (a host read-back here is one synchronisation per micro-batch of the training step)
+            from isx import ops
+            ga, gp, gn = ops.triplet_loss_grads(a, p, n, rows, 1.0 / a.size(0) if size_average else 1.0, normalized,
+                                                scale_dev=grad_output.detach().float())
+            return ga, gp, gn, None, None, None
         scale = float(grad_output.reshape(-1)[0]) / (a.size(0) if size_average else 1)
         if a.is_cuda:
             from isx import ops

@@ -90,7 +90,7 @@ class _Stepper(object):
         if self.reducer is not None and is_last:
             self.reducer.arm()                       # exchange buckets as this last backward fills them
         obj.backward()
-        return total + float(obj.detach().reshape(-1)[0])
+        return total + obj.detach().reshape(-1)[0]    # a device scalar: the step reads the running loss back once, not per micro-batch
 
     def step(self, optimizer, mini_batch, batch_args):
         if self.reducer is not None:
@@ -119,10 +119,11 @@ class _Stepper(object):
         if self.reducer is not None:
             self.reducer.finish()
         if self.world > 1:
-            t = torch.tensor([loss], dtype=torch.float64, device=next(self.net.parameters()).device)
+            t = (loss.double() if torch.is_tensor(loss) else torch.tensor(loss, dtype=torch.float64)).reshape(1).to(next(self.net.parameters()).device)
             dist.all_reduce(t)
-            loss = float(t.item())
+            loss = t
         optimizer.step()
+        loss = float(loss)                            # the one read-back of the step (after the optimizer has been enqueued)
         if self.world > 1:
             # BatchNorm in training mode (P.train_bn): each rank's running statistics saw only its slice -- average them so that the
             # replicas stay one model (same mining, same evaluation, a checkpoint that is every rank's)
