@@ -20,10 +20,11 @@ Rank 0 prints ONE JSON line (metric / value / roofline / cpu_baseline ...).  The
 per-kernel instrumentation; the per-kernel HIP-event timings behind the `roofline*` objects come from a
 separate instrumented pass over the same step.
 
-N > 1: the result exchange of step i (all-gather of the per-shard top-k lists + isx_topk_merge) is issued on a second
-HIP stream and rides behind the trunk of step i + 1 (`--no-overlap-exchange` serialises it again); `exchange_ms` is what
-the query all-gather, the two result all-gathers and the merge cost when nothing hides them (HIP events in the
-instrumented pass), `overlap_identical` says that both schedules returned the same bits.  `cpu_baseline` is timed on
+N > 1: the search stage of step i (all-gather of the query descriptors, score GEMM against this rank's shard, top-k, all-gather of the
+per-shard lists + isx_topk_merge) is issued on a second HIP stream behind an event and rides behind the trunk of step i + 1
+(`--no-overlap-exchange` keeps everything on one stream); `exchange_ms` is what the query all-gather, the two result all-gathers
+and the merge cost when nothing hides them (HIP events in the instrumented pass), `overlap_identical` says that both
+schedules returned the same bits.  `cpu_baseline` is timed on
 rank 0 at every N (the other ranks wait at the barrier).
 
 Side objects of the same line (each bounded to a few seconds; a failure in one is reported inside it and never costs the
@@ -70,7 +71,8 @@ def parse():
     ap.add_argument("--only-regions", action="store_true", help="run the configs[2] side measurement alone and print it (profiling aid; single GPU)")
     ap.add_argument("--regions-batch", type=int, default=128, help="448 x 448 images per launch of the region path")
     ap.add_argument("--no-overlap-exchange", action="store_true",
-                    help="N > 1: keep the result exchange of a step on the main stream (default: on a second stream behind the next step's trunk)")
+                    help="N > 1: keep the search stage of a step (query all-gather, GEMM, top-k, result exchange) on the main stream "
+                         "(default: on a second stream behind the next step's trunk)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -337,10 +339,37 @@ def main():
         dist.all_gather_into_tensor(all_i.view(-1, k), i)
         return ops.topk_merge(all_s, all_i)
 
+    # deferred mode (N > 1): everything behind the descriptors of a step -- query all-gather, score GEMM, top-k, result all-gathers, merge -- is
+    # issued on the side stream behind an event, with its own score buffer and two alternating descriptor buffers; the main stream goes
+    # straight on to the trunk of the next step, which hides the collectives' latencies and the search's low-occupancy tails
+    q_bufs = [torch.empty((B, D), device=dev) for _ in range(2)] if world > 1 else None
+    q_free = [None, None]                          # side-stream event: the query all-gather that read buffer b has completed
+    sim_side = torch.empty((M, Ng), device=dev) if world > 1 else None
+    slot_box = [0]
+
+    def search(Q_local, sim_buf, timed, marks):
+        """query block of every rank -> scores against this rank's shard -> per-shard top-k [-> exchange + merge]"""
+        if timed:
+            x0, x1 = ev(), ev(); x0.record()
+        Q = retrieval.gather_queries(Q_local)
+        if timed:
+            x1.record()
+            c, d = ev(), ev(); c.record()
+        ops.cosine_sim(Q, shard, out=sim_buf)
+        if timed:
+            d.record(); gemm_ev.append((c, d))
+        s, i = ops.topk_rows(sim_buf, k, idx_base=gallery.idx_base)
+        if world > 1:
+            if timed:
+                x2, x3 = ev(), ev(); x2.record()
+            s, i = exchange(s, i)
+            if timed:
+                x3.record(); exch_ev.append((x0, x1, x2, x3))
+        return s, i
+
     def step(timed, deferred=False):
         """One step.  `timed`: the instrumented pass (HIP events around the pool, the GEMM and the exchange legs on torch's current
-        stream, which is the stream every libisx launch goes to).  `deferred` (N > 1): the result exchange is issued on the side stream
-        behind an event; the main stream is free for the next step's trunk."""
+        stream, which is the stream every libisx launch goes to).  `deferred` (N > 1): the search stage of the step runs on the side stream."""
         with torch.no_grad():
             if args.backbone_dtype == "bf16":
                 with torch.autocast("cuda", dtype=torch.bfloat16):
@@ -348,35 +377,26 @@ def main():
                 fmap = fmap.float()
             else:
                 fmap = net.features(images)
+        if world > 1 and deferred:
+            b2 = slot_box[0]
+            slot_box[0] ^= 1
+            if q_free[b2] is not None:
+                torch.cuda.current_stream().wait_event(q_free[b2])      # the search two steps back has read this descriptor buffer
+            ops.gap_l2(fmap, out=q_bufs[b2])
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                out = search(q_bufs[b2], sim_side, False, None)
+                q_free[b2] = torch.cuda.Event()
+                q_free[b2].record(side)
+            return out
         if timed:
             a, b = ev(), ev(); a.record()
         ops.gap_l2(fmap, out=q_local)
         if timed:
             b.record(); gap_ev.append((a, b))
-            x0, x1 = ev(), ev(); x0.record()
-        Q = retrieval.gather_queries(q_local)
-        if timed:
-            x1.record()
-            c, d = ev(), ev(); c.record()
-        ops.cosine_sim(Q, shard, out=sim)
-        if timed:
-            d.record(); gemm_ev.append((c, d))
-        s, i = ops.topk_rows(sim, k, idx_base=gallery.idx_base)
-        if world > 1:
-            if deferred:
-                ready = torch.cuda.Event()
-                ready.record()
-                with torch.cuda.stream(side):
-                    side.wait_event(ready)
-                    s.record_stream(side); i.record_stream(side)
-                    s, i = exchange(s, i)
-            else:
-                if timed:
-                    x2, x3 = ev(), ev(); x2.record()
-                s, i = exchange(s, i)
-                if timed:
-                    x3.record(); exch_ev.append((x0, x1, x2, x3))
-        return s, i
+        return search(q_local, sim, timed, None)
 
     for _ in range(args.warmup):
         step(False, overlap)
@@ -618,8 +638,8 @@ def main():
             line["exchange_ms"] = tot
             line["exchange"] = dict(ex, exposed_when_serialised_frac_of_step=(tot / ms_per_step if tot is not None else None),
                                     overlapped=overlap, overlap_identical=overlap_identical,
-                                    legs="query all-gather (on the critical path) | per-shard top-k all-gather x 2 + isx_topk_merge"
-                                         + (" (on a second stream behind the next step's trunk)" if overlap else ""),
+                                    legs="query all-gather | per-shard top-k all-gather x 2 + isx_topk_merge"
+                                         + (" (with the score GEMM and the top-k between them on a second stream, behind the next step's trunk)" if overlap else ""),
                                     timing="HIP events on the launch stream, max over ranks, %d instrumented steps with the exchange in line" % ksteps)
         if not args.no_cpu_baseline:                 # rank 0 at every N; the other ranks wait at the barrier below
             try:
