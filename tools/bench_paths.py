@@ -89,6 +89,17 @@ def main():
             t_p1 = timed(lambda: ops.topk_rows(sim, 1))
             t_rank = timed(lambda: ops.average_precision(ops.rank_full(sim), ql, gl), n=2)
             ap = ops.average_precision_sim(sim, ql, gl).cpu()
+            # top-k only (no full score matrix): the exact search with the fp16-MFMA filter vs scores + top-k
+            from isx import retrieval
+            gal = retrieval.ShardedGallery(G, 0)
+            gal.search(Q, 100)
+            t_fast = timed(lambda: gal.search(Q, 100))
+            fs, fi = gal.search(Q, 100)
+            ps, pi = ops.topk_rows(sim, 100)
+            same = bool(torch.equal(fi, pi) and torch.equal(fs.view(torch.int32), ps.view(torch.int32)))
+            t_top = timed(lambda: ops.topk_rows(sim, 100))
+            out["search_top100_%dx%d" % (M, N)] = {"cosine_topk_fast_ms": t_fast * 1e3, "cosine_sim_plus_topk_rows_ms": (t_sim + t_top) * 1e3,
+                                                    "identical": same}
             out["retrieval_%dx%d" % (M, N)] = {
                 "cosine_sim_ms": t_sim * 1e3, "tflops": 2.0 * M * N * 2048 / t_sim / 1e12, "dist_per_s": M * N / t_sim,
                 "ap_sort_free_ms": t_ap * 1e3, "p_at_1_ms": t_p1 * 1e3, "rank_full_plus_ap_ms": t_rank * 1e3,
