@@ -319,7 +319,7 @@ def boxpool_s1_applicable_nhwc(fmap):
 def boxpool_s1_nhwc(fmap, kh, kw):
     """AvgPool2d((kh,kw), stride 1) of a channels-last (B,C,H,W) map, result channels-last: no transpose on the way in or out."""
     if not boxpool_s1_applicable_nhwc(fmap):
-        raise _lib.IsxError("fmap must be a channels-last float32 CUDA tensor (B,C,H,W) with C % 4 == 0 and H*W <= 1024")
+        raise _lib.IsxError("fmap must be a channels-last float32 CUDA tensor (B,C,H,W) with C % 4 == 0 and H*W <= 4096")
     _on_current_device(fmap, "fmap")
     B, Cc, H, W = fmap.shape
     out = torch.empty((B, Cc, H - kh + 1, W - kw + 1), device=fmap.device, dtype=torch.float32, memory_format=torch.channels_last)
