@@ -1,4 +1,4 @@
-"""A/B of the conv3x3 k-tile visiting order (ISX_LIB=scratch/ab/libisx_korder1.so vs the default library): time per ResNet-50 3x3 layer at B = 1024,
+"""A/B of the conv3x3 k-tile visiting order (git apply scratch/conv3x3_korder.patch, build conv.hip + expand.hip with -DISX_CONV3X3_KORDER=1 into a second library, ISX_LIB=<that library> vs the default one): time per ResNet-50 3x3 layer at B = 1024,
 max |diff| against torch's conv2d (sanity: the two orders are different fma chains)."""
 import sys, time, torch
 sys.path.insert(0, "/root/repo/instance-search_amd")
