@@ -282,6 +282,9 @@ def main():
         for f in fams.values():
             f["tflops"] = f["flop"] / (f["ms"] * 1e-3) / 1e12 if f["ms"] > 0 else None
         conv_flop = sum(f["flop"] for f in fams.values())
+        alg_bytes = sum(nb for _, _, nb, _, _ in timer)           # algorithmic bytes of the convolutions of one launch (activations in + out + weights)
+        tr_ = load_traffic().get("regions_leg") or {}
+        traffic_r = tr_.get("bytes_per_launch") if tr_.get("images_per_launch") == Br else None      # PMC profile of THIS leg at this batch, else null
         flop_img = 4.0 * RESNET50_GFLOP_PER_IMAGE * 1e9 + 2.0 * 64 * 2048 * n_cls        # every convolution sees 4x the pixels of 224 x 224; + the 1x1 classifier on 8 x 8 locations
         ips = Br / (ms_ * 1e-3)
         assert bool(torch.isfinite(slab).all())
@@ -289,7 +292,10 @@ def main():
                            "-> best-location descriptor (train/classif_regions.py:107-132), %d images per launch" % (n_cls, Br),
                "images_per_s": ips, "ms_per_launch": ms_, "images_per_launch": Br,
                "roofline": {"bound": "mfma", "achieved": flop_img * ips / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": flop_img * ips / 1e12 / PEAK_F32_MFMA_TFLOPS, "algorithmic_flop_per_image": flop_img, "traffic": None},
+                            "frac": flop_img * ips / 1e12 / PEAK_F32_MFMA_TFLOPS, "algorithmic_flop_per_image": flop_img, "traffic": traffic_r,
+                            "traffic_unit": "HBM bytes per launch (every kernel of the leg)", "traffic_source": tr_.get("source") if traffic_r is not None else None,
+                            "algorithmic_bytes_per_launch": alg_bytes,
+                            "traffic_over_algorithmic": (traffic_r / alg_bytes) if traffic_r and alg_bytes else None},
                "libisx_convolution_flop_per_image": conv_flop / Br,
                "all_convolutions_in_libisx": bool(conv_flop / Br > 0.995 * flop_img),
                "kernel_families": fams}

@@ -9,7 +9,10 @@ rng = np.random.default_rng(int(time.time()))
 g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
 t0 = time.time(); n = {"fast": 0, "conv1": 0, "conv3": 0, "dual": 0, "topk": 0, "sel": 0, "stem": 0, "pool": 0, "region": 0, "dba": 0, "gemm": 0}
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+last = t0
 while time.time() - t0 < budget:
+    if time.time() - last > 60:                      # a line a minute: gpurun takes seven silent minutes for a hang
+        last = time.time(); print("... %.0f s" % (last - t0), n, flush=True)
     kind = rng.integers(0, 11)
     if kind == 0:      # fast vs fp32 search
         M = int(rng.integers(1, 3000)); N = int(rng.integers(300, 200000)); D = int(rng.choice([8, 16, 64, 96, 256, 512, 1024, 2048])); k = int(rng.integers(1, 129))

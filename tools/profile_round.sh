@@ -20,6 +20,10 @@ echo "write done"
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-bench --no-kernel-pass --no-regions-bench > $OUT/mfma.log 2>&1
 echo "mfma done"
 python3 profiles/summarize_prof.py $TAG $OUT/stats $OUT/fetch $OUT/write $OUT/mfma > $OUT/summarize.log 2>&1 || tail -5 $OUT/summarize.log
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/rfetch -- python3 bench.py --only-regions > $OUT/rfetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/rwrite -- python3 bench.py --only-regions > $OUT/rwrite.log 2>&1
+python3 profiles/summarize_regions_pmc.py $TAG $OUT/rfetch $OUT/rwrite 128 >> $OUT/summarize.log 2>&1 || tail -5 $OUT/summarize.log
+echo "regions pmc done"
 mkdir -p $OUT/summaries && cp profiles/${TAG}_* profiles/roofline_traffic.json $OUT/summaries/ 2>/dev/null || true
 # the regions leg: per-kernel table of its own trace
 python3 - <<PY
