@@ -796,7 +796,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 
 static size_t a256(size_t v) { return (v + 255) & ~(size_t)255; }
 static int fast_kl(int k) {
-    int kl = (2 * k + 32 + 31) / 32 * 32;
+    static const int pct = [] { const char* e = getenv("ISX_FAST_KL_PCT"); return e ? atoi(e) : 200; }();      // A/B: candidates kept per query, in % of k (+ 32)
+    int kl = (pct * k / 100 + 32 + 31) / 32 * 32;
     if (kl < 64) kl = 64;
     if (kl > kGroupSelectMaxK) kl = kGroupSelectMaxK;
     return kl;
