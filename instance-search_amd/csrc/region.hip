@@ -205,8 +205,8 @@ ISX_API int isx_best_location_desc(const float* cls, int64_t B, int K, int Hp, i
                                    int64_t* loc, isx_stream_t stream) {
     ISX_REQUIRE(B >= 0 && K > 0 && Hp > 0 && Wp > 0 && B < (1ll << 31) && (int64_t)Hp * Wp < (1ll << 31),
                 "isx_best_location_desc: bad shape B=%lld K=%d Hp=%d Wp=%d", (long long)B, K, Hp, Wp);
-    ISX_REQUIRE(cls && desc && loc, "isx_best_location_desc: null pointer");
     if (B == 0) return ISX_OK;
+    ISX_REQUIRE(cls && desc && loc, "isx_best_location_desc: null pointer");
     hipLaunchKernelGGL(best_location_desc_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, cls, K, Hp, Wp, eps, desc, loc);
     ISX_CHECK_LAUNCH("isx_best_location_desc");
     return ISX_OK;
@@ -243,8 +243,8 @@ ISX_API int isx_best_location_desc_nhwc(const float* cls, int64_t B, int K, int 
                                         isx_stream_t stream) {
     ISX_REQUIRE(B >= 0 && K > 0 && Hp > 0 && Wp > 0 && B < (1ll << 31) && (int64_t)Hp * Wp < (1ll << 31),
                 "isx_best_location_desc_nhwc: bad shape B=%lld K=%d Hp=%d Wp=%d", (long long)B, K, Hp, Wp);
-    ISX_REQUIRE(cls && desc && loc, "isx_best_location_desc_nhwc: null pointer");
     if (B == 0) return ISX_OK;
+    ISX_REQUIRE(cls && desc && loc, "isx_best_location_desc_nhwc: null pointer");
     hipLaunchKernelGGL(best_location_desc_nhwc_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, cls, K, Hp, Wp, eps, desc, loc);
     ISX_CHECK_LAUNCH("isx_best_location_desc_nhwc");
     return ISX_OK;

@@ -35,6 +35,16 @@ def test_argument_validation_without_gpu():
     assert lib.isx_region_topk(None, 1, 4, 100, 100, 3, None, None, None) == -1
     assert b"4096" in lib.isx_last_error()
     assert lib.isx_topk_merge(None, None, 8, 4, 1024, None, None, None) == -1
+    # round-3 entries: channels-last region kernels, wide stem, DBA groups
+    assert lib.isx_boxpool_s1_nhwc(None, 1, 6, 14, 14, 7, 7, None, None) == -1 and b"multiple of 4" in lib.isx_last_error()
+    assert lib.isx_boxpool_s1_nhwc(None, 1, 8, 14, 14, 15, 7, None, None) == -1 and b"bad shape" in lib.isx_last_error()
+    assert lib.isx_stem7x7_pool_nhwc(None, 1, 8, 900, None, None, None, None) == -1 and b"896" in lib.isx_last_error()
+    assert lib.isx_stem7x7_pool_nhwc(None, 0, 8, 448, None, None, None, None) == 0
+    assert lib.isx_dba_groups(None, 10, 64, None, None, None, 2000, -1, None, None) == -1 and b"1024" in lib.isx_last_error()
+    assert lib.isx_dba_groups(None, 0, 64, None, None, None, 0, -1, None, None) == 0
+    assert lib.isx_region_topk_nhwc(None, 1, 4, 100, 100, 3, None, None, None) == -1 and b"4096" in lib.isx_last_error()
+    assert lib.isx_region_gather_l2_nhwc(None, 1, 6, 9, 9, 3, 3, None, 2, 7, None, 1e-10, None, None) == -1 and b"multiple of 4" in lib.isx_last_error()
+    assert lib.isx_best_location_desc_nhwc(None, 0, 4, 2, 2, 1e-10, None, None, None) == 0
     # empty problems are no-ops
     assert lib.isx_l2norm_rows(None, 0, 16, 1e-10, None, None) == 0
     assert lib.isx_cosine_sim(None, 0, None, 0, 8, None, None) == 0
