@@ -520,3 +520,14 @@ def test_folder_decode_on_threads_keeps_file_order(tmp_path, monkeypatch):
     for a, b in zip(seq, par):
         assert a.dtype == torch.uint8 and a.shape == b.shape and torch.equal(a, b)
 
+
+
+def test_row_segments_choice_is_a_divisor_and_bounded():
+    """ops._row_segments (few-query top-k by row segments): S divides N, every segment holds >= max(k, 1024) columns, the merge fits
+    isx_topk_merge (S * k <= 4096), and large query blocks / short rows keep the one-launch path."""
+    from isx import ops
+    for M, N, k in ((1000, 100000, 100), (1000, 100000, 1), (100, 100000, 100), (37, 65536, 1), (5, 49152, 256), (1000, 20000, 10)):
+        S = ops._row_segments(M, N, k)
+        assert S >= 2 and N % S == 0 and N // S >= max(k, 1024) and S * k <= 4096 and S <= 64
+    for M, N, k in ((5000, 100000, 100), (1000, 10000, 100), (3, 100003, 7), (10, 100000, 300)):
+        assert ops._row_segments(M, N, k) == 0
