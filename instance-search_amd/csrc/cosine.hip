@@ -278,6 +278,7 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     if (M == 0 || N == 0) return ISX_OK;
     if (((M + 63) / 64) * ((N + 63) / 64) >= (1ll << 31)) { isx_set_error("cosine gemm: too many tiles for one grid"); return ISX_ERR_ARG; }
     const bool aligned = (D % 32 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);     // no k tail for BK = 16 or 32
+    const bool aligned16 = aligned || ((D % 16 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0));   // enough for the BK = 16 (128x128) tiles: D = 464
     const int64_t split = (epi == 2) ? gemm_tail_split_rows(M, N) : 0;      // convolutions: 128x128 tiles + 64x64 tail in one grid
     static const float eff_gemm[4] = {kCfgs[0].eff, kCfgs[1].eff, kCfgs[2].eff, kCfgs[3].eff};
     int best = pick_tile_cfg(M, N, split, eff_gemm, 0xF);
@@ -295,7 +296,7 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
         const int64_t rounds = tm_ * tn_ / slots, rem = tm_ * tn_ - rounds * slots;
         const int64_t n_big = rounds * slots / tm_ * 128;                  // columns of the whole rounds
         if (rounds >= 1 && rem > 0 && rem <= slots * 3 / 5 && n_big > 0 && n_big < N && (n_big * D * 4) % 16 == 0) {
-            launch_cfg<2, 2, 16>(aligned, Q, M, G, n_big, D, C, ldc, thr, gmax, st, m_active, epi, relu);
+            launch_cfg<2, 2, 16>(aligned16, Q, M, G, n_big, D, C, ldc, thr, gmax, st, m_active, epi, relu);
             launch_cfg<1, 1, 32>(aligned, Q, M, G + n_big * D, N - n_big, D, C + n_big, ldc, thr, gmax, st, m_active, epi, relu);
             ISX_CHECK_LAUNCH("cosine_gemm");
             return ISX_OK;
@@ -313,7 +314,7 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
         return ISX_OK;
     }
     switch (best) {
-        case 0: launch_cfg<2, 2, 16>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
+        case 0: launch_cfg<2, 2, 16>(aligned16, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
         case 1: launch_cfg<1, 2, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
         case 2: launch_cfg<2, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
         default: launch_cfg<1, 1, 32>(aligned, Q, M, G, N, D, C, ldc, thr, gmax, st, m_active, epi, relu); break;
