@@ -308,8 +308,10 @@ def main():
         ql, gl = ql.to(dev), gl.to(dev)
         simr = torch.empty((Mq, Nr), device=dev)
 
-        def leg(f, n=3):
-            f(); torch.cuda.synchronize()
+        def leg(f, n=20):
+            for _ in range(5):                          # sub-millisecond launches: warm the clocks up before timing
+                f()
+            torch.cuda.synchronize()
             a, b = ev(), ev(); a.record()
             for _ in range(n):
                 f()
