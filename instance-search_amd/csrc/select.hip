@@ -20,14 +20,19 @@ constexpr int SEL_THREADS = 256;
 constexpr int SEL_CAP = 2048;
 constexpr int SEL_STRIP = SEL_THREADS * 4;
 
+// Exclusive prefix sum over the 64 lanes of a wave (all lanes active) + the wave total: DPP row shifts inside the rows of 16 lanes,
+// then the two row broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) -- six VALU adds, where six dependent
+// __shfl_up (ds_bpermute through the LDS crossbar) cost ~10^2 cycles each.  A lane without a source keeps `old` = 0.
 __device__ __forceinline__ int wave_excl_prefix(int v, int lane, int& total) {
+    (void)lane;
     int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        int t = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += t;
-    }
-    total = __shfl(incl, 63, 64);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);      // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);      // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);      // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);      // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1, 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2, 3
+    total = __builtin_amdgcn_readlane(incl, 63);
     return incl - v;
 }
 
@@ -253,30 +258,65 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
     uint64_t thr_key = buf[k - 1];
     int cnt = k;                                   // uniform
 
+    float thr_f = thr_key ? key_score(thr_key) : -INFINITY;      // score of the threshold key; a list that is not full admits everything
     if (!gf) {
-        // every group present (isx_topk_rows, bootstrap chunk): plain streaming scan, 256 scores per step
-        // (16-B loads when the row is 16-B aligned), append by shuffle prefix
+        // every group present (isx_topk_rows, bootstrap chunk): plain streaming scan, 256 scores per step.  Whole steps of 16-B aligned
+        // rows run two loads deep (registers A / B, unrolled: the wave waits for a step while the next one is in flight) behind a cheap
+        // reject: v < thr in float order (neither a NaN) implies key < thr_key, so the wave builds keys and a prefix sum only when some
+        // lane may hold a candidate.  The ragged end of the row and unaligned rows take the scalar loop below.
         const bool vec = ((((uintptr_t)r) & 15) == 0);
-        for (int64_t j0 = 0; j0 < Nc; j0 += 256) {
-            if (cnt - k > GS_NEW - 256) {              // room for a full step
-                thr_key = gs_flush(buf, hist, k, cnt, lane);
-                cnt = k;
-            }
-            const int64_t j = j0 + (int64_t)lane * 4;
-            float vv[4];
-            if (vec && j + 3 < Nc) {
-                const float4 v = *reinterpret_cast<const float4*>(r + j);
-                vv[0] = v.x; vv[1] = v.y; vv[2] = v.z; vv[3] = v.w;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) vv[q] = (j + q < Nc) ? r[j + q] : 0.0f;
-            }
+        const int64_t nfull = vec ? (Nc >> 8) : 0;
+        auto consume = [&](int64_t s, const float4& S) {
+            if (__ballot(!(S.x < thr_f && S.y < thr_f && S.z < thr_f && S.w < thr_f)) == 0ull) return;
+            const float vv[4] = {S.x, S.y, S.z, S.w};
+            const uint32_t j = col_base + (uint32_t)((s << 8) + lane * 4);
             uint64_t key[4];
             bool take[4];
             int c = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                key[q] = (j + q < Nc) ? rank_key(vv[q], col_base + (uint32_t)(j + q)) : 0ull;
+                key[q] = rank_key(vv[q], j + (uint32_t)q);
+                take[q] = key[q] > thr_key;
+                c += take[q] ? 1 : 0;
+            }
+            int total;
+            int off = cnt + wave_excl_prefix(c, lane, total);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (take[q]) buf[off++] = key[q];
+            cnt += total;
+        };
+        auto fetch = [&](int64_t s, float4& S) {       // past the end: a valid address, the step is never consumed
+            S = *reinterpret_cast<const float4*>(r + ((s < nfull ? s : nfull - 1) << 8) + lane * 4);
+        };
+        auto flush_if_full = [&]() {
+            if (cnt - k > GS_NEW - 256) {              // room for a full step
+                thr_key = gs_flush(buf, hist, k, cnt, lane);
+                thr_f = thr_key ? key_score(thr_key) : -INFINITY;
+                cnt = k;
+            }
+        };
+        if (nfull > 0) {
+            float4 A, B;
+            fetch(0, A); fetch(1, B);
+            for (int64_t s = 0; s < nfull; s += 2) {
+                flush_if_full();
+                consume(s, A); fetch(s + 2, A);
+                if (s + 1 < nfull) {
+                    flush_if_full();
+                    consume(s + 1, B);
+                }
+                fetch(s + 3, B);
+            }
+        }
+        for (int64_t j0 = nfull << 8; j0 < Nc; j0 += 256) {
+            flush_if_full();
+            const int64_t j = j0 + (int64_t)lane * 4;
+            uint64_t key[4];
+            bool take[4];
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                key[q] = (j + q < Nc) ? rank_key(r[j + q], col_base + (uint32_t)(j + q)) : 0ull;
                 take[q] = key[q] > thr_key;
                 c += take[q] ? 1 : 0;
             }
@@ -286,40 +326,58 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
             for (int q = 0; q < 4; ++q) if (take[q]) buf[off++] = key[q];
             cnt += total;
         }
-    } else
-    for (int g0 = 0; g0 < ngrp; g0 += 64) {
-        const int g = g0 + lane;
-        const bool q = (g < ngrp) && (gf[g] != 0);
-        unsigned long long mask = __ballot(q);
-        while (mask) {
-            if (cnt - k > GS_NEW - 256) {          // this step can add up to 4 x 64 keys
-                thr_key = gs_flush(buf, hist, k, cnt, lane);
-                cnt = k;
+    } else if (ngrp > 0) {
+        // filtered chunk.  The flag row is read 256 groups at a time -- four coalesced byte loads per lane in flight together, the next
+        // four issued before this block's segments are fetched -- instead of one dependent load per 64 groups.
+        auto flag_at = [&](int g) -> unsigned { return gf[g < ngrp ? g : ngrp - 1]; };     // clamped: the loads stay unconditional
+        unsigned fb[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) fb[b] = flag_at(b * 64 + lane);
+        for (int g0 = 0; g0 < ngrp; g0 += 256) {
+            unsigned long long m[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) m[b] = __ballot((g0 + b * 64 + lane < ngrp) && fb[b] != 0u);
+            if (g0 + 256 < ngrp) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) fb[b] = flag_at(g0 + 256 + b * 64 + lane);
             }
-            // up to eight qualifying groups per step: sub-step u gives one to each half-wave
-            int64_t col[4];
-            float v[4];
-            bool in[4];
+#pragma unroll 1
+            for (int b = 0; b < 4; ++b) {
+                unsigned long long mask = b == 0 ? m[0] : b == 1 ? m[1] : b == 2 ? m[2] : m[3];
+                const int gbase = g0 + b * 64;
+                while (mask) {
+                    if (cnt - k > GS_NEW - 256) {          // this step can add up to 4 x 64 keys
+                        thr_key = gs_flush(buf, hist, k, cnt, lane);
+                        thr_f = thr_key ? key_score(thr_key) : -INFINITY;
+                        cnt = k;
+                    }
+                    // up to eight qualifying groups per step: sub-step u gives one to each half-wave
+                    int64_t col[4];
+                    float v[4];
+                    bool in[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                int ga = -1, gb = -1;
-                if (mask) { ga = __ffsll((long long)mask) - 1; mask &= mask - 1; }
-                if (mask) { gb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
-                const int gsel = half ? gb : ga;
-                col[u] = (int64_t)(g0 + gsel) * 32 + l31;
-                in[u] = (gsel >= 0) && (col[u] < Nc);
-            }
+                    for (int u = 0; u < 4; ++u) {
+                        int ga = -1, gb = -1;
+                        if (mask) { ga = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+                        if (mask) { gb = __ffsll((long long)mask) - 1; mask &= mask - 1; }
+                        const int gsel = half ? gb : ga;
+                        col[u] = (int64_t)(gbase + gsel) * 32 + l31;
+                        in[u] = (gsel >= 0) && (col[u] < Nc);
+                    }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = in[u] ? r[col[u]] : 0.0f;      // four loads in flight
+                    for (int u = 0; u < 4; ++u) v[u] = in[u] ? r[col[u]] : 0.0f;      // four loads in flight
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint64_t key = in[u] ? rank_key(v[u], col_base + (uint32_t)col[u]) : 0ull;
-                const bool take = in[u] && key > thr_key;
-                const unsigned long long tm = __ballot(take);
-                if (tm) {
-                    const int pos = cnt + __popcll(tm & ((1ull << lane) - 1ull));
-                    if (take) buf[pos] = key;
-                    cnt += __popcll(tm);
+                    for (int u = 0; u < 4; ++u) {
+                        if (__ballot(in[u] && !(v[u] < thr_f)) == 0ull) continue;     // v < thr (float order) implies key < thr_key
+                        const uint64_t key = in[u] ? rank_key(v[u], col_base + (uint32_t)col[u]) : 0ull;
+                        const bool take = in[u] && key > thr_key;
+                        const unsigned long long tm = __ballot(take);
+                        if (tm) {
+                            const int pos = cnt + __popcll(tm & ((1ull << lane) - 1ull));
+                            if (take) buf[pos] = key;
+                            cnt += __popcll(tm);
+                        }
+                    }
                 }
             }
         }
