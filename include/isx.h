@@ -211,7 +211,8 @@ int isx_rows_to_f16(const float* x, int64_t B, int D, void* h, float* norm2, flo
 int isx_cosine_sim_f16(const void* Qh, int64_t M, const void* Gh, int64_t N, int D, float* sim, isx_stream_t stream);
 
 /* Gallery preparation, once per shard: Gh (N,D) fp16 = RNE(G * 2^s) with the power of two that brings
- * max|G| into [2^13, 2^14); gstats[2] (device) = {max_j |g_j|^2 (upper bound), max |G|}. */
+ * max|G| into [2^13, 2^14); gstats[4] (device) = {max_j |g_j|^2 (upper bound), max |G|,
+ * max_j |g_j - fp16 image of g_j|^2 (what the conversion lost: enters the error bound of the search), 0}. */
 int isx_gallery_to_f16(const float* G, int64_t N, int D, void* Gh, float* gstats, isx_stream_t stream);
 
 /* The search.  Gh/gstats: the cached output of isx_gallery_to_f16, or both NULL (converted per call into

@@ -426,12 +426,12 @@ int run_topk_chunks(const TopkJob& j) {
                 return ISX_ERR_HIP;
             }
             rc = launch_select_groups(chunk, nullptr /* all groups present */, M, w, w, c0, k, carry, thr, emit ? 1 : (last ? 2 : 0), j.idx_base, j.top_score,
-                                      j.top_idx, st, j.m_active, j.row_map);
+                                      j.top_idx, st, j.m_active, j.row_map, j.win, j.k_win);
         } else {
             rc = gemm(c0, w, thr, gflag);
             if (rc) return rc;
             rc = launch_select_groups(chunk, gflag, M, w, w, c0, k, carry, thr, emit ? 1 : (last ? 2 : 0), j.idx_base, j.top_score, j.top_idx, st, j.m_active,
-                                      j.row_map);
+                                      j.row_map, j.win, j.k_win);
         }
         if (rc) return rc;
         c0 += w;

@@ -10,7 +10,7 @@
 //      same fused filter epilogue / group select as the fp32 path (run_topk_chunks, cosine.hip) ->
 //      the KL = min(256, 2k + 32) best APPROXIMATE candidates of every query
 //                                                 cosine_gemm_f16_big_kernel / cosine_gemm_f16_kernel
-//   3. |S' - S| <= eps_i for every pair (eps_i = c * |q_i| * max_j |g_j|, bound below), hence every
+//   3. |S' - S| <= eps_i for every pair (bound below), hence every
 //      member of the exact top-k has S' >= a_k - 2 eps_i where a_k is the k-th best approximate
 //      score.  Candidates inside that window are re-scored EXACTLY (the k-ordered fp32 fma chain of
 //      the oracle) and sorted by the canonical key                            rescore_kernel
@@ -23,14 +23,15 @@
 // galleries that force step 4, adversarial orderings, magnitudes, non-finite values, 40 random shapes).  Reference call sites: the same as isx_cosine_topk
 // (test/classif_finetune_test.py:82 + utils/metrics.py:10-13,33).
 //
-// Error bound.  u16 = 2^-11 (fp16 RNE), u32 = 2^-24.  Operands are first multiplied by a power of two
-// (exact) that brings the largest |x| of the matrix into [2^13, 2^14): scores scale by the exact factor
-// sq*sg, and an element can lose relative precision in fp16 only when it is 2^27 times smaller than the
-// largest one (whether the hardware rounds fp16 subnormals gradually or flushes them).
-//   rounding of both operands       (2 u16 + u16^2) sum|q g|           <= (2^-10 + 2^-22) |q| |g|
-//   elements below the fp16 normal range   2^-14 / scale per element   <= 2 D 2^-27 qmax gmax
-//   fp32 accumulation, exact chain  (D-1) u32 sum|q g|,  MFMA chain (any order, truncation-safe) 2 D u32 sum|q g|
-//   eps_i = (2^-10 + 2^-22 + 3 D 2^-24) |q_i| max_j|g_j|  +  D 2^-26 qmax gmax        (inflated by 1 %)
+// Error bound (round 3: from what the conversion actually lost, not from the worst case of the format).  u32 = 2^-24.  Operands are
+// first multiplied by a power of two (exact) that brings the largest |x| of the matrix into [2^13, 2^14): scores scale by the exact
+// factor sq*sg.  The conversion stores h = RNE_fp16(x), or 0 where that would be an fp16 subnormal, and records per row the norm of the
+// loss r = |x - h| (differences exact in fp32).  With q~, g~ the stored rows:  q~.g~ - q.g = (q~ - q).g~ + q.(g~ - g), hence
+//   operand rounding                |q~.g~ - q.g| <= rq (|g| + rg) + |q| rg          (Cauchy-Schwarz; rq, rg = the recorded losses)
+//   fp32 accumulation, exact chain  (D-1) u32 sum|q g|,  MFMA chain (any order, truncation-safe) 2 D u32 sum|q~ g~|
+//   eps_i = rq_i (|g|max + rg_max) + |q_i| rg_max + 3 D 2^-24 (|q_i| + rq_i)(|g|max + rg_max)        (inflated by 1 %)
+// For unit rows at D = 2048 this is ~7.6e-4 against 1.34e-3 for the format's worst case (2^-10 |q||g|): the window of candidates that
+// must be re-scored shrinks from ~38 to ~21 beyond k per query.
 // Matrices whose largest |x| is outside [2^-20, 2^15], or not finite, take the exact fp32 path.
 #include <hip/hip_fp16.h>
 #include <type_traits>
@@ -76,18 +77,33 @@ __device__ __forceinline__ float f16_scale(float amax) {
 }
 
 // stats (optional): scale from stats[1] (must be final: amax_kernel ran before), max norm2 into stats[0].
+// In the scaled conversion of the search (stats given) fp16 results below the normal range are stored as ZERO (whether the matrix cores
+// round fp16 subnormals gradually or flush them then does not matter), and res2 (optional) receives the squared norm of what the row LOST: sum (x - h / scale)^2, the difference taken in
+// fp32 without rounding (x * scale and h lie within half an fp16 ulp of each other).  stats[2] = largest res2 (with want_norm_max).
+__device__ __forceinline__ _Float16 to_f16_normal(float vs, float& lost, bool flush) {
+    asm volatile("" : "+v"(vs));                         // the product as ONE fp32 value: left to itself hipcc converts with v_fma_mixlo_f16(x, scale, +0), and -0 + +0 = +0
+    _Float16 hv = (_Float16)vs;                          // conversion RNE
+    float hf = (float)hv;
+    if (flush && fabsf(hf) < 6.103515625e-05f) { hv = (_Float16)0.0f; hf = 0.0f; }
+    lost = vs - hf;
+    return hv;
+}
+
 __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restrict__ x, int64_t B, int D, _Float16* __restrict__ h,
                                                           float* __restrict__ norm2, float* __restrict__ amax,
-                                                          unsigned* __restrict__ stats, int want_norm_max) {
+                                                          unsigned* __restrict__ stats, int want_norm_max, float* __restrict__ res2) {
     const int lane = threadIdx.x & 63;
-    __shared__ float wn2[4];
+    __shared__ float wn2[4], wr2[4];
     const float scale = stats ? f16_scale(__uint_as_float(stats[1])) : 1.0f;
+    const float inv_s2 = 1.0f / (scale * scale);          // power of two: exact
+    const bool flush = stats != nullptr;                  // the plain building block (isx_rows_to_f16) keeps the IEEE image, subnormals included
+    float run_res = 0.0f;
     float run_max = 0.0f;                                // this wave's largest row norm (grid-stride over row groups:
     const bool vec = (D & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)h)) & 15) == 0;      // one atomic per workgroup at the end)
     for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < B; row += (int64_t)gridDim.x * 4) {
         const float* r = x + row * D;
         _Float16* o = h + row * D;
-        float ss = 0.0f, mx = 0.0f;
+        float ss = 0.0f, mx = 0.0f, rs = 0.0f;
         if (vec) {
             // 8 elements per lane and step: two 16-B loads, one 16-B store
             for (int j = lane * 8; j < D; j += 512) {
@@ -96,7 +112,9 @@ __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restric
                 half8 hv;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
-                    hv[q] = (_Float16)(v[q] * scale);    // power-of-two scaling is exact; conversion RNE
+                    float lost;
+                    hv[q] = to_f16_normal(v[q] * scale, lost, flush);       // power-of-two scaling is exact
+                    rs += lost * lost;
                     ss += v[q] * v[q];
                     mx = nanmax(mx, fabsf(v[q]));
                 }
@@ -105,7 +123,9 @@ __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restric
         } else {
             for (int j = lane; j < D; j += 64) {
                 const float v = r[j];
-                o[j] = (_Float16)(v * scale);
+                float lost;
+                o[j] = to_f16_normal(v * scale, lost, flush);
+                rs += lost * lost;
                 ss += v * v;
                 mx = nanmax(mx, fabsf(v));
             }
@@ -114,18 +134,25 @@ __global__ __launch_bounds__(256) void rows_to_f16_kernel(const float* __restric
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) mx = nanmax(mx, __shfl_xor(mx, s, 64));
         ss *= 1.000001f;                                                    // slight inflation: norm2 is an upper bound
+        rs = wave_sum(rs) * inv_s2 * 1.00001f;                              // unscaled, slightly inflated (the caller adds 1 % to eps)
         if (!(ss >= 0.0f)) ss = INFINITY;
         if (!(mx >= 0.0f)) mx = INFINITY;
+        if (!(rs >= 0.0f)) rs = INFINITY;
         if (lane == 0) {
             if (norm2) norm2[row] = ss;
             if (amax) amax[row] = mx;
+            if (res2) res2[row] = rs;
         }
         run_max = fmaxf(run_max, ss);
+        run_res = fmaxf(run_res, rs);
     }
     if (want_norm_max) {                                   // uniform per launch
-        if (lane == 0) wn2[threadIdx.x >> 6] = run_max;
+        if (lane == 0) { wn2[threadIdx.x >> 6] = run_max; wr2[threadIdx.x >> 6] = run_res; }
         __syncthreads();
-        if (threadIdx.x == 0) atomicMax(&stats[0], __float_as_uint(fmaxf(fmaxf(wn2[0], wn2[1]), fmaxf(wn2[2], wn2[3]))));
+        if (threadIdx.x == 0) {
+            atomicMax(&stats[0], __float_as_uint(fmaxf(fmaxf(wn2[0], wn2[1]), fmaxf(wn2[2], wn2[3]))));
+            atomicMax(&stats[2], __float_as_uint(fmaxf(fmaxf(wr2[0], wr2[1]), fmaxf(wr2[2], wr2[3]))));
+        }
     }
 }
 
@@ -659,16 +686,28 @@ constexpr int RS_T = 256;
 constexpr int RS_BK = 32;
 constexpr int RS_LD = 36;
 
-__device__ __forceinline__ float fast_eps(float qn2, float qmax, float gn2, float gmax, int D) {
-    // eps = (2^-10 + 2^-22 + 3 D 2^-24) |q| |g|max + D 2^-26 qmax gmax, evaluated in fp32 and inflated by 1 %
-    const float c1 = 9.765625e-4f + 2.384185791015625e-7f + 3.0f * (float)D * 5.9604644775390625e-8f;
-    const float c2 = (float)D * 1.490116119384765625e-8f;
-    return 1.01f * (c1 * sqrtf(qn2) * sqrtf(gn2) + c2 * qmax * gmax);
+__device__ __forceinline__ float fast_eps(float qn2, float qres2, float gn2, float gres2, int D) {
+    // eps = rq (|g|max + rg) + |q| rg + 3 D 2^-24 (|q| + rq)(|g|max + rg), evaluated in fp32 and inflated by 1 %
+    const float qn = sqrtf(qn2), rq = sqrtf(qres2), gn = sqrtf(gn2), rg = sqrtf(gres2);
+    const float c1 = 3.0f * (float)D * 5.9604644775390625e-8f;
+    return 1.01f * (rq * (gn + rg) + qn * rg + c1 * (qn + rq) * (gn + rg));
+}
+
+// Width of the window of interest per query row, in the (scaled) score domain of the approximate pass: 2 eps; +inf where the fp16 pass
+// is not usable (the row then takes the exact fallback).  Read by the group selects of the approximate pass and by rescore_kernel.
+__global__ __launch_bounds__(256) void window_kernel(const float* __restrict__ qnorm2, const float* __restrict__ qres2, const float* __restrict__ qstats,
+                                                     const float* __restrict__ gstats, int D, int64_t M, float* __restrict__ win) {
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const float qmax = qstats[1], gmax = gstats[1];
+    const float sc = f16_scale(qmax) * f16_scale(gmax);
+    const float eps = fast_eps(qnorm2[row], qres2[row], gstats[0], gstats[2], D) * sc;
+    const bool usable = f16_usable(qmax) && f16_usable(gmax) && (eps < 1e30f);
+    win[row] = usable ? 2.0f * eps : INFINITY;
 }
 
 __global__ __launch_bounds__(RS_T) void rescore_kernel(const float* __restrict__ Q, const float* __restrict__ G, int D, int64_t N, int KL, int k,
-                                                       const uint64_t* __restrict__ cand, const float* __restrict__ qnorm2,
-                                                       const float* __restrict__ qstats, const float* __restrict__ gstats,
+                                                       const uint64_t* __restrict__ cand, const float* __restrict__ win,
                                                        int64_t idx_base, float* __restrict__ top_score, int64_t* __restrict__ top_idx,
                                                        int* __restrict__ ok) {
     __shared__ __attribute__((aligned(16))) float tile[RS_T * RS_LD];     // 36 KB
@@ -680,15 +719,13 @@ __global__ __launch_bounds__(RS_T) void rescore_kernel(const float* __restrict__
     keys[t] = key;
     if (t < 2) cnt_s[t] = 0;
     __syncthreads();
-    // approximate scores live in the scaled domain: S' ~ sq * sg * S
-    const float qmax = qstats[1], gmax = gstats[1];
-    const float sc = f16_scale(qmax) * f16_scale(gmax);
-    const float eps = fast_eps(qnorm2[row], qmax, gstats[0], gmax, D) * sc;
+    // approximate scores live in the scaled domain: S' ~ sq * sg * S; so does the window width 2 eps (window_kernel)
+    const float w2 = win[row];
     const int kk = (k < KL) ? k : KL;
     const uint64_t kth = keys[kk - 1];                                    // 0 when the list holds fewer than k
-    const bool usable = f16_usable(qmax) && f16_usable(gmax) && (eps < 1e30f);
+    const bool usable = (w2 < INFINITY);
     float floor_v = -INFINITY;
-    if (kth) floor_v = key_score(kth) - 2.0f * eps - 2e-7f * fabsf(key_score(kth));   // (fp32 rounding of this line covered)
+    if (kth) floor_v = key_score(kth) - w2 - 2e-7f * fabsf(key_score(kth));   // (fp32 rounding of this line covered)
     const bool valid = key != 0ull;
     const bool in_win = valid && (key_score(key) >= floor_v);
     if (valid) atomicAdd(&cnt_s[0], 1);
@@ -841,32 +878,33 @@ ISX_API int isx_rows_to_f16(const float* x, int64_t B, int D, void* h, float* no
     if (B == 0) return ISX_OK;
     ISX_REQUIRE(x && h && norm2 && amax, "isx_rows_to_f16: null pointer");
     hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, B, D, (_Float16*)h, norm2, amax,
-                       (unsigned*)nullptr, 0);
+                       (unsigned*)nullptr, 0, (float*)nullptr);
     ISX_CHECK_LAUNCH("isx_rows_to_f16");
     return ISX_OK;
 }
 
 // stats must be zeroed (stream-ordered) before: pass 1 max |x|, pass 2 scaled conversion + max norm2.
-static int convert_scaled(const float* x, int64_t B, int D, _Float16* h, float* norm2, unsigned* stats, int want_norm_max, hipStream_t st) {
+static int convert_scaled(const float* x, int64_t B, int D, _Float16* h, float* norm2, float* res2, unsigned* stats, int want_norm_max, hipStream_t st) {
     const int64_t n = B * D;
     int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(amax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, stats);
     ISX_CHECK_LAUNCH("amax");
     hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((B + 3) / 4 < 4096 ? (B + 3) / 4 : 4096)), dim3(256), 0, st, x, B, D, h, norm2, (float*)nullptr, stats,
-                       want_norm_max);
+                       want_norm_max, res2);
     ISX_CHECK_LAUNCH("rows_to_f16");
     return ISX_OK;
 }
 
-// Gallery preparation for isx_cosine_topk_fast: power-of-two scaled fp16 image of the rows + gstats[2] =
-// {max squared row norm (upper bound), max |x|}.  Done once per gallery shard and cached by the caller.
+// Gallery preparation for isx_cosine_topk_fast: power-of-two scaled fp16 image of the rows + gstats[4] =
+// {max squared row norm (upper bound), max |x|, max squared norm of what a row lost in the conversion, 0}.  Done once per gallery
+// shard and cached by the caller.
 ISX_API int isx_gallery_to_f16(const float* G, int64_t N, int D, void* Gh, float* gstats, isx_stream_t stream) {
     ISX_REQUIRE(N >= 0 && D > 0 && N < (1ll << 33), "isx_gallery_to_f16: bad shape N=%lld D=%d", (long long)N, D);
     ISX_REQUIRE(gstats && ((G && Gh) || N == 0), "isx_gallery_to_f16: null pointer");
-    if (hipMemsetAsync(gstats, 0, 8, (hipStream_t)stream) != hipSuccess) { isx_set_error("isx_gallery_to_f16: hipMemsetAsync failed"); return ISX_ERR_HIP; }
+    if (hipMemsetAsync(gstats, 0, 16, (hipStream_t)stream) != hipSuccess) { isx_set_error("isx_gallery_to_f16: hipMemsetAsync failed"); return ISX_ERR_HIP; }
     if (N == 0) return ISX_OK;
-    return convert_scaled(G, N, D, (_Float16*)Gh, nullptr, (unsigned*)gstats, 1, (hipStream_t)stream);
+    return convert_scaled(G, N, D, (_Float16*)Gh, nullptr, nullptr, (unsigned*)gstats, 1, (hipStream_t)stream);
 }
 
 // Approximate similarity matrix from fp16 operands (fp32 accumulate): building block / diagnostic of the
@@ -922,8 +960,9 @@ ISX_API int isx_cosine_topk_fast(const float* Q, int64_t M, const float* G, int6
     int rc;
 
     // 1. fp16 operands
-    if (hipMemsetAsync(qst, 0, 8, st) != hipSuccess) { isx_set_error("isx_cosine_topk_fast: hipMemsetAsync failed"); return ISX_ERR_HIP; }
-    rc = convert_scaled(Q, M, D, qh, qn2, (unsigned*)qst, 0, st);
+    if (hipMemsetAsync(qst, 0, 16, st) != hipSuccess) { isx_set_error("isx_cosine_topk_fast: hipMemsetAsync failed"); return ISX_ERR_HIP; }
+    float* qres2 = (float*)ok;                          // per-row conversion loss, read by window_kernel; rescore_kernel rewrites the slot as `ok`
+    rc = convert_scaled(Q, M, D, qh, qn2, qres2, (unsigned*)qst, 0, st);
     if (rc) return rc;
     const _Float16* gh = (const _Float16*)Gh;
     const float* gs = gstats;
@@ -939,11 +978,17 @@ ISX_API int isx_cosine_topk_fast(const float* Q, int64_t M, const float* G, int6
     a.Qh = qh; a.Gh = gh; a.M = M; a.N = N; a.D = D; a.k = kl;
     a.idx_base = 0; a.emit = false;
     a.ws = w + L.chunk; a.ws_bytes = ws_bytes - L.chunk; a.st = st;
+    // only candidates within 2 eps of the k-th best approximate score are re-scored: the selects tighten the filter threshold accordingly
+    // (the window widths live in the `list` slot, which compact_rows_kernel rewrites after the approximate pass)
+    float* win = (float*)(w + L.list);
+    hipLaunchKernelGGL(window_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, qn2, qres2, qst, gs, D, M, win);
+    ISX_CHECK_LAUNCH("window");
+    a.win = (k < kl) ? win : nullptr; a.k_win = k;
     rc = run_topk_chunks(a);
     if (rc) return rc;
     const uint64_t* cand = (const uint64_t*)(w + L.chunk);
     // 3. exact re-scoring inside the error window
-    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)M), dim3(RS_T), 0, st, Q, G, D, N, kl, k, cand, qn2, qst, gs, idx_base, top_score, top_idx, ok);
+    hipLaunchKernelGGL(rescore_kernel, dim3((unsigned)M), dim3(RS_T), 0, st, Q, G, D, N, kl, k, cand, win, idx_base, top_score, top_idx, ok);
     ISX_CHECK_LAUNCH("rescore");
     // 4. exact fp32 search for the rows that were not covered (usually none: every launch below exits at once)
     hipLaunchKernelGGL(compact_rows_kernel, dim3(1), dim3(1024), 0, st, ok, (int)M, list, count);

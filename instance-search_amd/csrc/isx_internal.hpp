@@ -50,9 +50,11 @@ int launch_select(const float* sim, int64_t M, int64_t Nc, int64_t ld, int64_t c
 // (thr[row] = score of the k-th key, -inf while fewer than k).
 int launch_select_groups(const float* sim, const uint8_t* gflag, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
                          uint64_t* carry, float* thr, int mode, int64_t idx_base, float* top_score, int64_t* top_idx,
-                         hipStream_t st, const int* m_active = nullptr, const int* row_map = nullptr);
+                         hipStream_t st, const int* m_active = nullptr, const int* row_map = nullptr, const float* win = nullptr, int k_win = 0);
 // mode 0: intermediate chunk (carry unsorted, k-th largest key in slot k-1), 1: last chunk, emit sorted lists, 2: last chunk, sorted carry.
 // m_active / row_map (optional, device): only rows < *m_active are processed and row r emits to output row row_map[r].
+// win / k_win (optional): the caller only needs candidates within win[row] of the final k_win-th best score (k_win < k); the threshold
+// written for the next filter GEMM is then max(k-th best, current k_win-th best - win[row]).
 
 constexpr int kGroupSelectMaxK = 256;
 
@@ -69,6 +71,7 @@ struct TopkJob {
     int64_t idx_base; float* top_score; int64_t* top_idx; bool emit;
     void* ws; size_t ws_bytes; hipStream_t st;
     const int* m_active; const int* row_map;
+    const float* win; int k_win;                  // optional window of interest below the k_win-th best score (see launch_select_groups)
 };
 int run_topk_chunks(const TopkJob& job);
 size_t topk_fixed_bytes(int64_t M, int k);

@@ -146,23 +146,20 @@ __device__ __forceinline__ uint64_t wave_or_u64(uint64_t v) {
     return v;
 }
 
-// Returns the new threshold key (k-th largest; 0 while the list holds fewer than k keys).  cnt > k on entry; on exit
-// buf[0, k) holds the survivors (unsorted, zero padded).  Uniform control flow; all 64 lanes call it.
-__device__ __forceinline__ uint64_t gs_flush(uint64_t* buf, uint32_t* hist, int k, int cnt, int lane) {
-    __syncthreads();                               // appended keys visible
-    uint64_t v[GS_R];
+// The want-th largest of the cnt keys a wave holds in registers (lane l: keys l, 64 + l, ...; slots >= cnt are zero): radix descent, most
+// significant byte first.  Uniform control flow; the barriers are workgroup barriers of the one-wave workgroup.  0 when want > #keys.
+template <int R>
+__device__ __forceinline__ uint64_t radix_kth(const uint64_t (&v)[R], int cnt, int want, uint32_t* hist, int lane) {
     uint64_t all_and = ~0ull, all_or = 0ull;
 #pragma unroll
-    for (int r = 0; r < GS_R; ++r) {
+    for (int r = 0; r < R; ++r) {
         const int i = r * 64 + lane;
-        v[r] = (i < cnt) ? buf[i] : 0ull;          // slots beyond cnt behave like empty (zero) entries
         if (r * 64 < cnt) { all_or |= v[r]; all_and &= (i < cnt) ? v[r] : ~0ull; }
     }
     all_or = wave_or_u64(all_or);
     all_and = ~wave_or_u64(~all_and);
     const uint64_t diff = all_and ^ all_or;        // bits on which the keys differ (uniform)
     uint64_t prefix = 0ull, mask = 0ull, T = 0ull;
-    int want = k;                                  // rank (from the top) still to be located inside the prefix class
     bool done = false;
 #pragma unroll 1
     for (int shift = 56; shift >= 0 && !done; shift -= 8) {
@@ -174,7 +171,7 @@ __device__ __forceinline__ uint64_t gs_flush(uint64_t* buf, uint32_t* hist, int 
         for (int i = lane; i < 256; i += 64) hist[i] = 0u;
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < GS_R; ++r)
+        for (int r = 0; r < R; ++r)
             if (r * 64 + lane < cnt && (v[r] & mask) == prefix) atomicAdd(&hist[(unsigned)(v[r] >> shift) & 255u], 1u);
         __syncthreads();
         // lane l owns bins 4l .. 4l+3; suffix sums from bin 255 downwards
@@ -191,7 +188,7 @@ __device__ __forceinline__ uint64_t gs_flush(uint64_t* buf, uint32_t* hist, int 
             cum += cj[j];
         }
         const unsigned long long who = __ballot(digit >= 0);
-        if (who == 0ull) {                         // want > number of keys in the class: cannot happen (cnt > k)
+        if (who == 0ull) {                         // want > number of keys in the class: cannot happen (cnt >= want)
             T = 0ull;
             done = true;
             break;
@@ -206,13 +203,27 @@ __device__ __forceinline__ uint64_t gs_flush(uint64_t* buf, uint32_t* hist, int 
         if (inbin == 1) {                          // a single key left in the class: it is T
             uint64_t f = 0ull;
 #pragma unroll
-            for (int r = 0; r < GS_R; ++r)
+            for (int r = 0; r < R; ++r)
                 if (r * 64 + lane < cnt && (v[r] & mask) == prefix) f |= v[r];
             T = wave_or_u64(f);
             done = true;
         }
     }
     if (!done) T = prefix;                         // all eight bytes fixed
+    return T;
+}
+
+// Returns the new threshold key (k-th largest; 0 while the list holds fewer than k keys).  cnt > k on entry; on exit
+// buf[0, k) holds the survivors (unsorted, zero padded).  Uniform control flow; all 64 lanes call it.
+__device__ __forceinline__ uint64_t gs_flush(uint64_t* buf, uint32_t* hist, int k, int cnt, int lane) {
+    __syncthreads();                               // appended keys visible
+    uint64_t v[GS_R];
+#pragma unroll
+    for (int r = 0; r < GS_R; ++r) {
+        const int i = r * 64 + lane;
+        v[r] = (i < cnt) ? buf[i] : 0ull;          // slots beyond cnt behave like empty (zero) entries
+    }
+    const uint64_t T = radix_kth<GS_R>(v, cnt, k, hist, lane);
     // compaction: the non-empty keys >= T (distinct keys: exactly k of them when T != 0)
     __syncthreads();
     int base = 0;
@@ -241,7 +252,10 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
                                                            uint64_t* __restrict__ carry, float* __restrict__ thr, int mode,
                                                            int64_t idx_base, float* __restrict__ top_score,
                                                            int64_t* __restrict__ top_idx, const int* __restrict__ m_active,
-                                                           const int* __restrict__ row_map) {
+                                                           const int* __restrict__ row_map, const float* __restrict__ win, int k_win) {
+    // win / k_win (optional, the approximate pass of fast.hip): only candidates with score >= a - win[row] can matter to the caller, a = the
+    // k_win-th best score of the final list (k_win < k).  a only grows from chunk to chunk, so the threshold handed to the next filter GEMM
+    // is max(k-th best, CURRENT k_win-th best - win[row]) instead of the k-th best alone: fewer stored groups, same final window.
     // mode 0: intermediate chunk, the carry stays UNSORTED with the k-th largest key in slot k-1; 1: last chunk, emit the sorted
     // lists; 2: last chunk, leave the sorted keys in the carry (fast.hip re-scores them)
     __shared__ __attribute__((aligned(16))) uint64_t buf[GS_BUF];
@@ -398,18 +412,32 @@ __global__ __launch_bounds__(64) void select_groups_kernel(const float* __restri
         }
     } else {
         for (int i = lane; i < k; i += 64) carry[row * k + i] = buf[i];
-        if (lane == 0 && thr) thr[row] = buf[k - 1] ? key_score(buf[k - 1]) : -INFINITY;
+        if (thr) {
+            float t = buf[k - 1] ? key_score(buf[k - 1]) : -INFINITY;
+            if (win && mode == 0 && k_win < k && buf[k - 1] != 0ull) {      // full list (uniform): its k_win-th best key by one more radix descent
+                uint64_t v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (r * 64 + lane < k) ? buf[r * 64 + lane] : 0ull;
+                const uint64_t kw = radix_kth<4>(v, k, k_win, hist, lane);
+                if (kw != 0ull) {
+                    const float a = key_score(kw);
+                    // rounded DOWN past the caller's own evaluation of a_final - win - 2e-7 |a_final| (a <= a_final; fast.hip, rescore_kernel)
+                    t = fmaxf(t, a - win[row] - 4e-7f * fabsf(a));
+                }
+            }
+            if (lane == 0) thr[row] = t;
+        }
     }
 }
 
 int launch_select_groups(const float* sim, const uint8_t* gflag, int64_t M, int64_t Nc, int64_t ld, int64_t col_base, int k,
                          uint64_t* carry, float* thr, int mode, int64_t idx_base, float* top_score, int64_t* top_idx,
-                         hipStream_t st, const int* m_active, const int* row_map) {
+                         hipStream_t st, const int* m_active, const int* row_map, const float* win, int k_win) {
     if (M == 0) return ISX_OK;
     if (M >= (1ll << 31) || k > kGroupSelectMaxK) { isx_set_error("select_groups: unsupported M=%lld k=%d", (long long)M, k); return ISX_ERR_ARG; }
     const int ngrp = (int)((Nc + 31) / 32);
     hipLaunchKernelGGL(select_groups_kernel, dim3((unsigned)M), dim3(64), 0, st, sim, gflag, Nc, ld, ngrp, (uint32_t)col_base, k, carry, thr,
-                       mode, idx_base, top_score, top_idx, m_active, row_map);
+                       mode, idx_base, top_score, top_idx, m_active, row_map, win, k_win);
     ISX_CHECK_LAUNCH("select_groups");
     return ISX_OK;
 }

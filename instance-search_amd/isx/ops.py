@@ -441,11 +441,11 @@ def cosine_topk(Q, G, k, idx_base=0, ws=None, out=None):
 
 
 def gallery_to_f16(G):
-    """(Gh (N,D) fp16 scaled image, gstats (2,) f32) -- the cached gallery side of cosine_topk_fast."""
+    """(Gh (N,D) fp16 scaled image, gstats (4,) f32: max |g|^2, max |G|, max conversion loss^2, 0) -- the cached gallery side of cosine_topk_fast."""
     G = _f32(G, "G")
     N, D = G.shape
     Gh = torch.empty((N, D), device=G.device, dtype=torch.float16)
-    gstats = torch.empty((2,), device=G.device, dtype=torch.float32)
+    gstats = torch.empty((4,), device=G.device, dtype=torch.float32)
     check(lib().isx_gallery_to_f16(G.data_ptr(), N, D, Gh.data_ptr(), gstats.data_ptr(), _stream()), "isx_gallery_to_f16")
     return Gh, gstats
 
@@ -473,7 +473,7 @@ def cosine_topk_fast(Q, G, k, idx_base=0, gallery_f16=None, ws=None, out=None):
     gh = gs = 0
     if gallery_f16 is not None:
         Gh, gstats = gallery_f16
-        assert Gh.dtype == torch.float16 and Gh.shape == G.shape and Gh.is_contiguous() and gstats.numel() == 2
+        assert Gh.dtype == torch.float16 and Gh.shape == G.shape and Gh.is_contiguous() and gstats.numel() == 4
         gh, gs = Gh.data_ptr(), gstats.data_ptr()
     if ws is None:
         ws = torch.empty((cosine_topk_fast_workspace(M, N, D, k, gallery_f16 is not None),), device=Q.device, dtype=torch.uint8)

@@ -238,12 +238,88 @@ def test_fast_search_through_the_pingpong_filter_on_small_shapes(ops, force_f16_
 def test_gallery_to_f16_scaling(ops):
     rng = np.random.default_rng(21)
     G = unit(rng, 500, 64) * np.float32(0.3)
-    gh, gstats = ops.gallery_to_f16(dev(G))
     amax = np.abs(G).max()
     scale = 2.0 ** (13 - np.floor(np.log2(amax)))
-    np.testing.assert_array_equal(host(gh).view(np.uint16), (G * np.float32(scale)).astype(np.float16).view(np.uint16))
+    G[3, :5] = np.float32(1e-10) * np.arange(1, 6, dtype=np.float32)            # below the fp16 normal range after scaling: stored as zero
+    gh, gstats = ops.gallery_to_f16(dev(G))
+    want = (G * np.float32(scale)).astype(np.float16)
+    want[np.abs(want.astype(np.float32)) < 2.0 ** -14] = 0
+    assert (want[3, :5] == 0).all()
+    np.testing.assert_array_equal(host(gh).view(np.uint16), want.view(np.uint16))
     st = host(gstats)
-    assert st[1] == amax and st[0] >= (G.astype(np.float64) ** 2).sum(1).max() * (1 - 1e-6)
+    assert st.shape == (4,) and st[1] == amax and st[0] >= (G.astype(np.float64) ** 2).sum(1).max() * (1 - 1e-6)
+    # st[2]: the largest squared norm of what a row lost in the conversion -- an upper bound, and a tight one
+    lost = ((G.astype(np.float64) - want.astype(np.float64) / scale) ** 2).sum(1).max()
+    assert lost <= st[2] <= lost * 1.001
+    # the loss is what the error bound of the search now rests on: well below the format's worst case 2^-11 |g|
+    assert st[2] < (2.0 ** -11) ** 2 * st[0] * 0.5
+
+
+def _f16_scale(amax):
+    return 2.0 ** (13 - np.floor(np.log2(amax)))
+
+
+@pytest.mark.parametrize("case", ["random", "coherent", "tiny_tail", "alternating", "one_hot_plus_dust"])
+def test_fast_error_bound_covers_the_approximate_scores(ops, case):
+    """The window of the exact-fast search rests on |S' - S| <= eps_i with eps_i built from what the fp16 conversion LOST (fast.hip header):
+    eps_i = 1.01 (rq_i (|g|max + rg) + |q_i| rg + 3 D 2^-24 (|q_i| + rq_i)(|g|max + rg)).  Checked pair by pair against float64 scores on
+    rows built to make the bound work hard: `coherent` = every element of every row the same value a hair below an fp16 rounding midpoint
+    (all losses have one sign and Cauchy-Schwarz is an equality: the bound must be nearly TIGHT there, which is what gives this test teeth)."""
+    rng = np.random.default_rng(5)
+    M, N, D = 96, 160, 2048
+    if case == "random":
+        Q, G = unit(rng, M, D), unit(rng, N, D)
+    elif case == "coherent":
+        c = np.float32(1.0 + 2.0 ** -11 * 0.998)                       # between the halves 1 and 1 + 2^-10: rounds down, loses ~2^-11
+        Q = np.full((M, D), c, np.float32)                             # |q| = c sqrt(D): the scaling is a power of two, c stays a hair below the midpoint
+        G = np.full((N, D), c, np.float32)
+        Q[1::2] *= np.float32(-1)
+    elif case == "tiny_tail":
+        Q, G = unit(rng, M, D), unit(rng, N, D)
+        Q[:, D // 2:] *= np.float32(1e-7); G[:, D // 3:] *= np.float32(3e-8)     # flushed to zero by the conversion: the loss is the element itself
+    elif case == "alternating":
+        c = np.float32(1.0 + 2.0 ** -11 * 0.998)
+        sgn = np.where(np.arange(D) % 2 == 0, 1, -1).astype(np.float32)
+        Q = np.full((M, D), c, np.float32) * sgn
+        G = np.full((N, D), c, np.float32) * sgn
+    else:
+        Q = np.zeros((M, D), np.float32); G = np.zeros((N, D), np.float32)
+        Q[np.arange(M), rng.integers(0, D, M)] = 1; G[np.arange(N), rng.integers(0, D, N)] = 1
+        Q += rng.standard_normal((M, D)).astype(np.float32) * np.float32(2e-5); G += rng.standard_normal((N, D)).astype(np.float32) * np.float32(2e-5)
+    qh, qst = ops.gallery_to_f16(dev(Q))
+    gh, gst = ops.gallery_to_f16(dev(G))
+    qst, gst = host(qst), host(gst)
+    sq, sg = _f16_scale(qst[1]), _f16_scale(gst[1])
+    approx = host(ops.cosine_sim_f16(qh, gh)).astype(np.float64) / (sq * sg)
+    exact = Q.astype(np.float64) @ G.astype(np.float64).T
+    qt, gt = host(qh).astype(np.float64) / sq, host(gh).astype(np.float64) / sg
+    rq = np.sqrt(((Q - qt) ** 2).sum(1)); rg_rows = np.sqrt(((G - gt) ** 2).sum(1))
+    qn = np.sqrt((Q.astype(np.float64) ** 2).sum(1))
+    gn, rg = np.sqrt(float(gst[0])), np.sqrt(float(gst[2]))
+    assert rg >= rg_rows.max() and rg <= rg_rows.max() * 1.001 + 1e-30           # the statistic the library keeps IS the largest loss
+    eps = 1.01 * (rq * (gn + rg) + qn * rg + 3 * D * 2.0 ** -24 * (qn + rq) * (gn + rg))
+    err = np.abs(approx - exact)
+    assert (err <= eps[:, None]).all(), (case, float((err / eps[:, None]).max()))
+    if case == "coherent":
+        assert (err / eps[:, None]).max() > 0.6                                   # the bound is within 1.7x of an error that really occurs (rounding term: equality)
+    if case == "random":
+        assert eps.max() < 1e-3                                                    # ~7.6e-4 at D = 2048, against 1.34e-3 for the format's worst case
+
+
+def test_rows_on_both_sides_of_a_rounding_midpoint(ops):
+    """Constant rows whose value straddles an fp16 rounding midpoint: every loss has one sign (the error bound's Cauchy-Schwarz step is an
+    equality), rows below the midpoint collapse onto ONE approximate score while their exact scores all differ, rows above it jump by 2^-10.
+    The windows of the queries that rank into the collapsed block cannot be covered by the candidate list -- those rows must take the exact
+    fallback -- and the lists must still be the oracle's, bit for bit, in canonical order."""
+    rng = np.random.default_rng(31)
+    D, N, M, k = 256, 6000, 40, 50
+    mid = 1.0 + 2.0 ** -11
+    c = (mid + (rng.random(N) - 0.99) * 2.0 ** -11 * 0.9).astype(np.float32)           # ~1 % of the rows above the midpoint, the rest below
+    G = np.repeat(c[:, None], D, 1)
+    G[:, 0] += (rng.random(N).astype(np.float32) - 0.5) * np.float32(1e-3)             # a little individuality outside the collapsed pattern
+    Q = np.abs(unit(rng, M, D)) + np.float32(0.05)
+    fb = check_vs_oracle(ops, Q, G.astype(np.float32), k, idx_base=2)
+    assert fb > 0
 
 
 def test_sharded_gallery_fast_equals_fp32(ops):
