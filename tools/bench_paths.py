@@ -18,9 +18,20 @@ from utils.dataset import synthetic_descriptors  # noqa: E402
 
 
 def timed(f, n=3, w=1):
+    """Seconds per call.  Calls shorter than a few milliseconds are repeated until the timed region holds >= 40 ms of work (and the
+    warm-up as much): three launches of a sub-millisecond kernel out of an idle chip measure its clock ramp, not the kernel."""
     for _ in range(w):
         f()
     torch.cuda.synchronize()
+    t = time.perf_counter()
+    f()
+    torch.cuda.synchronize()
+    one = time.perf_counter() - t
+    if one < 0.013:
+        n = max(n, min(400, int(0.04 / max(one, 1e-5))))
+        for _ in range(n):
+            f()
+        torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(n):
         f()
