@@ -43,6 +43,10 @@ namespace isx {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
+#ifndef ISX_PP_STAMP            // scratch/lab/f16_pp_epi_lab.hip defines it: shader-clock stamps at the phase boundaries of gemm_f16_pp_kernel
+#define ISX_PP_STAMP(i)
+#endif
+
 // ---- 1. fp32 -> fp16 rows ------------------------------------------------------------------------
 // stats words are bit patterns of non-negative floats (unsigned order == float order) accumulated with
 // atomicMax: order independent, deterministic.  stats[0] = max squared row norm (upper bound), stats[1] = max |x|.
@@ -467,6 +471,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __rest
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    ISX_PP_STAMP(0);
 
     f32x4_t acc[2][2][4][2];
 #pragma unroll
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __rest
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (wm == 1) __builtin_amdgcn_s_barrier();                  // waves 4-7 run one barrier behind (wave-uniform branch)
+    ISX_PP_STAMP(1);
 
     for (int t = 0; t < T; ++t) {
         const char* buf = lds + (t & 1) * PP_BUF_B;
@@ -575,6 +581,7 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __rest
         __builtin_amdgcn_s_barrier();
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();                  // pairs the extra barrier of waves 4-7: every LDS read is behind us now
+    ISX_PP_STAMP(2);
 
     // epilogue.  C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r.  The two 16-column tiles j = 0, 1 of a
     // piece form one 32-column group of the filter.  The k loop is short (fp16 rate), so the epilogue is kept lean: thresholds
@@ -587,8 +594,17 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __rest
         if (tid < GBM) thr_s[tid] = (m0 + tid < M) ? thr[m0 + tid] : INFINITY;
         __syncthreads();
     }
+    ISX_PP_STAMP(3);
     const int l15 = lane & 15, lq = lane >> 4;
     const bool interior = (m0 + GBM <= M) && (n0 + GBN <= N);           // uniform: the common case carries no edge tests at all
+    // the thresholds of this lane's 32 rows: eight 16-B LDS reads in flight together (one exposed latency instead of sixteen)
+    f32x4_t t4s[2][4];
+    if (FILTER) {
+#pragma unroll
+        for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t4s[ah][i] = *reinterpret_cast<const f32x4_t*>(thr_s + ah * 128 + wm * 64 + i * 16 + lq * 4);
+    }
     auto store_tile = [&](auto IN) {
         constexpr bool IN_ = decltype(IN)::value;
 #pragma unroll
@@ -603,7 +619,18 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __rest
                     const int rbase = ah * 128 + wm * 64 + i * 16 + lq * 4;   // tile row of r = 0
                     float* cp = C + (m0 + rbase) * ldc + na;
                     if (FILTER) {
-                        const f32x4_t t4 = *reinterpret_cast<const f32x4_t*>(thr_s + rbase);
+                        const f32x4_t t4 = t4s[ah][i];
+                        if (IN_) {
+                            // block reject first: the epilogue is VALU-issue-bound (two waves per SIMD, ~1 k instructions each: 10 % of a
+                            // workgroup's life by shader-clock stamps, scratch/lab/f16_pp_epi_lab.hip) and with tight thresholds most 16 x 32
+                            // blocks hold no candidate at all.  fmaxf drops a NaN operand, as the two compares below do.
+                            const bool any = fmaxf(acc[ah][bh][i][0][0], acc[ah][bh][i][1][0]) >= t4[0] || fmaxf(acc[ah][bh][i][0][1], acc[ah][bh][i][1][1]) >= t4[1] ||
+                                             fmaxf(acc[ah][bh][i][0][2], acc[ah][bh][i][1][2]) >= t4[2] || fmaxf(acc[ah][bh][i][0][3], acc[ah][bh][i][1][3]) >= t4[3];
+                            if (__ballot(any) == 0ull) {
+                                if (l15 == 0) *reinterpret_cast<unsigned*>(flg_s + (bh * 4 + wn) * 256 + rbase) = 0u;
+                                continue;
+                            }
+                        }
                         unsigned fl = 0;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -633,15 +660,24 @@ __global__ __launch_bounds__(512) void gemm_f16_pp_kernel(const _Float16* __rest
     };
     if (interior) store_tile(std::true_type{});
     else store_tile(std::false_type{});
+    ISX_PP_STAMP(4);
     if (FILTER) {
         __syncthreads();
         if (tid < GBM && m0 + tid < M) {
             uint8_t* fp = gflag + (m0 + tid) * (int64_t)ngrp + (n0 >> 5);
+            if (interior && (ngrp & 7) == 0 && (((uintptr_t)gflag) & 7) == 0) {      // the eight flag bytes of a row as ONE 8-byte store (n0 / 32 is a multiple of 8)
+                unsigned long long v = 0ull;
 #pragma unroll
-            for (int g = 0; g < 8; ++g)
-                if (interior || n0 + g * 32 < N) fp[g] = flg_s[g * 256 + tid];
+                for (int g = 0; g < 8; ++g) v |= (unsigned long long)flg_s[g * 256 + tid] << (8 * g);
+                *reinterpret_cast<unsigned long long*>(fp) = v;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 8; ++g)
+                    if (interior || n0 + g * 32 < N) fp[g] = flg_s[g * 256 + tid];
+            }
         }
     }
+    ISX_PP_STAMP(5);
 }
 
 static std::atomic<int> g_force_f16_tile{-1};        // debug / A-B hook: 0 = 128x128, 1 = 256x256, 2 = 256x256 register-staged (2b), -1 = automatic
