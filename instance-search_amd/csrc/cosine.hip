@@ -347,7 +347,7 @@ int launch_cosine_gemm_filter(const float* Q, int64_t M, const float* G, int64_t
 // 32-column groups whose best score reaches thr are stored and read back, so for typical data the
 // M x N matrix is never written -- just one float per 32 scores.  Exact for any data: in the worst
 // case (every group qualifies) the chunk is simply materialised in full, as in round 0.
-constexpr int64_t kFirstChunk = 8192;
+static const int64_t kFirstChunk = [] { const char* e = getenv("ISX_TOPK_FIRST"); const long long v = e ? atoll(e) : 0; return (int64_t)(v >= 256 ? v / 256 * 256 : 8192); }();      // A/B knob; default 8192
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 // ---- chunked running top-k driver (shared by isx_cosine_topk and the fast path of fast.hip) ------
@@ -356,7 +356,7 @@ size_t topk_chunk_bytes(int64_t M, int64_t nc) { return align256((size_t)M * ((n
 
 int64_t topk_recommended_chunk(int64_t M, int64_t N) {
     // whole matrix if it is <= 1 GiB, else column chunks of ~1 GiB (multiple of 2048 columns)
-    const size_t budget = (size_t)1 << 30;
+    static const size_t budget = [] { const char* e = getenv("ISX_TOPK_CHUNK_MB"); const long long v = e ? atoll(e) : 0; return (size_t)(v >= 64 ? v : 1024) << 20; }();   // A/B knob; default 1 GiB
     int64_t nc = N;
     if ((size_t)M * N * 4 > budget) {
         nc = (int64_t)(budget / ((size_t)M * 4));
