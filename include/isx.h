@@ -248,7 +248,7 @@ int isx_average_precision(const int64_t* ranked, int64_t M, int64_t N, const int
 /* The same AP values straight from the score matrix, WITHOUT the full sort: AP only depends on the
  * ranks of the query's positives (every other rank adds exactly 0 in utils/metrics.py:34-44), and
  * rank(p) = #{gallery keys above key(p)} is one streaming pass.  Bit-identical to
- * isx_rank_full + isx_average_precision.  Queries with more than 256 positives get ap = -1.0
+ * isx_rank_full + isx_average_precision.  Queries with more than 2048 positives get ap = -1.0
  * (use the sorted path for those); NaN where the reference returns None.  sim: (M,N). */
 int isx_average_precision_sim(const float* sim, int64_t M, int64_t N, const int32_t* qlab, const int32_t* glab,
                               int kth, double* ap, isx_stream_t stream);

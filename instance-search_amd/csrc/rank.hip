@@ -167,30 +167,32 @@ __global__ __launch_bounds__(RK_THREADS) void average_precision_kernel(const int
 // ----------------------------------------------- average precision without the sort --
 // AP only depends on the RANKS OF THE POSITIVES: the reference's loop (utils/metrics.py:34-44) adds
 // (recall - old_recall) * (...) at every rank, which is exactly 0 unless the rank holds a positive.
-// rank(p) = #{gallery keys > key(p)}, so one streaming pass over the score row with the (few)
-// positive keys held in registers replaces the full sort.  Per query: <= AP_MAXP positives (more ->
-// ap = -1, the caller uses rank_full + average_precision).  Same float64 terms, summed in rank
-// order by one thread -> bit-identical to the sorted path and to the reference.
-constexpr int AP_MAXP = 256;             // positives per query the sort-free kernel handles (more -> ap = -1: the caller sorts that row)
+// Per query row: (1) the canonical keys of the P positives are collected and sorted (descending) in LDS; (2) ONE pass over the
+// score row: a gallery key x below the smallest positive key cannot precede any positive and is dropped after one compare (on
+// retrieval data that is nearly every x); any other x finds b(x) = #{positives > x} by binary search in the sorted keys and counts
+// into a histogram H[b]; (3) rank of the i-th positive (in rank order) = sum_{b <= i} H[b] - 1 (itself), a prefix sum; (4) the same
+// float64 terms as the reference, added in rank order by one thread -> bit-identical to the sorted path and to the reference.
+// O(N log P) compares per row instead of the O(N P) of the first sort-free kernel (1 k x 100 k, 100 positives per query: 3.2 ms ->
+// see BASELINE.md; 900 positives were SLOWER than the full sort).  Up to AP_MAXP positives per query (more -> ap = -1, the caller
+// uses rank_full + average_precision for that row).
+constexpr int AP_MAXP = 2048;            // positives per query the sort-free kernel handles; 16 KB keys (later: terms) + 8 KB histogram
 
 // NT threads per query row; VEC: 16-B loads of the score row and the label array (N % 4 == 0, both 16-B aligned).  One workgroup per row is
-// latency-bound when there are few rows (1 000 queries x 100 000 gallery rows: 256 threads walked 390 dependent load -> compare steps twice,
-// 0.54 ms): few-row launches run 1024 threads per row with four elements per load (25 steps).
+// latency-bound when there are few rows: few-row launches run 1024 threads per row with four elements per load.
 template <int NT, bool VEC>
 __global__ __launch_bounds__(NT) void average_precision_sim_kernel(const float* __restrict__ sim, int64_t N,
                                                                    const int32_t* __restrict__ qlab,
                                                                    const int32_t* __restrict__ glab, int kth,
                                                                    double* __restrict__ ap_out) {
-    __shared__ uint64_t pkey[AP_MAXP];
-    __shared__ int pcnt[AP_MAXP];
-    __shared__ double terms[AP_MAXP];        // AP term of the positive that is h-th in rank order (among the counted ones)
-    __shared__ int npos_s;
+    __shared__ __attribute__((aligned(16))) uint64_t pkey[AP_MAXP];     // positive keys, sorted descending; re-used for the float64 terms
+    __shared__ int hist[AP_MAXP];                                         // H[b], then the rank of the b-th positive
+    __shared__ int wsum[NT / 64];
+    __shared__ int npos_s, skip_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int64_t row = blockIdx.x;
     const int32_t q = qlab[row];
     const float* r = sim + row * N;
-    if (tid == 0) npos_s = 0;
-    for (int p = tid; p < AP_MAXP; p += NT) { pcnt[p] = 0; pkey[p] = ~0ull; }
+    if (tid == 0) { npos_s = 0; skip_s = 0; }
     __syncthreads();
     auto found = [&](int64_t j, float v) {
         const int slot = atomicAdd(&npos_s, 1);
@@ -218,56 +220,78 @@ __global__ __launch_bounds__(NT) void average_precision_sim_kernel(const float* 
     const int64_t n_pos = (int64_t)n_lab - (kth - 1);
     if (n_pos <= 0) { if (tid == 0) ap_out[row] = __longlong_as_double(0x7FF8000000000000ll); return; }
     if (n_lab > AP_MAXP) { if (tid == 0) ap_out[row] = -1.0; return; }
-    // ranks: count, for every positive, the gallery keys above it.  The pass is bound by its 64-bit compares (N x positives per row), so it is
-    // instantiated for 8 / 16 / 32 register slots; a row walks its positives in chunks of 32 (one more pass over the L2-resident score row per
-    // chunk) and the last chunk takes the smallest instantiation that holds it (unused slots hold ~0: never exceeded)
-    auto count_pass = [&](auto np_tag, int base) {
-        constexpr int NP = decltype(np_tag)::value;
-        uint64_t pk[NP];
-        int cnt[NP];
-#pragma unroll
-        for (int p = 0; p < NP; ++p) { pk[p] = (base + p < AP_MAXP) ? pkey[base + p] : ~0ull; cnt[p] = 0; }
-        if (VEC) {
-            const float4* r4 = reinterpret_cast<const float4*>(r);
-            for (int64_t j4 = tid; j4 < (N >> 2); j4 += NT) {
-                const float4 v = r4[j4];
-                const uint64_t x0 = rank_key(v.x, (uint32_t)(4 * j4)), x1 = rank_key(v.y, (uint32_t)(4 * j4 + 1));
-                const uint64_t x2 = rank_key(v.z, (uint32_t)(4 * j4 + 2)), x3 = rank_key(v.w, (uint32_t)(4 * j4 + 3));
-#pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    cnt[p] += ((x0 > pk[p]) ? 1 : 0) + ((x1 > pk[p]) ? 1 : 0) + ((x2 > pk[p]) ? 1 : 0) + ((x3 > pk[p]) ? 1 : 0);
-            }
-        } else {
-            for (int64_t j = tid; j < N; j += NT) {
-                const uint64_t x = rank_key(r[j], (uint32_t)j);
-#pragma unroll
-                for (int p = 0; p < NP; ++p) cnt[p] += (x > pk[p]) ? 1 : 0;
-            }
+    // (1) sort the positives (the collection order above is arbitrary); padding keys 0 sort last
+    int n2 = 2;
+    while (n2 < n_lab) n2 <<= 1;
+    for (int p = n_lab + tid; p < n2; p += NT) pkey[p] = 0ull;
+    for (int p = tid; p < n_lab; p += NT) hist[p] = 0;
+    __syncthreads();
+    bitonic_sort_desc<NT>(pkey, n2);
+    __syncthreads();
+    // (2) one pass over the row
+    const uint64_t pmin = pkey[n_lab - 1];
+    auto count = [&](uint64_t x) {
+        if (x < pmin) return;                                    // precedes no positive
+        int lo = 0, hi = n_lab;                                  // b = #{i : pkey[i] > x}  (x >= pmin: b <= n_lab - 1)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (pkey[mid] > x) lo = mid + 1; else hi = mid;
         }
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int c = wave_sum(cnt[p]);
-            if (lane == 0 && c && base + p < AP_MAXP) atomicAdd(&pcnt[base + p], c);
-        }
+        atomicAdd(&hist[lo], 1);
     };
-    for (int base = 0; base < n_lab; base += 32) {
-        const int left = n_lab - base;
-        if (left <= 8) count_pass(std::integral_constant<int, 8>{}, base);
-        else if (left <= 16) count_pass(std::integral_constant<int, 16>{}, base);
-        else count_pass(std::integral_constant<int, 32>{}, base);
+    if (VEC) {
+        const float4* r4 = reinterpret_cast<const float4*>(r);
+        for (int64_t j4 = tid; j4 < (N >> 2); j4 += NT) {
+            const float4 v = r4[j4];
+            count(rank_key(v.x, (uint32_t)(4 * j4)));
+            count(rank_key(v.y, (uint32_t)(4 * j4 + 1)));
+            count(rank_key(v.z, (uint32_t)(4 * j4 + 2)));
+            count(rank_key(v.w, (uint32_t)(4 * j4 + 3)));
+        }
+    } else {
+        for (int64_t j = tid; j < N; j += NT) count(rank_key(r[j], (uint32_t)j));
     }
     __syncthreads();
-    // every positive p knows its rank pcnt[p] (distinct: canonical keys never tie).  h = the counted positives ranked before it; its term goes
-    // to terms[h] and ONE thread adds the terms in rank order -- the order of the reference's loop, hence the same float64 bits
-    const double dn = (double)n_pos;
-    for (int p = tid; p < n_lab; p += NT) {
-        const int rp = pcnt[p];
-        if (rp < kth - 1) continue;                              // the first kth-1 ranks are skipped entirely
-        int h = 0;
-        for (int o = 0; o < n_lab; ++o) {
-            const int ro = pcnt[o];
-            h += (ro >= kth - 1 && ro < rp) ? 1 : 0;
+    // (3) inclusive prefix sum of H over the n_lab buckets -> rank of the i-th positive = prefix - 1.  Thread t owns the EPT consecutive
+    // buckets t * EPT ...; wave totals through LDS.
+    constexpr int EPT = (AP_MAXP + NT - 1) / NT;
+    int loc[EPT], tsum = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid * EPT + e;
+        loc[e] = (i < n_lab) ? hist[i] : 0;
+        tsum += loc[e];
+    }
+    int incl = tsum;                                             // inclusive scan over the lanes of the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int before = incl - tsum;
+    for (int w = 0; w < (tid >> 6); ++w) before += wsum[w];
+    __syncthreads();                                             // every hist[] value is in registers: the ranks may overwrite them
+    int skipped = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid * EPT + e;
+        before += loc[e];
+        if (i < n_lab) {
+            hist[i] = before - 1;                                // the positive itself sits in bucket i
+            skipped += (before - 1 < kth - 1) ? 1 : 0;          // the first kth-1 ranks are skipped entirely (a prefix of the rank order)
         }
+    }
+    if (skipped) atomicAdd(&skip_s, skipped);
+    __syncthreads();
+    // (4) terms in rank order
+    double* terms = reinterpret_cast<double*>(pkey);             // the keys are no longer needed
+    const int i0 = skip_s;
+    const double dn = (double)n_pos;
+    __syncthreads();
+    for (int i = i0 + tid; i < n_lab; i += NT) {
+        const int rp = hist[i], h = i - i0;
         const int64_t j = rp - (kth - 1);
         const double recall = (double)(h + 1) / dn, old_recall = (double)h / dn;
         const double precision = (double)(h + 1) / ((double)j + 1.0);
@@ -276,10 +300,8 @@ __global__ __launch_bounds__(NT) void average_precision_sim_kernel(const float* 
     }
     __syncthreads();
     if (tid == 0) {
-        int counted = 0;
-        for (int p = 0; p < n_lab; ++p) counted += (pcnt[p] >= kth - 1) ? 1 : 0;
         double ap = 0.0;
-        for (int h = 0; h < counted; ++h) ap += terms[h];
+        for (int h = 0; h < n_lab - i0; ++h) ap += terms[h];     // ONE thread, rank order: the order of the reference's loop, hence the same float64 bits
         ap_out[row] = ap;
     }
 }

@@ -541,7 +541,7 @@ def average_precision(ranked, qlab, glab, kth=1):
 
 
 def average_precision_sim(sim, qlab, glab, kth=1):
-    """AP per query straight from the score matrix (no sort).  Rows with more than 256 positives are
+    """AP per query straight from the score matrix (no sort).  Rows with more than 2048 positives are
     recomputed through rank_full + average_precision, so the result always equals the sorted path."""
     sim = _f32(sim, "sim")
     M, N = sim.shape
