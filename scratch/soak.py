@@ -7,14 +7,23 @@ import oracle as O
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(time.time()))
 g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
-t0 = time.time(); n = {"fast": 0, "conv1": 0, "conv3": 0, "dual": 0, "topk": 0, "sel": 0, "stem": 0, "pool": 0, "region": 0, "dba": 0, "gemm": 0}
+t0 = time.time(); n = {"fast": 0, "conv1": 0, "conv3": 0, "dual": 0, "topk": 0, "sel": 0, "stem": 0, "pool": 0, "region": 0, "dba": 0, "gemm": 0, "ap": 0}
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 last = t0
 while time.time() - t0 < budget:
     if time.time() - last > 60:                      # a line a minute: gpurun takes seven silent minutes for a hang
         last = time.time(); print("... %.0f s" % (last - t0), n, flush=True)
-    kind = rng.integers(0, 11)
-    if kind == 0:      # fast vs fp32 search
+    kind = rng.integers(0, 12)
+    if len(sys.argv) > 2: kind = int(rng.choice([int(v) for v in sys.argv[2].split(',')]))      # restrict to some kinds: soak.py 300 0,11
+    if kind == 11:     # sort-free AP vs full sort + AP (float64, bit for bit), any number of positives per query, tied scores
+        M = int(rng.integers(1, 60)); N = int(rng.integers(10, 70000)); L = int(rng.integers(1, max(2, N // int(rng.integers(1, 40))) + 1)); kth = int(rng.integers(1, 4))
+        sim = torch.round(torch.rand(M, N, device="cuda", generator=g) * float(rng.choice([50, 1000, 1e6]))) / 1000
+        if rng.integers(3) == 0: sim = sim.sort(dim=1, descending=bool(rng.integers(2))).values
+        gl = torch.randint(0, L, (N,), device="cuda", generator=g).int(); ql = torch.randint(0, L + 1, (M,), device="cuda", generator=g).int()
+        a = ops.average_precision_sim(sim, ql, gl, kth); b = ops.average_precision(ops.rank_full(sim), ql, gl, kth)
+        assert torch.equal(a.isnan(), b.isnan()) and torch.equal(a[~a.isnan()], b[~b.isnan()]), ("ap", M, N, L, kth)
+        n["ap"] += 1
+    elif kind == 0:      # fast vs fp32 search
         M = int(rng.integers(1, 3000)); N = int(rng.integers(300, 200000)); D = int(rng.choice([8, 16, 64, 96, 256, 512, 1024, 2048])); k = int(rng.integers(1, 129))
         if M * N * D > 4e11: continue
         Q = torch.randn(M, D, device="cuda", generator=g); G = torch.randn(N, D, device="cuda", generator=g)
