@@ -275,6 +275,30 @@ def test_topk_rows_adversarial(ops):
     assert (host(ti)[2] == np.arange(k)).all()
 
 
+@pytest.mark.parametrize("N,k", [(300, 64), (20000, 64), (65536, 100), (100003, 7)])
+def test_topk_rows_non_finite_and_signed_zero_scores(ops, N, k):
+    """NaNs of both signs, infinities, signed zeros and denormals among the scores: the selection kernel's cheap reject (a float compare
+    against the score of the threshold key) must hand every such value to the canonical key compare, whose order is the oracle's
+    (+NaN above +inf, -NaN below -inf, -0 folded onto +0, index ascending among equals)."""
+    rng = np.random.default_rng(N + k)
+    M = 6
+    sim = rng.standard_normal((M, N)).astype(np.float32)
+    special = np.array([np.nan, -np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-45, -1e-45, 3.4e38, -3.4e38], np.float32)
+    special.view(np.uint32)[1] |= 0x80000000                                # make the second one a NEGATIVE NaN whatever numpy did with the sign
+    for r in range(M):
+        pos = rng.choice(N, size=min(N // 2, 40 * (r + 1)), replace=False)
+        sim[r, pos] = special[rng.integers(0, len(special), pos.size)]
+    sim[4] = np.where(rng.random(N) < 0.5, np.float32(0.0), np.float32(-0.0))      # a row of signed zeros only: index order decides
+    sim[5, : N // 2] = np.nan                                                # more NaNs than k: the list is all NaN, lowest indices first
+    ts, ti = ops.topk_rows(dev(sim), k, idx_base=3)
+    os_, oi = O.topk_rows(sim, k, idx_base=3)
+    np.testing.assert_array_equal(host(ti), oi)
+    fold = lambda a: np.where(a == 0, np.float32(0.0), a).view(np.uint32)           # a score of -0 leaves the key domain as +0 (equal as numbers)
+    np.testing.assert_array_equal(fold(host(ts)), fold(os_))                        # everything else bit for bit, NaN payloads included
+    assert (host(ti)[4] == np.arange(k) + 3).all()
+    assert np.isnan(host(ts)[5]).all() and (host(ti)[5] == np.arange(k) + 3).all()
+
+
 @pytest.mark.parametrize("M,N", [(1, 1), (5, 24), (12, 40), (3, 4096), (4, 4097), (6, 10000), (2, 70000)])
 def test_rank_full_and_ap(ops, M, N):
     rng = np.random.default_rng(N)
