@@ -334,6 +334,22 @@ def test_average_precision_sim_equals_sorted_path(ops, M, N, L):
         np.testing.assert_array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
 
 
+def test_average_precision_sim_with_non_finite_scores(ops):
+    """NaN / inf / signed-zero scores: the sort-free AP ranks by the canonical keys only, like the full sort."""
+    rng = np.random.default_rng(99)
+    M, N, L = 8, 30000, 60
+    sim = rng.standard_normal((M, N)).astype(np.float32)
+    special = np.array([np.nan, np.inf, -np.inf, 0.0, -0.0, 1e-45], np.float32)
+    for r in range(M):
+        pos = rng.choice(N, size=500 * (r + 1), replace=False)
+        sim[r, pos] = special[rng.integers(0, len(special), pos.size)]
+    gl = (np.arange(N) % L).astype(np.int32)
+    ql = (np.arange(M) % L).astype(np.int32)
+    want = O.average_precision(O.rank_full(sim), ql, gl, 1)
+    got = host(ops.average_precision_sim(dev(sim), dev(ql), dev(gl), 1))
+    np.testing.assert_array_equal(got, want)
+
+
 def test_metrics_golden(ops, golden):
     g = golden("metrics.npz")
     sim, ql, gl = g["sim"], g["qlab"], g["glab"]
