@@ -21,6 +21,11 @@
  *     the process (relaxed atomics: flipping one while another host thread
  *     launches is a data-race-free way to get either tile shape), never change a
  *     result, and are not part of this ABI.)
+ *   - environment, read once per process, tuning only (no value changes a result):
+ *     ISX_TAIL_SPLIT=0 (128x128 grids without the 64x64 tail), ISX_TOPK_CHUNK_MB
+ *     (score-chunk budget of the running top-k, default 1024), ISX_TOPK_FIRST
+ *     (bootstrap chunk, default 8192 columns), ISX_FAST_KL_PCT (candidates kept per
+ *     query by the fp16 filter, in % of k, default 200)
  *   - return 0 = ISX_OK, <0 = error; isx_last_error() gives a thread-local message
  *   - canonical ranking order everywhere: (score DESCENDING, index ASCENDING),
  *     -0.0 == +0.0; gallery indices must be < 2^32
