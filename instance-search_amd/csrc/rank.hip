@@ -240,14 +240,24 @@ __global__ __launch_bounds__(NT) void average_precision_sim_kernel(const float* 
         atomicAdd(&hist[lo], 1);
     };
     if (VEC) {
+        // four 16-B loads in flight per thread (the loop is latency-bound otherwise: few rows, two workgroups per CU), and a float compare
+        // in front of the key compare: v < the smallest positive SCORE implies key < pmin (neither a NaN)
         const float4* r4 = reinterpret_cast<const float4*>(r);
-        for (int64_t j4 = tid; j4 < (N >> 2); j4 += NT) {
-            const float4 v = r4[j4];
+        const float smin = key_score(pmin);
+        const int64_t n4 = N >> 2;
+        auto take4 = [&](int64_t j4, const float4& v) {
+            if (v.x < smin && v.y < smin && v.z < smin && v.w < smin) return;
             count(rank_key(v.x, (uint32_t)(4 * j4)));
             count(rank_key(v.y, (uint32_t)(4 * j4 + 1)));
             count(rank_key(v.z, (uint32_t)(4 * j4 + 2)));
             count(rank_key(v.w, (uint32_t)(4 * j4 + 3)));
+        };
+        int64_t j4 = tid;
+        for (; j4 + 3 * NT < n4; j4 += 4 * NT) {
+            const float4 v0 = r4[j4], v1 = r4[j4 + NT], v2 = r4[j4 + 2 * NT], v3 = r4[j4 + 3 * NT];
+            take4(j4, v0); take4(j4 + NT, v1); take4(j4 + 2 * NT, v2); take4(j4 + 3 * NT, v3);
         }
+        for (; j4 < n4; j4 += NT) take4(j4, r4[j4]);
     } else {
         for (int64_t j = tid; j < N; j += NT) count(rank_key(r[j], (uint32_t)j));
     }
