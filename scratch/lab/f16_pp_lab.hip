@@ -20,6 +20,7 @@ extern "C" int isx_cosine_sim_f16(const void* Qh, int64_t M, const void* Gh, int
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16w __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HT_B = 128 * BK * 2;          // one half-tile: 128 rows x 128 B = 16 KB
@@ -326,6 +327,135 @@ __global__ __launch_bounds__(512) void gemm_pp2(const _Float16* __restrict__ Q, 
 }
 
 template <int MF>
+__global__ __launch_bounds__(512) void gemm_pp2w(const _Float16* __restrict__ Q, int64_t M, const _Float16* __restrict__ G, int64_t N, int D,
+                                                float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int nwg = tiles_m * tiles_n;
+    const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (b >> 3);
+    constexpr int GN = 8;
+    const int per_group = GN * tiles_m, gid = wg / per_group, first_n = gid * GN;
+    const int gsz = min(GN, tiles_n - first_n), within = wg - gid * per_group;
+    const int64_t m0 = (int64_t)(within / gsz) * BM, n0 = (int64_t)(first_n + within % gsz) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    // a wave's 64 x 32 piece of a quadrant as TWO v_mfma_f32_32x32x16_f16 tiles (half the operand-register reads per FLOP of the 16x16x32 form)
+    f32x16w acc[2][2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][bb][i][e] = 0.0f;
+    const _Float16* gsrc[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int slot = ht_slot(j);
+        const bool isb = slot >= 2;
+        const int half_ = slot & 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wave * 16 + i * 8 + (lane >> 3);
+            int64_t gr = (isb ? n0 : m0) + half_ * 128 + r;
+            const int64_t lim = isb ? N : M;
+            gr = gr < lim ? gr : lim - 1;
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            gsrc[j][i] = (isb ? G : Q) + gr * D + c * 8;
+        }
+    }
+    const int T = D / BK;
+    auto issue = [&](int j, int t) {
+        char* dst = lds + (t & 1) * BUF_B + ht_slot(j) * HT_B + wave * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc[j][i] + t * BK),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    };
+    // 32x32x16 fragments: lane l holds row (l & 31), chunk 2 s + (l >> 5) of its row, s = 0..3 over the 64-k tile
+    const int l31 = lane & 31, hsw = (l31 >> 1) & 7;
+    int a_ad[4], b_ad[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int c = ((2 * s + (lane >> 5)) ^ hsw) << 4;
+        a_ad[s] = wm * 64 * 128 + l31 * 128 + c;
+        b_ad[s] = 2 * HT_B + wn * 32 * 128 + l31 * 128 + c;
+    }
+    half8 af[2][4], bf[2][4];
+    auto read_a = [&](const char* buf, int ah) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) af[i][s] = *reinterpret_cast<const half8*>(buf + ah * HT_B + i * 4096 + a_ad[s]);
+    };
+    auto read_b = [&](const char* buf, int bh) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) bf[bh][s] = *reinterpret_cast<const half8*>(buf + bh * HT_B + b_ad[s]);
+    };
+    auto mfmas2 = [&](int ah) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[ah][bh][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][s], bf[bh][s], acc[ah][bh][i], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+#pragma unroll
+    for (int h = 0; h < 6; ++h)
+        if (h / 4 < T) issue(h % 4, h / 4);
+    if (T > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < T; ++t) {
+        const char* buf = lds + (t & 1) * BUF_B;
+        // ---- phase A
+        read_a(buf, 0);
+        read_b(buf, 0);
+        read_b(buf, 1);
+        if (t + 1 < T) { issue(2, t + 1); issue(3, t + 1); }
+        LGKMCNT0();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas2(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- phase B
+        read_a(buf, 1);
+        if (t + 2 < T) { issue(0, t + 2); issue(1, t + 2); asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LGKMCNT0();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas2(1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int ah = 0; ah < 2; ++ah)
+#pragma unroll
+        for (int bh = 0; bh < 2; ++bh)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int64_t n = n0 + bh * 128 + wn * 32 + l31;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t m = m0 + ah * 128 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (m < M && n < N) C[m * ldc + n] = acc[ah][bh][i][e];
+                }
+            }
+}
+
+template <int MF>
 __global__ __launch_bounds__(512) void gemm_pp3(const _Float16* __restrict__ Q, int64_t M, const _Float16* __restrict__ G, int64_t N, int D,
                                                 float* __restrict__ C, int64_t ldc, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -474,6 +604,12 @@ static void launch_pp3(const _Float16* Q, int64_t M, const _Float16* G, int64_t 
     hipLaunchKernelGGL(gemm_pp3<0>, dim3(tm * tn), dim3(512), 2 * BUF_B, 0, Q, M, G, N, D, C, N, tm, tn);
 }
 
+static void launch_pp2w(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C) {
+    const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
+    static bool once = false;
+    if (!once) { CK(hipFuncSetAttribute((const void*)gemm_pp2w<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF_B)); once = true; }
+    hipLaunchKernelGGL(gemm_pp2w<0>, dim3(tm * tn), dim3(512), 2 * BUF_B, 0, Q, M, G, N, D, C, N, tm, tn);
+}
 static void launch_pp2(const _Float16* Q, int64_t M, const _Float16* G, int64_t N, int D, float* C) {
     const int tm = (int)((M + BM - 1) / BM), tn = (int)((N + BN - 1) / BN);
     static bool once = false;
@@ -544,6 +680,9 @@ int main(int argc, char** argv) {
         t = time_ms([&] { launch_pp2(dq, M, dg, N, D, c1); });
         CK(hipGetLastError());
         printf("ping-pong 2 phases         : %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
+        t = time_ms([&] { launch_pp2w(dq, M, dg, N, D, c1); });
+        CK(hipGetLastError());
+        printf("ping-pong 2 ph, 32x32x16   : %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
         t = time_ms([&] { launch_pp3(dq, M, dg, N, D, c1); });
         CK(hipGetLastError());
         printf("ping-pong, DMA in MFMA segs: %.3f ms  %.0f TF\n", t, fl / t * 1e-9);
@@ -559,6 +698,9 @@ int main(int argc, char** argv) {
     CK(hipMemset(c1, 0xFF, (size_t)M * N * 4));
     launch_pp2(dq, M, dg, N, D, c1); CK(hipDeviceSynchronize());
     compare("ping-pong 2 phases");
+    CK(hipMemset(c1, 0xFF, (size_t)M * N * 4));
+    launch_pp2w(dq, M, dg, N, D, c1); CK(hipDeviceSynchronize());
+    compare("ping-pong 2 phases, 32x32x16");
     CK(hipMemset(c1, 0xFF, (size_t)M * N * 4));
     launch_pp3(dq, M, dg, N, D, c1); CK(hipDeviceSynchronize());
     compare("ping-pong, DMA in MFMA segs");
