@@ -16,9 +16,12 @@ rank extracts B images and holds a 10k-row gallery shard.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
            --master-port 29500 bench.py --gpus 8 --steps 10 --warmup 3
 
-Rank 0 prints ONE JSON line (metric / value / roofline / cpu_baseline ...).  The K timed steps carry no
-per-kernel instrumentation; the per-kernel HIP-event timings behind the `roofline*` objects come from a
-separate instrumented pass over the same step.
+Rank 0 prints the record twice: first `{"bench_detail": {...}}` -- everything (per-family and per-layer-shape rooflines, every
+side measurement in full), also written to `bench_detail.json` (gpurun_out/ when that directory exists, else next to this
+file) -- and then, as the LAST stdout line, the compact record the driver parses (<= 6 KB: metric / value / ms_per_step / config /
+ONE `roofline` for the dominant kernel family / `roofline_step` / `retrieval_shard` / `extraction_regions` / `cpu_baseline`).
+The K timed steps carry no per-kernel instrumentation; the per-kernel HIP-event timings behind the `roofline*` objects come
+from a separate instrumented pass over the same step.
 
 N > 1: the search stage of step i (all-gather of the query descriptors, score GEMM against this rank's shard, top-k, all-gather of the
 per-shard lists + isx_topk_merge) is issued on a second HIP stream behind an event and rides behind the trunk of step i + 1
@@ -173,6 +176,149 @@ def cpu_baseline(args, gallery_cpu, images_cpu):
             "sample": "%d images (%d passes over %d): torch-CPU fp32 %s trunk + mean-pool + L2 + torch.mm vs the %d-row gallery + topk(%d), "
                       "%d threads, %.1f s" % (n, passes, nb, args.backbone, G.size(0), args.k, threads, dt),
             "top1_matches_oracle_on_sample": checked}
+
+
+def cpu_baseline_retrieval(args, seconds=6.0):
+    """The retrieval half of the metric on the host cores (reference test/classif_finetune_test.py:82 + utils/metrics.py:25-55):
+    `torch.mm(Q, G.t())` fp32 + `topk(k)` on a 1k x 62.5k x 2048 slice of BASELINE configs[4] (1/10 of the queries x 1/16 of the rows;
+    distances/s is size-independent for a GEMM this large, so the figure is quoted per distance, not scaled), repeated for a bounded time,
+    and the reference's literal per-rank Python AP loop (oracle.avg_precision_literal -- the checker's restatement, timed here as the
+    CPU baseline only) on a few queries of a 10k-row gallery -> ms per query."""
+    import torch
+    threads = usable_cpus()
+    torch.set_num_threads(threads)
+    M, N, D, k = 1000, 62500, 2048, args.k
+    g = torch.Generator().manual_seed(5)
+    Q = torch.nn.functional.normalize(torch.randn(M, D, generator=g), dim=1)
+    G = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=1)
+    torch.mm(Q[:64], G.t()).topk(k, dim=1)                   # warm the thread pool
+    t_mm = t_topk = 0.0
+    reps, t0 = 0, time.time()
+    while True:
+        a = time.time()
+        sim = torch.mm(Q, G.t())
+        b = time.time()
+        sim.topk(k, dim=1)
+        c = time.time()
+        t_mm += b - a; t_topk += c - b
+        reps += 1
+        el = time.time() - t0
+        if reps >= 20 or el + el / reps > seconds:
+            break
+    out = {"value": reps * M * N / (t_mm + t_topk), "unit": "distances/s", "cores": threads, "kind": "port",
+           "sample": "%d x (torch.mm + topk(%d)) on %d queries x %d rows x %d (a 1/10 x 1/16 slice of configs[4]), fp32, %d threads, %.1f s"
+                     % (reps, k, M, N, D, threads, t_mm + t_topk),
+           "mm_ms": 1e3 * t_mm / reps, "topk_ms": 1e3 * t_topk / reps, "mm_tflops": 2.0 * M * N * D * reps / t_mm / 1e12}
+    try:                                                    # the literal rank-by-rank AP loop of the reference, on a 10k-row gallery
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        Ng, nq = 10000, 8
+        lab_g = [i % (Ng // 10) for i in range(Ng)]
+        simq = torch.mm(Q[:nq], G[:Ng].t())
+        a = time.time()
+        aps = [O.avg_precision_literal(simq[i], i % (Ng // 10), lab_g) for i in range(nq)]
+        out["ap_loop_ms_per_query"] = 1e3 * (time.time() - a) / nq
+        out["ap_loop_sample"] = "%d queries x %d gallery rows: sort + the per-rank Python loop of utils/metrics.py:25-45" % (nq, Ng)
+        assert all(x is not None for x in aps)
+    except Exception as e:
+        out["ap_loop_error"] = "%s: %s" % (type(e).__name__, e)
+    return out
+
+
+# ---- the driver's line ------------------------------------------------------------------------------------------------
+MAX_LINE_BYTES = 6144
+
+
+def _r(x, nd=4):
+    """numbers to `nd` significant digits (the side file keeps full precision)"""
+    if isinstance(x, float):
+        return float("%.*g" % (nd, x))
+    if isinstance(x, dict):
+        return {k_: _r(v, nd) for k_, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k_: d[k_] for k_ in keys if isinstance(d, dict) and k_ in d}
+
+
+def compact_line(full, detail_file=None):
+    """The full record -> the line the driver parses: the contract's scalar fields verbatim, ONE `roofline` (dominant kernel family),
+    a one-number-per-family table, and the headline numbers of the side measurements.  Everything else stays in the side file.
+    Guaranteed <= MAX_LINE_BYTES: optional objects are dropped (largest first) if a future field ever pushes it over."""
+    line = _pick(full, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                        "dtype", "data", "config", "dist_per_s"))
+    ro = full.get("roofline")
+    if isinstance(ro, dict):
+        line["roofline"] = _pick(ro, ("family", "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit",
+                                      "traffic_over_algorithmic", "traffic_source", "share_of_step", "launches_per_step", "ms_per_step",
+                                      "algorithmic_flop_per_step", "algorithmic_bytes_per_step", "frac_of_per_launch_rooflines", "timing"))
+        if isinstance(line["roofline"].get("traffic_source"), str):
+            line["roofline"]["traffic_source"] = line["roofline"]["traffic_source"].split(":")[0]
+    else:
+        line["roofline"] = None
+    if isinstance(full.get("roofline_step"), dict):
+        line["roofline_step"] = _pick(full["roofline_step"], ("bound", "achieved", "peak", "unit", "frac", "algorithmic_flop_per_step_per_gpu"))
+    fams = {}
+    for key, o in full.items():
+        if key.startswith("roofline_") and key != "roofline_step" and isinstance(o, dict):
+            fams[key[len("roofline_"):]] = [o.get("bound"), o.get("frac"), o.get("ms_per_step", o.get("launch_ms"))]
+    if fams:
+        line["families"] = {"columns": ["bound", "frac", "ms_per_step"], "rows": fams}
+    sh = full.get("retrieval_shard")
+    if isinstance(sh, dict):
+        c = _pick(sh, ("error", "shape", "gallery_rows_per_gpu", "k", "ms", "dist_per_s", "tflops_end_to_end", "frac_of_f16_mfma_peak",
+                       "identical_to_fp32_path", "includes"))
+        if isinstance(sh.get("fp32_path"), dict):
+            c["fp32_path"] = _pick(sh["fp32_path"], ("ms", "dist_per_s", "frac_of_f32_mfma_peak"))
+        line["retrieval_shard"] = c
+    rg = full.get("extraction_regions")
+    if isinstance(rg, dict):
+        c = _pick(rg, ("error", "images_per_s", "ms_per_launch", "images_per_launch", "all_convolutions_in_libisx", "images_per_s_all_gpus", "note"))
+        if isinstance(rg.get("roofline"), dict):
+            c["roofline"] = _pick(rg["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic"))
+        if isinstance(rg.get("retrieval_1000x100000"), dict):
+            c["retrieval_1000x100000"] = _pick(rg["retrieval_1000x100000"], ("descriptor_dim", "total_ms", "dist_per_s",
+                                                                              "cosine_sim_frac_of_f32_mfma_peak", "mAP"))
+        c["workload"] = "BASELINE configs[2]: ResNet-50 TuneClassifSub @448x448 -> best-location descriptors"
+        line["extraction_regions"] = c
+    if "exchange_ms" in full:
+        line["exchange_ms"] = full["exchange_ms"]
+        line["exchange"] = _pick(full.get("exchange") or {}, ("query_allgather_ms", "result_allgather_merge_ms", "exposed_when_serialised_frac_of_step",
+                                                              "overlapped", "overlap_identical", "implementation"))
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("error", "value", "unit", "cores", "kind", "sample", "cpu_model", "top1_matches_oracle_on_sample"))
+        if isinstance(cb.get("retrieval"), dict):
+            c["retrieval"] = _pick(cb["retrieval"], ("error", "value", "unit", "cores", "kind", "sample", "mm_tflops", "ap_loop_ms_per_query",
+                                                      "ap_loop_sample", "ap_loop_error"))
+        line["cpu_baseline"] = c
+    if detail_file:
+        line["detail_file"] = detail_file
+    line = _r(line)
+    for key in ("value", "ms_per_step", "dist_per_s"):          # the contract's scalars keep their digits
+        if key in full:
+            line[key] = full[key]
+    for victim in ("families", "exchange", "extraction_regions", "retrieval_shard", "roofline_step"):      # never expected: a safety net
+        if len(json.dumps(line)) <= MAX_LINE_BYTES:
+            break
+        line.pop(victim, None)
+        line.setdefault("dropped_for_size", []).append(victim)
+    return line
+
+
+def write_detail(full):
+    """The full record -> bench_detail.json (gpurun_out/ when present: that directory travels back from the GPU box)."""
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    path = os.path.join(out_dir if os.path.isdir(out_dir) else ROOT, "bench_detail.json")
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except Exception:
+        return None
 
 
 def load_traffic():
@@ -341,10 +487,7 @@ def main():
 
     def exchange(s, i):
         """per-shard lists of every rank -> merged global lists (RCCL all-gather x 2 + isx_topk_merge)"""
-        all_s = torch.empty((world, M, k), dtype=s.dtype, device=dev)
-        all_i = torch.empty((world, M, k), dtype=i.dtype, device=dev)
-        dist.all_gather_into_tensor(all_s.view(-1, k), s)
-        dist.all_gather_into_tensor(all_i.view(-1, k), i)
+        all_s, all_i = retrieval.exchange_topk(s, i)          # RCCL group: isx_shard_topk_allgather (one grouped launch on this stream)
         return ops.topk_merge(all_s, all_i)
 
     # deferred mode (N > 1): everything behind the descriptors of a step -- query all-gather, score GEMM, top-k, result all-gathers, merge -- is
@@ -646,6 +789,7 @@ def main():
             line["exchange_ms"] = tot
             line["exchange"] = dict(ex, exposed_when_serialised_frac_of_step=(tot / ms_per_step if tot is not None else None),
                                     overlapped=overlap, overlap_identical=overlap_identical,
+                                    implementation=retrieval.exchange_backend(None, True) + " + isx_topk_merge",
                                     legs="query all-gather | per-shard top-k all-gather x 2 + isx_topk_merge"
                                          + (" (with the score GEMM and the top-k between them on a second stream, behind the next step's trunk)" if overlap else ""),
                                     timing="HIP events on the launch stream, max over ranks, %d instrumented steps with the exchange in line" % ksteps)
@@ -654,9 +798,17 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args, shard.cpu(), images_cpu)
             except Exception as e:
                 line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(line), flush=True)
+            try:
+                line["cpu_baseline"]["retrieval"] = cpu_baseline_retrieval(args)
+            except Exception as e:
+                line["cpu_baseline"]["retrieval"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        detail_file = write_detail(line)
+        print(json.dumps({"bench_detail": line}), flush=True)          # everything, on an EARLIER line (and in the side file)
+        print(json.dumps(compact_line(line, detail_file)), flush=True)      # the driver's line: last on stdout, <= 6 KB
     if world > 1:
         dist.barrier()
+        torch.cuda.synchronize()
+        retrieval.close_native_comms()
         dist.destroy_process_group()
 
 

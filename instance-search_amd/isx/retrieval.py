@@ -7,7 +7,8 @@ rows [lo_p, hi_p) (contiguous split).  A search is
        fp16-MFMA filter + exact fp32 re-scoring, bit-identical to isx_cosine_topk; the fp16 image of
        the shard is built once and cached)
     2. ONE all-gather of the (M,k) fp32 scores and (M,k) int64 global indices over RCCL/xGMI
-       (12 B per entry: 12 MB per rank at M = 10k, k = 100 -- tiny next to the GEMM)
+       (12 B per entry: 12 MB per rank at M = 10k, k = 100 -- tiny next to the GEMM): `exchange_topk`, which on GPU tensors
+       in an RCCL process group is the C ABI's `isx_shard_topk_allgather` (one grouped launch on the caller's stream)
     3. canonical merge of the P*k candidates per query                  (libisx isx_topk_merge)
 The canonical comparator (score desc, GLOBAL index asc) makes the result independent of P and
 of the gather order: sharded == unsharded bit for bit (tests/test_distributed.py).
@@ -92,6 +93,56 @@ class NativeComm(object):
             self.handle = None
 
 
+_NATIVE_COMMS = {}            # torch.distributed group -> the libisx communicator opened over it (one per process and group)
+
+
+def native_comm_for(group=None):
+    """The libisx RCCL communicator of `group`, opened on first use (a collective: every rank of the group gets here together, at its
+    first exchange) and kept for the life of the process."""
+    nc = _NATIVE_COMMS.get(group)
+    if nc is None:
+        nc = _NATIVE_COMMS[group] = NativeComm(group)
+    return nc
+
+
+def close_native_comms():
+    for nc in _NATIVE_COMMS.values():
+        nc.close()
+    _NATIVE_COMMS.clear()
+
+
+def exchange_backend(group=None, cuda=True):
+    """Which implementation exchange_topk takes for tensors on (cuda ? the GPU : the host) in this process group."""
+    import os
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return "none (one rank)"
+    if cuda and dist.get_backend(group) == "nccl" and os.environ.get("ISX_NATIVE_COMM", "1") != "0":
+        return "isx_shard_topk_allgather (libisx: one grouped ncclAllGather pair over RCCL)"
+    return "torch.distributed all_gather_into_tensor x 2 (%s)" % dist.get_backend(group)
+
+
+def exchange_topk(s, i, group=None, native_comm=None):
+    """THE exchange step of the sharded search: per-shard (M,k) lists of every rank -> (P,M,k) rank-major, on every rank.
+    GPU tensors in an RCCL ("nccl") process group go through the C ABI's `isx_shard_topk_allgather` -- scores and indices as ONE grouped
+    RCCL launch on the caller's stream; CPU tensors / gloo groups (the world_size-2 CPU tests, ISX_BENCH_ONE_DEVICE) through
+    torch.distributed.  ISX_NATIVE_COMM=0 forces the torch.distributed path (A/B)."""
+    if native_comm is None and (not dist.is_initialized() or dist.get_world_size(group) == 1):
+        return s[None], i[None]
+    if native_comm is None and s.is_cuda and exchange_backend(group).startswith("isx_"):
+        native_comm = native_comm_for(group)
+    if native_comm is not None and s.is_cuda:
+        if native_comm.nranks == 1:
+            return s[None], i[None]
+        return native_comm.allgather_topk(s.contiguous(), i.contiguous())
+    P = dist.get_world_size(group)
+    all_s = torch.empty((P,) + tuple(s.shape), dtype=s.dtype, device=s.device)
+    all_i = torch.empty((P,) + tuple(i.shape), dtype=i.dtype, device=i.device)
+    # concatenated (P*M, k) views: the layout both RCCL and gloo accept for an all-gather
+    dist.all_gather_into_tensor(all_s.view(-1, s.size(1)), s.contiguous(), group=group)
+    dist.all_gather_into_tensor(all_i.view(-1, i.size(1)), i.contiguous(), group=group)
+    return all_s, all_i
+
+
 class ShardedGallery(object):
     """This rank's slice of a row-sharded descriptor gallery."""
 
@@ -99,7 +150,7 @@ class ShardedGallery(object):
         self.shard = shard.contiguous()
         self.idx_base = int(idx_base)
         self.group = group
-        self.native_comm = native_comm        # NativeComm: all-gather issued by libisx instead of torch.distributed
+        self.native_comm = native_comm        # an explicit NativeComm (default: the group's own, opened on first use -- exchange_topk)
         self.fast = bool(fast) and self.shard.is_cuda
         self._ws = None
         self._f16 = None                      # (Gh, gstats), built on first search
@@ -162,18 +213,9 @@ class ShardedGallery(object):
     def search(self, Q, k):
         """Global canonical top-k for the (replicated) query block Q: (scores (M,k), idx (M,k))."""
         s, i = self.local_search(Q, k)
-        if self.native_comm is not None and s.is_cuda:
-            if self.native_comm.nranks == 1:
-                return s, i
-            return merge_topk(*self.native_comm.allgather_topk(s, i))
-        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+        all_s, all_i = exchange_topk(s, i, self.group, self.native_comm)
+        if all_s.size(0) == 1:
             return s, i
-        P = dist.get_world_size(self.group)
-        all_s = torch.empty((P,) + tuple(s.shape), dtype=s.dtype, device=s.device)
-        all_i = torch.empty((P,) + tuple(i.shape), dtype=i.dtype, device=i.device)
-        # concatenated (P*M, k) views: the layout both RCCL and gloo accept for an all-gather
-        dist.all_gather_into_tensor(all_s.view(-1, s.size(1)), s, group=self.group)
-        dist.all_gather_into_tensor(all_i.view(-1, i.size(1)), i, group=self.group)
         return merge_topk(all_s, all_i)
 
 

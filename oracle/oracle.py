@@ -192,6 +192,30 @@ def average_precision(ranked, qlab, glab, kth=1):
     return ap
 
 
+def avg_precision_literal(sim_row, query_label, gallery_labels, kth=1):
+    """utils/metrics.py:25-45 as the reference runs it: ONE query, a descending sort of its score row and a pure-Python walk over
+    every rank (old_recall / old_precision trapezoid).  `sim_row`: 1-d torch tensor or numpy array; labels: Python list.  Used by
+    tests (against isxo_average_precision) and timed by bench.py's cpu_baseline leg as the reference's mAP cost per query."""
+    row = np.asarray(sim_row, dtype=np.float32)
+    n_pos = sum(1 for l in gallery_labels if l == query_label) - (kth - 1)
+    if n_pos <= 0:
+        return None
+    ranked = np.argsort(-row, kind="stable")              # canonical tie-break (score desc, index asc); the reference's sort is unspecified on ties
+    old_recall, old_precision, ap = 0.0, 1.0, 0.0
+    inter, j = 0, 0
+    for n, k in enumerate(ranked.tolist()):
+        if n + 1 < kth:
+            continue
+        if gallery_labels[k] == query_label:
+            inter += 1
+        recall = inter / float(n_pos)
+        precision = inter / (j + 1.0)
+        ap += (recall - old_recall) * ((old_precision + precision) / 2.0)
+        old_recall, old_precision = recall, precision
+        j += 1
+    return ap
+
+
 def mean_avg_precision(ap):
     """utils/metrics.py:48-55: plain sequential Python sum over the non-skipped queries."""
     vals = [float(a) for a in ap if not np.isnan(a)]

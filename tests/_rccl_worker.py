@@ -43,6 +43,11 @@ def main():
         gal = R.ShardedGallery(Gd[lo:hi], lo, fast=fast)
         s, i = gal.search(Qd, k)
         res["dist_" + name] = (s.cpu(), i.cpu())
+    assert R.exchange_backend().startswith("isx_shard_topk_allgather")        # the default exchange of an RCCL group is the C-ABI entry
+    os.environ["ISX_NATIVE_COMM"] = "0"                                        # A/B: the same search over torch.distributed's all-gather
+    s, i = R.ShardedGallery(Gd[lo:hi], lo).search(Qd, k)
+    res["torchdist"] = (s.cpu(), i.cpu())
+    del os.environ["ISX_NATIVE_COMM"]
     nc = R.NativeComm()
     assert nc.nranks == world
     gal = R.ShardedGallery(Gd[lo:hi], lo, native_comm=nc)
@@ -84,6 +89,8 @@ def main():
         res["ref_flat"] = torch.cat([p.grad.reshape(-1) for p in ref.parameters()]).cpu()
     torch.save(res, "%s.%d" % (out, rank))
     dist.barrier()
+    torch.cuda.synchronize()
+    R.close_native_comms()
     dist.destroy_process_group()
 
 

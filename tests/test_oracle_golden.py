@@ -102,6 +102,10 @@ def test_metrics(golden):
         assert (p1, c, t) == tuple(g["p1_kth%d" % kth])
         np.testing.assert_array_equal(hit, g["p1_maxlabel_kth%d" % kth])
         np.testing.assert_array_equal(ts[:, kth - 1], g["p1_maxsim_kth%d" % kth])
+        # the literal per-query Python loop (timed by bench.py's cpu_baseline leg) against the reference's own values
+        lit = [O.avg_precision_literal(sim[i], int(ql[i]), gl.tolist(), kth) for i in range(sim.shape[0])]
+        assert [x is None for x in lit] == list(np.isnan(ref))
+        assert [x for x in lit if x is not None] == list(ref[~np.isnan(ref)])
     rt = O.rank_full(g["tie_sim"])
     apt = O.average_precision(rt, g["tie_qlab"], g["tie_glab"], 1)
     np.testing.assert_array_equal(apt, g["tie_ap"])

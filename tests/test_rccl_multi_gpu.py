@@ -47,7 +47,7 @@ def test_rccl_sharded_search_and_grad_allreduce(tmp_path):
     r = [torch.load("%s.%d" % (out, k)) for k in range(world)]
     us, ui = r[0]["unsharded"]
     for k in range(world):
-        for name in ("dist_fast", "dist_f32", "native", "replicated"):
+        for name in ("dist_fast", "dist_f32", "torchdist", "native", "replicated"):
             s, i = r[k][name]
             assert torch.equal(i, ui), (k, name)                               # ranked lists: bit-exact, every rank, every exchange path
             assert torch.equal(s.view(torch.int32), us.view(torch.int32)), (k, name)
@@ -66,6 +66,7 @@ def test_bench_two_gpus_bare_command_line():
     p = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines) == 2 and lines[0].startswith('{"bench_detail"') and len(lines[1]) <= 6144
+    d = json.loads(lines[1])
+    assert "isx_shard_topk_allgather" in d["exchange"]["implementation"] and d["exchange"]["overlap_identical"] is True
     assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 2 and d["value"] > 0
