@@ -216,9 +216,9 @@ def cpu_baseline_retrieval(args, seconds=6.0):
         lab_g = [i % (Ng // 10) for i in range(Ng)]
         simq = torch.mm(Q[:nq], G[:Ng].t())
         a = time.time()
-        aps = [O.avg_precision_literal(simq[i], i % (Ng // 10), lab_g) for i in range(nq)]
+        aps = [O.avg_precision_literal(simq[i], i % (Ng // 10), lab_g, 1, tensor_iteration=True) for i in range(nq)]
         out["ap_loop_ms_per_query"] = 1e3 * (time.time() - a) / nq
-        out["ap_loop_sample"] = "%d queries x %d gallery rows: sort + the per-rank Python loop of utils/metrics.py:25-45" % (nq, Ng)
+        out["ap_loop_sample"] = "%d queries x %d gallery rows: sort + the per-rank Python loop of utils/metrics.py:25-45, walked over a torch index tensor as the reference does" % (nq, Ng)
         assert all(x is not None for x in aps)
     except Exception as e:
         out["ap_loop_error"] = "%s: %s" % (type(e).__name__, e)

@@ -19,6 +19,9 @@ collectives by issue order, so the order must not depend on what a rank happened
 import torch
 import torch.distributed as dist
 
+# bytes this rank sent + received in the exchanges of the most recent optimizer step, by leg (tools/bench_train.py prints them)
+STATS = {}
+
 
 def broadcast_module_state(module, src=0, group=None):
     """Make every replica start from rank `src`'s parameters AND buffers (BatchNorm statistics, counters).

@@ -6,11 +6,13 @@ signatures, attributes and state-dict keys:
   DescriptorNet        (:92-130)   global siamese descriptor: features -> L2 -> Shift -> Linear -> L2
   RegionDescriptorNet  (:133-231)  descriptor summed over the k best-classified windows
 
-Backbone convolutions run through PyTorch-ROCm.  Everything after the last conv runs in the
-hand-written HIP kernels of libisx when the tensors are on the GPU and no autograd graph is
-being recorded (inference, the path this repo accelerates); with autograd or on CPU the
-same arithmetic runs as plain torch modules.
+Inference (no autograd graph, GPU): the BN-folded trunk and everything after the last conv run in the
+hand-written HIP kernels of libisx.  Training on the GPU: the FROZEN PREFIX of the trunk (the reference trains
+layer4 only, train/*_p.py:14-17) still runs as that folded HIP trunk, the trainable suffix and the head carry
+the autograd graph (_SplitTrunk).  On the CPU the same arithmetic runs as plain torch modules.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -119,35 +121,68 @@ class TuneClassifSub(TuneClassif):
         return [self.forward_single(x) for x in scales]
 
 
-def _frozen(module):
-    return not any(p.requires_grad for p in module.parameters())
+# A/B switch: ISX_SPLIT_TRUNK=0 (or model.siamese.SPLIT_TRUNK = False) runs the training trunk as plain `features(x)` -- the
+# "plain torch run" the split trunk is tested against.
+SPLIT_TRUNK = os.environ.get("ISX_SPLIT_TRUNK", "1") != "0"
 
 
-class _FrozenTrunk(object):
-    """Siamese training with a fully frozen backbone (untrained = -1, the reference's default): the trunk needs no
-    autograd graph, so it runs as the BN-folded inference trunk with the hand-written convolution kernels
-    (model/nn_utils.fold_batch_norm), built once -- frozen weights cannot change under it."""
+def first_trainable(features):
+    """Index of the first module of `features` that holds a trainable parameter (len(features): the whole trunk is frozen).
+    set_untrained_blocks freezes a PREFIX of the parameterised modules (reference model/nn_utils.py:5-23), so everything in front
+    of this index needs no autograd graph."""
+    for i, m in enumerate(features):
+        if any(p.requires_grad for p in m.parameters()):
+            return i
+    return len(features)
+
+
+class _SplitTrunk(object):
+    """Siamese training on the GPU: the trunk is cut at the first trainable block (the reference's configurations train layer4 of a
+    ResNet / conv5 of AlexNet: train/*_p.py:14-17,48; `untrained = -1` freezes everything).
+
+      frozen prefix   -- needs no autograd graph and cannot change under the optimiser, so it runs as the BN-folded inference trunk with
+                         the hand-written convolution kernels (model/nn_utils.fold_batch_norm) under no_grad, built once;
+      trainable suffix -- the original modules with autograd on the prefix's output (channels-last).
+
+    With BatchNorm learning (P.train_bn) or on the CPU the trunk is the plain `features(x)`."""
 
     def __init__(self):
         self.folded = None
         self.key = None
+        self.split = 0
 
-    def __call__(self, features, x):
-        if not (x.is_cuda and x.dtype == torch.float32 and _frozen(features)):
-            return features(x)
-        if _bn_training(features):
-            return features(x)                      # BN statistics are being updated: keep the plain trunk
-        # the folded copy is stale as soon as any weight or BN buffer under `features` is written in place (load_state_dict, an
-        # optimiser step) or replaced: identity + version counter of every tensor are the key (no state_dict() is built per call;
-        # writes through `.data` bypass the counters -- set `self.folded = None` after such surgery)
-        key = (id(features), str(x.device),
-               tuple((id(t), t._version) for t in features.parameters()), tuple((id(t), t._version) for t in features.buffers()))
+    def usable(self, features, x):
+        if not SPLIT_TRUNK:
+            return False
+        return x.is_cuda and x.dtype == torch.float32 and not _bn_training(features) and first_trainable(features) > 0
+
+    def prefix(self, features, x):
+        """frozen prefix of `features` on x -> (feature tensor without graph, index the suffix starts at)"""
+        split = first_trainable(features)
+        mods = list(features)[:split]
+        # the folded copy is stale as soon as any weight or BN buffer of the prefix is written in place (load_state_dict) or replaced, or
+        # the split moves: identity + version counter of every prefix tensor are the key (no state_dict() is built per call; writes
+        # through `.data` bypass the counters -- set `self.folded = None` after such surgery)
+        key = (id(features), str(x.device), split,
+               tuple((id(t), t._version) for m in mods for t in m.parameters()), tuple((id(t), t._version) for m in mods for t in m.buffers()))
         if self.folded is None or self.key != key:
             from .nn_utils import fold_batch_norm
-            self.folded = fold_batch_norm(features).to(x.device).to(memory_format=torch.channels_last)
-            self.key = key
+            self.folded = fold_batch_norm(nn.Sequential(*mods)).to(x.device).to(memory_format=torch.channels_last)
+            self.key, self.split = key, split
         with torch.no_grad():
-            return self.folded(x.contiguous(memory_format=torch.channels_last))
+            return self.folded(x.contiguous(memory_format=torch.channels_last)), split
+
+    @staticmethod
+    def suffix(features, f, split):
+        for m in list(features)[split:]:
+            f = m(f)
+        return f
+
+    def __call__(self, features, x):
+        if not self.usable(features, x):
+            return features(x)
+        f, split = self.prefix(features, x)
+        return self.suffix(features, f, split)
 
 
 def _bn_training(features):
@@ -187,40 +222,41 @@ class DescriptorNet(nn.Module):
         self.feature_size = feature_dim if feature_dim > 0 else get_feature_size(classifier)
         self.feature_reduc1 = _descriptor_head(in_features, self.feature_size)
         self.feature_reduc2 = NormalizeL2()
-        self._trunk = _FrozenTrunk()
+        self._trunk = _SplitTrunk()
 
     def forward_single(self, x):
         x = self._trunk(self.features, x) if self.training else self.features(x)
         x = x.reshape(x.size(0), -1)
         return self.feature_reduc2(_apply_head(self.feature_reduc1, x))
 
-    def _head_only(self, f):
-        """descriptor head + final L2 on trunk features (B, C, h, w) that were computed elsewhere"""
+    def _tail_and_head(self, f):
+        """trainable trunk suffix + descriptor head + final L2 on PREFIX features (B, C, h, w) that were computed elsewhere"""
+        f = _SplitTrunk.suffix(self.features, f, self._trunk.split)
         return self.feature_reduc2(_apply_head(self.feature_reduc1, f.reshape(f.size(0), -1)))
 
     def trunk_precomputable(self):
-        """True when precompute_trunk can serve training steps: training mode, every trunk parameter frozen, BatchNorm not learning, GPU."""
+        """True when precompute_trunk can serve training steps: training mode, GPU, a frozen trunk prefix, BatchNorm not learning."""
         p = next(self.features.parameters(), None)
-        return bool(self.training and p is not None and p.is_cuda and _frozen(self.features) and not _bn_training(self.features))
+        return bool(self.training and p is not None and p.is_cuda and not _bn_training(self.features) and first_trainable(self.features) > 0)
 
     def precompute_trunk(self, *xs):
-        """Training with a FROZEN trunk and frozen BatchNorm (the reference's default, untrained = -1): the trunk output of an image does not
-        depend on the batch it rides in and needs no autograd graph, so the trunk of a whole mini-batch can run as ONE launch of the folded
-        inference trunk instead of once per micro-batch of 8 triplets (24 images: far too few to fill the chip).  Returns the feature tensors
-        of the given image batches (same split), or None when the trunk has to run inside the step (trainable blocks, BatchNorm learning,
-        CPU tensors, eval mode)."""
+        """Training with a frozen trunk PREFIX and frozen BatchNorm (the reference's configurations: stem + layers 1-3 frozen, layer4
+        trained; or everything frozen with untrained = -1): the prefix output of an image does not depend on the batch it rides in and needs
+        no autograd graph, so the prefix of a whole mini-batch runs as ONE launch of the folded inference trunk instead of once per
+        micro-batch of 8 triplets (24 images: far too few to fill the chip).  Returns the prefix feature tensors of the given image batches
+        (same split), or None when the trunk has to run inside the step (nothing frozen, BatchNorm learning, CPU tensors, eval mode)."""
         if not self.training or not xs or not all(x.is_cuda and x.dtype == torch.float32 for x in xs):
             return None
-        if not _frozen(self.features) or _bn_training(self.features) or len(set(tuple(x.shape[1:]) for x in xs)) != 1:
+        if not self._trunk.usable(self.features, xs[0]) or len(set(tuple(x.shape[1:]) for x in xs)) != 1:
             return None
         sizes = [x.size(0) for x in xs]
-        f = self._trunk(self.features, torch.cat(xs, 0))
+        f, _ = self._trunk.prefix(self.features, torch.cat(xs, 0))
         return tuple(f.split(sizes, 0))
 
     def forward_features(self, f1, f2=None, f3=None):
-        """forward() of training mode on precomputed trunk features: the branches go through the head together, exactly as forward() sends them
-        through trunk + head together (same rows in the same (3 B, F) matrix: same bits)."""
-        return _many(self._head_only, [f for f in (f1, f2, f3) if f is not None])
+        """forward() of training mode on precomputed prefix features: the branches go through suffix + head together, exactly as forward()
+        sends them through the whole net together (same rows in the same batch: same bits)."""
+        return _many(self._tail_and_head, [f for f in (f1, f2, f3) if f is not None])
 
     def forward(self, x1, x2=None, x3=None):
         # the reference runs one trunk pass per branch (model/siamese.py:124-130); the branches share the weights, so with

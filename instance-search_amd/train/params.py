@@ -2,18 +2,40 @@
 (train/*_p.py: `P = Params()` built at import).  Only the fields of the retrieval path exist
 (test mains set: test_pre_proc, cuda_device, image_input_size, test_batch_size, preload_net,
 cnn_model, feature_size2d, embeddings_classify, feature_dim, num_classes, classif_model,
-bn_model, regions_k -- test/*_test.py:44-56); training hyper-parameters are out of scope.
+bn_model, regions_k -- test/*_test.py:44-56) and of siamese training (train/siamese_descriptor_p.py:62-101).
 Unlike the reference nothing is read from disk at import."""
 
 
+# Blocks of the base network that are NOT trained, lowest first (reference train/*_p.py:14-17,48: every training `Params` takes
+# `untrained_blocks[cnn_model.lower()]`).  A block is a module with parameters of `features`; for a ResNet the stem has two (conv1,
+# bn1) and every residual block is one, so the table freezes the stem and layers 1-3 and TRAINS layer4 (and conv5 of AlexNet).  The
+# reference lists alexnet and resnet152; its own comment gives ResNet-50's layout (3, 4, 6, 3), the BASELINE's backbone.
+UNTRAINED_BLOCKS = {
+    'alexnet': 4,
+    'resnet152': 2 + 3 + 8 + 36,
+    'resnet50': 2 + 3 + 4 + 6,
+    'resnet18': 2 + 2 + 2 + 2,
+}
+
+
 class Params(object):
+    @property
+    def untrained_blocks(self):
+        """The table's entry for the CURRENT cnn_model unless a value was assigned (P.untrained_blocks = -1 freezes the whole
+        trunk: descriptor-head-only training, this repo's round-2/3 benchmark configuration)."""
+        v = self.__dict__.get('_untrained_blocks')
+        return UNTRAINED_BLOCKS.get(str(self.cnn_model).lower(), -1) if v is None else v
+
+    @untrained_blocks.setter
+    def untrained_blocks(self, v):
+        self.__dict__['_untrained_blocks'] = v
+
     def __init__(self, **overrides):
         self.cnn_model = 'AlexNet'
         self.cuda_device = 0
         self.image_input_size = (3, 224, 224)
         self.num_classes = 464
         self.feature_size2d = (6, 6)
-        self.untrained_blocks = -1
         self.preload_net = ''
         self.bn_model = ''
         self.classif_model = ''

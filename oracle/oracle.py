@@ -192,7 +192,7 @@ def average_precision(ranked, qlab, glab, kth=1):
     return ap
 
 
-def avg_precision_literal(sim_row, query_label, gallery_labels, kth=1):
+def avg_precision_literal(sim_row, query_label, gallery_labels, kth=1, tensor_iteration=False):
     """utils/metrics.py:25-45 as the reference runs it: ONE query, a descending sort of its score row and a pure-Python walk over
     every rank (old_recall / old_precision trapezoid).  `sim_row`: 1-d torch tensor or numpy array; labels: Python list.  Used by
     tests (against isxo_average_precision) and timed by bench.py's cpu_baseline leg as the reference's mAP cost per query."""
@@ -203,7 +203,12 @@ def avg_precision_literal(sim_row, query_label, gallery_labels, kth=1):
     ranked = np.argsort(-row, kind="stable")              # canonical tie-break (score desc, index asc); the reference's sort is unspecified on ties
     old_recall, old_precision, ap = 0.0, 1.0, 0.0
     inter, j = 0, 0
-    for n, k in enumerate(ranked.tolist()):
+    if tensor_iteration:                                  # as the reference walks it: element by element of a torch LongTensor (0-d tensors as indices)
+        import torch
+        ranked_iter = torch.from_numpy(ranked)
+    else:
+        ranked_iter = ranked.tolist()
+    for n, k in enumerate(ranked_iter):
         if n + 1 < kth:
             continue
         if gallery_labels[k] == query_label:

@@ -419,3 +419,80 @@ def test_minibatch_trunk_precompute_is_bit_identical():
         assert torch.equal(a[k], b[k]), k
     torch.manual_seed(0)
     assert any("feature_reduc1" in k for k in a)
+
+
+def test_untrained_blocks_follow_the_reference_table():
+    """train/*_p.py:14-17,48 of the reference: untrained_blocks[cnn_model.lower()] -- layer4 of a ResNet (conv5 of AlexNet) is TRAINED."""
+    from isx import backbones
+    from model.siamese import DescriptorNet, TuneClassif, first_trainable
+    from train.params import Params, UNTRAINED_BLOCKS
+    assert UNTRAINED_BLOCKS["alexnet"] == 4 and UNTRAINED_BLOCKS["resnet152"] == 2 + 3 + 8 + 36 and UNTRAINED_BLOCKS["resnet50"] == 15
+    P = Params()
+    assert P.untrained_blocks == 4                        # AlexNet default
+    P.cnn_model = "ResNet152"
+    assert P.untrained_blocks == 49
+    P.untrained_blocks = -1
+    assert P.untrained_blocks == -1                       # an assigned value wins
+    P.untrained_blocks = None
+    P.cnn_model = "resnet50"
+    net = DescriptorNet(TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5, untrained=P.untrained_blocks), 16, (7, 7),
+                        untrained=P.untrained_blocks)
+    names = [n for n, p in net.named_parameters() if p.requires_grad and n.startswith("features.")]
+    split = first_trainable(net.features)
+    assert split == 4 + 3 + 4 + 6                          # conv1, bn1, relu, maxpool, then layers 1-3: the first block of layer4
+    assert names and all(int(n.split(".")[1]) >= split for n in names)
+    assert sum(1 for _ in net.features[split:]) == 3       # layer4 = 3 bottlenecks
+    frozen = DescriptorNet(TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5), 16, (7, 7), untrained=-1)
+    assert first_trainable(frozen.features) == len(frozen.features)
+
+
+@pytest.mark.gpu
+def test_reference_config_split_trunk_matches_plain_torch_training():
+    """The reference's training configuration (untrained_blocks from its table: stem + layers 1-3 frozen, layer4 + head trained): the frozen
+    prefix runs as the BN-folded HIP trunk without a graph, the suffix with autograd.  After two epochs of SGD (gradient accumulation,
+    semi-hard then hard mining) the weights equal the PLAIN torch run's (whole trunk = features(x) with autograd) to <= 1e-6 relative to the
+    weight scale, and layer4 really moved."""
+    import copy
+    import model.siamese as ms
+    from train import siamese_descriptor as sd
+    from utils.dataset import synthetic_image_set
+    saved = copy.copy(sd.P.__dict__)
+    tr = synthetic_image_set(32, 4, seed=1, structure=0.5)
+    te = synthetic_image_set(8, 4, seed=2, structure=0.5)
+    out, init = {}, None
+    try:
+        for split in (True, False):
+            ms.SPLIT_TRUNK = split
+            torch.manual_seed(0); random.seed(0)
+            P = sd.P
+            P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), 32
+            P.train_epochs, P.train_batch_size, P.train_micro_batch, P.test_batch_size = 2, 12, 4, 16
+            P.train_loss_int, P.train_epoch_switch, P.train_lr, P.train_pre_proc = 1000, 1, 1e-3, True
+            P.untrained_blocks = None                                  # the reference's table: 15 for ResNet-50
+            assert P.untrained_blocks == 15
+            if init is None:
+                init = {k: v.detach().clone() for k, v in sd.get_siamese_net().state_dict().items()}
+            torch.manual_seed(0); random.seed(0)
+            net, _ = sd.main(tr, tr, te)
+            assert net.trunk_precomputable() == split
+            out[split] = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    finally:
+        ms.SPLIT_TRUNK = True
+        sd.P.__dict__.clear(); sd.P.__dict__.update(saved)
+    a, b = out[True], out[False]
+    worst, moved4, moved_head = 0.0, 0.0, 0.0
+    for k in a:
+        if not a[k].dtype.is_floating_point:
+            continue
+        scale = float(b[k].abs().max()) + 1e-12
+        worst = max(worst, float((a[k] - b[k]).abs().max()) / scale)
+        d = float((b[k] - init[k].to(b[k].device)).abs().max())
+        if k.startswith("features.17.") or k.startswith("features.18.") or k.startswith("features.19."):
+            moved4 = max(moved4, d)
+        elif k.startswith("features."):
+            assert d == 0.0, k                                          # frozen prefix untouched
+        else:
+            moved_head = max(moved_head, d)
+    print("reference-config training, split trunk vs plain torch: max |dw| / max|w| = %.3g; layer4 moved %.3g, head moved %.3g" % (worst, moved4, moved_head))
+    assert moved4 > 0 and moved_head > 0
+    assert worst <= 1e-6
