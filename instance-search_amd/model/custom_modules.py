@@ -95,6 +95,45 @@ class Shift(nn.Module):
         return x + self.param.view(1, -1)
 
 
+class _RowDeferredLinearFn(Function):
+    """y = x W^T + b whose backward can hand the (x, dy) rows to the training step instead of forming dW itself (isx/dp.py RowSink)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from isx import dp
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy.mm(weight) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            sink = dp.current_sink()
+            if sink is not None and sink.accepts(weight):
+                sink.add(weight, x, dy)                    # dW = dY^T X is formed ONCE per optimizer step, over every micro-batch's (and rank's) rows
+            else:
+                dw = dp.weight_gradient_from_rows(dy, x)
+        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+class RowDeferredLinear(nn.Linear):
+    """nn.Linear (same parameters, same state-dict keys) for the descriptor head `Linear(100352 -> 2048)` (reference
+    model/siamese.py:104-114): ONE 822 MB weight.  Inside a training step (utils/train_general._Stepper) its weight gradient is not
+    accumulated micro-batch by micro-batch (eight read-modify-write passes over 822 MB) nor all-reduced (822 MB twice per rank): the
+    (x, dy) rows are collected -- 9.8 MB per micro-batch -- all-gathered across the ranks, and dW = dY^T X is formed once per step.
+    Outside a step (no RowSink active) it behaves exactly like nn.Linear."""
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            return _RowDeferredLinearFn.apply(x, self.weight, self.bias)
+        return torch.nn.functional.linear(x, self.weight, self.bias)
+
+
 # ---------------------------------------------------------------------------------------- losses
 def _triplet_rows(anchor, pos, neg, margin, normalized):
     """Per-row clamped loss (reference custom_modules.py:153-167)."""

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .custom_modules import NormalizeL2, Shift
+from .custom_modules import NormalizeL2, RowDeferredLinear, Shift
 from .nn_utils import convolutionalize, extract_layers, get_feature_size, set_untrained_blocks
 
 
@@ -151,10 +151,12 @@ class _SplitTrunk(object):
         self.key = None
         self.split = 0
 
+    @staticmethod
+    def enabled(features):
+        return SPLIT_TRUNK and not _bn_training(features) and first_trainable(features) > 0
+
     def usable(self, features, x):
-        if not SPLIT_TRUNK:
-            return False
-        return x.is_cuda and x.dtype == torch.float32 and not _bn_training(features) and first_trainable(features) > 0
+        return x.is_cuda and x.dtype == torch.float32 and self.enabled(features)
 
     def prefix(self, features, x):
         """frozen prefix of `features` on x -> (feature tensor without graph, index the suffix starts at)"""
@@ -201,7 +203,7 @@ def _many(forward_single, xs):
 
 
 def _descriptor_head(in_features, out_features):
-    return nn.Sequential(NormalizeL2(), Shift(in_features), nn.Linear(in_features, out_features))
+    return nn.Sequential(NormalizeL2(), Shift(in_features), RowDeferredLinear(in_features, out_features))
 
 
 def _apply_head(head, rows):
@@ -237,7 +239,7 @@ class DescriptorNet(nn.Module):
     def trunk_precomputable(self):
         """True when precompute_trunk can serve training steps: training mode, GPU, a frozen trunk prefix, BatchNorm not learning."""
         p = next(self.features.parameters(), None)
-        return bool(self.training and p is not None and p.is_cuda and not _bn_training(self.features) and first_trainable(self.features) > 0)
+        return bool(self.training and p is not None and p.is_cuda and _SplitTrunk.enabled(self.features))
 
     def precompute_trunk(self, *xs):
         """Training with a frozen trunk PREFIX and frozen BatchNorm (the reference's configurations: stem + layers 1-3 frozen, layer4

@@ -11,7 +11,7 @@ import torch
 
 from model.siamese import DescriptorNet, TuneClassif
 from model.custom_modules import TripletLoss
-from utils import (choose_rand_neg, embeddings_device_dim, fold_batches, get_pos_couples, get_similarities, log, move_device,
+from utils import (choose_rand_neg, choose_rand_neg_index, embeddings_device_dim, fold_batches, get_pos_couples, get_similarities, log, move_device,
                    tensor, test_print_descriptor, train_gen)
 from ._common import base_model, device_batch_size, load_weights, make_resident, stage_batch, stage_images, test_transform
 from .siamese_descriptor_p import P
@@ -106,6 +106,9 @@ def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, op
         missing = sum(1 for k in negs if k < 0)
         if missing:
             log(P, 'cant find semi-hard neg for {0} couples, falling back to random neg'.format(missing))
+        # the random fall-back (reference :108-131 draws it while the batch is built) is drawn here, once per epoch and in couple order: every
+        # data-parallel rank holds the same list, whatever slice of the mini-batches it will run
+        negs = [k if k >= 0 else choose_rand_neg_index(train_set, c[0]) for c, k in zip(shuffled, negs)]
         tagged = [c + (k,) for c, k in zip(shuffled, negs)]
         return tagged, {'epoch': epoch}
 

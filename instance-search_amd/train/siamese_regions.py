@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from model.siamese import RegionDescriptorNet, TuneClassifSub
 from model.custom_modules import TripletLoss
-from utils import (choose_rand_neg, fold_batches, get_pos_couples, get_similarities, log, move_device, tensor,
+from utils import (choose_rand_neg, choose_rand_neg_index, fold_batches, get_pos_couples, get_similarities, log, move_device, tensor,
                    test_print_descriptor, train_gen)
 from ._common import base_model, device_batch_size, fold_shape_buckets, load_weights, make_resident, scatter_rows, stage_batch, test_transform
 from .siamese_descriptor import mine_epoch_negatives, shuffle_couples
@@ -51,6 +51,7 @@ def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, cr
         similarities, _ = get_similarities(P, get_embeddings, net, testset_tuple[1])
         shuffled = shuffle_couples(couples)
         negs = mine_epoch_negatives(similarities, testset_tuple[1], shuffled, epoch < P.train_epoch_switch).tolist()
+        negs = [k if k >= 0 else choose_rand_neg_index(train_set, c[0]) for c, k in zip(shuffled, negs)]     # fixed per epoch, on every rank alike
         return [c + (k,) for c, k in zip(shuffled, negs)], {'epoch': epoch}
 
     def create_batch(batch, n, epoch):

@@ -55,6 +55,17 @@ def choose_rand_neg(train_set, lab):
             return im
 
 
+def choose_rand_neg_index(train_set, lab):
+    """Index of a random image whose label differs from `lab`: choose_rand_neg resolved to an index, so that the random fall-back
+    negatives of an epoch can be fixed when the epoch is created (identically on every data-parallel rank) instead of being drawn
+    while the batches are built."""
+    import random
+    while True:
+        k = random.randrange(len(train_set))
+        if train_set[k][1] != lab:
+            return k
+
+
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 

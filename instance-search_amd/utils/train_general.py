@@ -1,8 +1,8 @@
 """Batch fold driver and the generic training loop (reference utils/train_general.py): fold_batches
 (:27-38), anneal (:41-48), micro/mini-batch steps with gradient accumulation (:51-74), train_gen
 (:77-105), output_stats (:12-23).  Added: data-parallel execution -- with torch.distributed
-initialised every rank takes an equal slice of each mini-batch and the summed gradients are
-all-reduced over RCCL before the optimizer step (isx.dp.GradAllReducer)."""
+initialised every rank takes the micro-batches of its subtree of each mini-batch and the gradients are
+summed in a fixed tree order across the ranks (isx/dp.py), bit-identical to the single-process run."""
 import random
 
 import torch
@@ -59,67 +59,102 @@ def _dp():
 
 
 class _Stepper(object):
-    """One optimizer step = gradient accumulation over the micro-batches of this rank's slice of a mini-batch
-    (reference utils/train_general.py:51-74: micro_batch_gen / mini_batch_gen), then -- data parallel -- the
-    bucketed gradient all-reduce, overlapped with the backward of the last micro-batch."""
+    """One optimizer step = the gradients of the micro-batches of a mini-batch (reference utils/train_general.py:51-74: micro_batch_gen /
+    mini_batch_gen accumulate them one after the other), summed here in the canonical TREE order of isx/dp.py: a rank runs the
+    micro-batches of its subtree, TreeExchange finishes the sum across the ranks in the same order, and the descriptor head's 822 MB
+    weight gradient is formed once per step from the all-gathered (x, dy) rows (RowDeferredLinear / RowSink).  The update is therefore
+    bit-identical for 1, 2, 4, 8 ranks.  `P.train_grad_exchange = "allreduce"` (and world sizes that are not a power of two): sequential
+    accumulation over this rank's contiguous slice + bucketed all-reduce overlapped with the last backward (dp.GradAllReducer)."""
 
-    def __init__(self, P, net, make_batch, make_loss, reducer):
-        self.P, self.net, self.make_batch, self.make_loss, self.reducer = P, net, make_batch, make_loss, reducer
+    def __init__(self, P, net, make_batch, make_loss):
+        from isx import dp
+        from model.custom_modules import RowDeferredLinear
+        self.P, self.net, self.make_batch, self.make_loss = P, net, make_batch, make_loss
         self.rank, self.world = _dp()
+        mode = getattr(P, 'train_grad_exchange', 'tree')
+        if mode not in ('tree', 'allreduce'):
+            raise ValueError("P.train_grad_exchange must be 'tree' or 'allreduce', got %r" % (mode,))
+        if mode == 'tree' and not dp.is_power_of_two(self.world):
+            log(P, 'world size {0} is not a power of two: gradient exchange falls back to all-reduce (not bit-identical to one process)'.format(self.world))
+            mode = 'allreduce'
+        self.mode = mode
+        self.deferred = [m.weight for m in net.modules() if isinstance(m, RowDeferredLinear) and m.weight.requires_grad]
+        rest = [p for p in net.parameters() if p.requires_grad and not any(p is w for w in self.deferred)]
+        if mode == 'tree':
+            self.flat = dp.FlatGrads(rest)
+            self.exchange = dp.TreeExchange() if self.world > 1 else None
+        else:
+            self.flat = dp.GradAllReducer(rest)
+            self.exchange = None
 
-    def _accumulate(self, total, start, is_last, triplets, mini_size, batch_args, pre=None):
-        P = self.P
+    # -- one micro-batch ---------------------------------------------------------------------------------------------------------
+    def _forward_backward(self, triplets, offset, mini_size, batch_args, pre, arm=False):
         if pre is not None:
-            # trunk features of the whole slice were computed in one launch (frozen trunk): this micro-batch takes its rows
+            # prefix features of the whole local slice were computed in one launch (frozen trunk prefix): this micro-batch takes its rows
             feats, targets_all = pre
             n = len(triplets)
-            out = self.net.forward_features(*[f[start:start + n] for f in feats])
-            targets = [t[start:start + n] if torch.is_tensor(t) and t.dim() > 0 and t.size(0) == feats[0].size(0) else t for t in targets_all]
+            out = self.net.forward_features(*[f[offset:offset + n] for f in feats])
+            targets = [t[offset:offset + n] if torch.is_tensor(t) and t.dim() > 0 and t.size(0) == feats[0].size(0) else t for t in targets_all]
             loss, loss2 = self.make_loss(out, targets)
         else:
             inputs, targets = self.make_batch(triplets, len(triplets), **batch_args)
             loss, loss2 = self.make_loss(self.net(*inputs), targets)
-        return self._backward(total, is_last, loss, loss2, len(triplets), mini_size)
-
-    def _backward(self, total, is_last, loss, loss2, k, mini_size):
         P = self.P
-        share = k / float(mini_size)
+        share = len(triplets) / float(mini_size)
         obj = loss * share if P.train_loss_avg else loss
         if loss2 is not None:
             obj = obj + P.train_loss2_alpha * (loss2 * share if P.train_loss2_avg else loss2)
-        if self.reducer is not None and is_last:
-            self.reducer.arm()                       # exchange buckets as this last backward fills them
+        if arm:
+            self.flat.arm()                          # all-reduce path: exchange buckets as this last backward fills them
         obj.backward()
-        return total + obj.detach().reshape(-1)[0]    # a device scalar: the step reads the running loss back once, not per micro-batch
+        return obj.detach().reshape(-1)[0]           # a device scalar: the step reads the running loss back once, not per micro-batch
+
+    def _precompute(self, local, n_leaves, batch_args):
+        """Frozen trunk prefix: ONE batch construction for the whole local slice (same image order as micro-batch by micro-batch) and one
+        prefix launch; the micro-batches then run suffix + head on their rows of the features."""
+        if not (getattr(self.P, 'train_trunk_per_minibatch', True) and n_leaves > 1 and getattr(self.net, 'trunk_precomputable', lambda: False)()):
+            return None
+        rng_state = random.getstate()
+        inputs, targets = self.make_batch(local, len(local), **batch_args)
+        feats = self.net.precompute_trunk(*inputs)
+        if feats is None:                            # (CPU tensors, ragged shapes): the batch is built again per micro-batch, from the same random state
+            random.setstate(rng_state)
+            return None
+        return feats, targets
 
     def step(self, optimizer, mini_batch, batch_args):
-        if self.reducer is not None:
-            self.reducer.zero_grad()
+        from isx import dp
+        P, n = self.P, len(mini_batch)
+        mb = P.train_micro_batch if 0 < P.train_micro_batch < n else n
+        if self.mode == 'tree':
+            leaves = [mini_batch[s:s + mb] for s in range(0, n, mb)]
+            lo, hi = dp.rank_leaves(len(leaves), self.world, self.rank)
+            mine = leaves[lo:hi]
         else:
-            optimizer.zero_grad()
-        n = len(mini_batch)
-        mine = mini_batch[(n * self.rank) // self.world:(n * (self.rank + 1)) // self.world]
-        loss = 0.0
-        if mine:
-            pre = None
-            if (getattr(self.P, 'train_trunk_per_minibatch', True) and 0 < self.P.train_micro_batch < len(mine)
-                    and getattr(self.net, 'trunk_precomputable', lambda: False)()):
-                # frozen trunk: ONE batch construction for the whole slice (same image / random-negative order as micro-batch by micro-batch)
-                # and one trunk launch; the micro-batches below run the head on their rows of the features
-                rng_state = random.getstate()
-                inputs, targets = self.make_batch(mine, len(mine), **batch_args)
-                feats = self.net.precompute_trunk(*inputs)
-                if feats is not None:
-                    pre = (feats, targets)
-                else:                                # (CPU tensors, ragged shapes): the batch is built again per micro-batch, from the same random state
-                    del inputs, targets
-                    random.setstate(rng_state)
-            loss = fold_batches(self._accumulate, 0.0, mine, self.P.train_micro_batch,
-                                add_args={'mini_size': n, 'batch_args': batch_args, 'pre': pre})
-        if self.reducer is not None:
-            self.reducer.finish()
+            sl = mini_batch[(n * self.rank) // self.world:(n * (self.rank + 1)) // self.world]
+            mine = [sl[s:s + mb] for s in range(0, len(sl), mb)]
+            lo, hi = 0, len(mine)
+        local = [t for leaf in mine for t in leaf]
+        offsets = [sum(len(l) for l in mine[:j]) for j in range(len(mine))]
+        pre = self._precompute(local, len(mine), batch_args) if mine else None
+        self.flat.zero_grad()
+        losses = []
+        with dp.RowSink(self.deferred) as sink:
+            if self.mode == 'tree':
+                def leaf(i):
+                    losses.append(self._forward_backward(mine[i - lo], offsets[i - lo], n, batch_args, pre))
+                    return self.flat.take()
+                self.flat.put(dp.tree_sum(lo, hi, leaf))
+                if self.exchange is not None:
+                    self.exchange.allreduce_(self.flat.flat)
+            else:
+                for j, triplets in enumerate(mine):
+                    losses.append(self._forward_backward(triplets, offsets[j], n, batch_args, pre, arm=(j == len(mine) - 1)))
+                self.flat.finish()
+            sink.finish()
+        loss = torch.stack(losses).double().sum() if losses else torch.zeros((), dtype=torch.float64)
         if self.world > 1:
-            t = (loss.double() if torch.is_tensor(loss) else torch.tensor(loss, dtype=torch.float64)).reshape(1).to(next(self.net.parameters()).device)
+            t = loss.reshape(1).to(next(self.net.parameters()).device)
             dist.all_reduce(t)
             loss = t
         optimizer.step()
@@ -138,16 +173,16 @@ def train_gen(train_type, P, test_print, test_net, net, train_set, testset_tuple
     mini-batches of P.train_batch_size (a trailing partial one is dropped) -> statistics / evaluation."""
     set_net_train(net, True, bn_train=P.train_bn)
     rank, world = _dp()
-    reducer = None
     if world > 1:
-        from isx.dp import GradAllReducer, broadcast_module_state
+        from isx.dp import broadcast_module_state
         broadcast_module_state(net, src=0)      # replicas start from rank 0's weights and buffers (the descriptor head is random-init)
-        reducer = GradAllReducer(list(net.parameters()))
-    stepper = _Stepper(P, net, create_batch, create_loss, reducer)
+    stepper = _Stepper(P, net, create_batch, create_loss)
     for epoch in range(P.train_epochs):
         optimizer = anneal(net, optimizer, epoch, P.train_annealing)
-        if world > 1:
-            random.seed(getattr(P, 'train_seed', 0) + epoch)    # identical couple order on every rank
+        if world > 1 or getattr(P, 'train_seed', None) is not None:
+            # identical couple order (and random fall-back negatives) on every rank -- and, with P.train_seed set, in a single process,
+            # so that runs with 1, 2, 4, 8 ranks train on the same triplets (the reference leaves `random` unseeded)
+            random.seed((getattr(P, 'train_seed', 0) or 0) + epoch)
         dataset, batch_args = create_epoch(epoch, train_set, testset_tuple)
 
         def one(state, start, is_final, mini_batch):

@@ -83,8 +83,9 @@ class _TinyNet(nn.Module):
 
     def __init__(self):
         super().__init__()
+        from model.custom_modules import RowDeferredLinear
         self.features = nn.Sequential(nn.Conv2d(3, 4, 3, stride=2), nn.BatchNorm2d(4), nn.ReLU())
-        self.head = nn.Linear(4 * 3 * 3, 8)
+        self.head = RowDeferredLinear(4 * 3 * 3, 8)          # as DescriptorNet's head: weight gradient from the step's (x, dy) rows
         self.feature_size = 8
 
     def one(self, x):
@@ -95,8 +96,9 @@ class _TinyNet(nn.Module):
         return (self.one(a), self.one(p), self.one(n)) if self.training and n is not None else self.one(a)
 
 
-def _run_training(rank, world, port, out, train_bn=False, save_all=False):
+def _run_training(rank, world, port, out, train_bn=False, save_all=False, mode="tree", batch=8, micro=2):
     sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
+    torch.set_num_threads(1)                # same CPU kernels (and summation order) whatever the number of processes
     if world > 1:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -108,7 +110,8 @@ def _run_training(rank, world, port, out, train_bn=False, save_all=False):
     random.seed(0)
     net = _TinyNet()
     P = sd.P
-    P.cuda_device, P.train_epochs, P.train_batch_size, P.train_micro_batch = -1, 2, 8, 2
+    P.cuda_device, P.train_epochs, P.train_batch_size, P.train_micro_batch = -1, 2, batch, micro
+    P.train_grad_exchange = mode
     P.train_loss_int, P.train_test_int, P.test_batch_size, P.feature_dim, P.train_seed = 1000, 1000, 8, 8, 5
     P.train_epoch_switch, P.train_pre_proc, P.train_loss_avg = 1, True, False
     P.train_bn = bool(train_bn)
@@ -146,23 +149,44 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def test_data_parallel_training_matches_single_process(tmp_path):
-    """2 ranks x half of every mini-batch + gradient all-reduce == 1 process with the whole mini-batch
-    (gradient accumulation over micro-batches, BatchNorm frozen), after 2 epochs of SGD."""
-    single = str(tmp_path / "single.pt")
-    dp = str(tmp_path / "dp.pt")
-    mp.spawn(_run_training, args=(1, 0, single), nprocs=1, join=True)
-    mp.spawn(_run_training, args=(2, _free_port(), dp), nprocs=2, join=True)
-    a, b = torch.load(single), torch.load(dp)
-    assert set(a) == set(b)
-    moved = 0.0
+def _moved(a):
     torch.manual_seed(0)
     init = _TinyNet().state_dict()
-    for k in a:
-        np.testing.assert_allclose(a[k].numpy(), b[k].numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
-        moved += float((a[k].float() - init[k].float()).abs().sum())
+    return sum(float((a[k].float() - init[k].float()).abs().sum()) for k in a), init
+
+
+@pytest.mark.parametrize("world,batch,micro", [(2, 8, 2), (4, 8, 2), (2, 6, 2), (4, 4, 2)])
+def test_data_parallel_training_is_bit_identical_to_single_process(tmp_path, world, batch, micro):
+    """P ranks x the micro-batches of their subtree + TreeExchange + row-deferred head gradient == 1 process with the whole mini-batch,
+    BIT FOR BIT on the whole state dict after 2 epochs of SGD with momentum (gradient accumulation in the canonical tree order,
+    BatchNorm frozen).  (2, 6, 2): 3 leaves on 2 ranks, an uneven tree; (4, 4, 2): more ranks than leaves, two ranks idle."""
+    single = str(tmp_path / "single.pt")
+    dp = str(tmp_path / "dp.pt")
+    mp.spawn(_run_training, args=(1, 0, single, False, False, "tree", batch, micro), nprocs=1, join=True)
+    mp.spawn(_run_training, args=(world, _free_port(), dp, False, True, "tree", batch, micro), nprocs=world, join=True)
+    a = torch.load(single)
+    moved, init = _moved(a)
     assert moved > 1e-3                                          # training really changed the weights
     assert torch.equal(a["features.1.running_mean"], init["features.1.running_mean"])     # BN frozen (train_bn False)
+    for r in range(world):
+        b = torch.load(dp + ".%d" % r)
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (r, k, float((a[k].float() - b[k].float()).abs().max()))
+
+
+def test_data_parallel_allreduce_mode_matches_single_process(tmp_path):
+    """P.train_grad_exchange = "allreduce": 2 ranks x half of every mini-batch + bucketed gradient all-reduce (+ the row-deferred head
+    gradient) == 1 process, up to the rounding of a different summation order."""
+    single = str(tmp_path / "single.pt")
+    dp = str(tmp_path / "dp.pt")
+    mp.spawn(_run_training, args=(1, 0, single, False, False, "allreduce"), nprocs=1, join=True)
+    mp.spawn(_run_training, args=(2, _free_port(), dp, False, False, "allreduce"), nprocs=2, join=True)
+    a, b = torch.load(single), torch.load(dp)
+    assert set(a) == set(b)
+    for k in a:
+        np.testing.assert_allclose(a[k].numpy(), b[k].numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+    assert _moved(a)[0] > 1e-3
 
 
 def test_data_parallel_train_bn_keeps_replicas_identical(tmp_path):
@@ -496,3 +520,34 @@ def test_reference_config_split_trunk_matches_plain_torch_training():
     print("reference-config training, split trunk vs plain torch: max |dw| / max|w| = %.3g; layer4 moved %.3g, head moved %.3g" % (worst, moved4, moved_head))
     assert moved4 > 0 and moved_head > 0
     assert worst <= 1e-6
+
+
+def test_canonical_tree_is_rank_count_invariant():
+    """isx/dp.py: the sum over a rank's subtree, finished over the ranks in tree order, is the single-process tree sum -- bit for bit --
+    for every leaf count and P in {1, 2, 4, 8}; rank_leaves partitions the leaves in order."""
+    from isx import dp
+    g = torch.Generator().manual_seed(0)
+    for m in range(1, 12):
+        leaves = [torch.randn(257, generator=g) * (10.0 ** (i % 5 - 2)) for i in range(m)]
+        want = dp.tree_sum(0, m, lambda i: leaves[i].clone())
+        for P in (1, 2, 4, 8):
+            ranges = [dp.rank_leaves(m, P, r) for r in range(P)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == m and all(a[1] == b[0] for a, b in zip(ranges[:-1], ranges[1:]))
+            parts = [dp.tree_sum(lo, hi, lambda i: leaves[i].clone()) for lo, hi in ranges]
+            parts = [p if p is not None else torch.zeros(257) for p in parts]           # idle ranks contribute zeros
+            got = dp.tree_sum(0, P, lambda j: parts[j])
+            assert torch.equal(got, want), (m, P)
+    with pytest.raises(ValueError):
+        dp.rank_leaves(8, 3, 0)
+
+
+def test_grad_all_reducer_buckets_are_byte_ranges():
+    """One large parameter no longer makes one large bucket: buckets are ranges of the flat buffer (reverse parameter order)."""
+    from isx.dp import GradAllReducer
+    big, small = nn.Parameter(torch.zeros(1000, 10)), nn.Parameter(torch.zeros(7))
+    r = GradAllReducer([big, small], bucket_mb=1000 * 4 / float(1 << 20))            # 1000 floats per bucket
+    assert r.flat.numel() == 10007 and len(r.ranges) == 11 and all(hi - lo <= 1000 for lo, hi in r.ranges)
+    assert r.slices[small] == (0, 7) and r.slices[big] == (7, 10007)                   # backward order: the last parameter first
+    assert r.members[0] == [big, small] or r.members[0] == [small, big]
+    assert all(m == [big] for m in r.members[1:])
+    assert r._is_view(big) and r._is_view(small)
