@@ -327,6 +327,45 @@ int isx_triplet_loss_bwd_dev(const float* anchor, const float* pos, const float*
                              float scale, const float* scale_dev, int normalized, float* g_anchor, float* g_pos, float* g_neg,
                              isx_stream_t stream);
 
+/* ---- backward pass of the TRAINABLE trunk suffix (siamese training, reference configuration) ---------------------------------
+ * The reference trains layer4 of the ResNet (train/siamese_descriptor_p.py:14-17,48 -> model/nn_utils.py:5-23) and leaves the
+ * backward pass to torch autograd: `loss.backward()` in utils/train_general.py:51-61.  These entries are that backward pass for
+ * the 1x1 / 3x3 convolutions of the residual blocks on channels-last activations, with the (eval-mode) BatchNorm folded into the
+ * convolution: forward = isx_conv1x1_nhwc / isx_conv3x3_nhwc / isx_conv1x1_dual_nhwc on w' = w * s, b' = beta - mean * s,
+ * s = gamma / sqrt(var + eps).  Every sum has a fixed order: a micro-batch's gradient does not depend on the launch around it. */
+
+/* Gradient of a 1x1 convolution wrt its input: dx = (dz . W' (+ add)) . [mask > 0].  dz: (M, Cout); wt = W'^T as (Cin, Cout)
+ * row-major; add (identity-shortcut gradient) and mask (OUTPUT of the ReLU below this convolution): (M, Cin) or NULL; dx: (M, Cin). */
+int isx_conv1x1_dgrad_nhwc(const float* dz, int64_t M, int Cout, const float* wt, int Cin, const float* add, const float* mask,
+                           float* dx, isx_stream_t stream);
+
+/* Gradient of a 3x3 convolution (padding 1) wrt its input, as a stride-1 3x3 convolution of dz with
+ * wt[ci][kh][kw][co] = w'[co][2-kh][2-kw][ci]; a stride-2 layer passes dz zero-upsampled to the input grid.
+ * dz: (B,H,W,Cout), wt: (Cin,3,3,Cout), mask / dx: (B,H,W,Cin); mask as above or NULL.  Cout % 32 == 0. */
+int isx_conv3x3_dgrad_nhwc(const float* dz, int64_t B, int H, int W, int Cout, const float* wt, int Cin, const float* mask,
+                           float* dx, isx_stream_t stream);
+
+/* Weight gradient: dw[co][tap][ci] = sum over output pixels p of dz[p][co] * x[src(p, tap)][ci].  taps = 1: 1x1 convolution with
+ * `stride` (no padding); taps = 9: 3x3, padding 1, `stride`.  x: (B,H,W,Cin), dz: (B,Ho,Wo,Cout), dw: (Cout,taps,Cin) -- the
+ * layout of the forward kernels' weights.  Pixels are summed in index order (k-ordered fp32 fma chain).  Cin, Cout % 64 == 0. */
+int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int H, int W, int Cin, int Cout, int taps, int stride,
+                        float* dw, isx_stream_t stream);
+
+/* Backward of y = relu(.) at a block output plus the bias gradient: dz = dy . [y > 0], db[c] = sum_r dz[r][c].
+ * dy, y, dz: (M, C) (dz == dy allowed), db: (C). */
+int isx_relu_grad_colsum(const float* dy, const float* y, int64_t M, int C, float* dz, float* db, isx_stream_t stream);
+
+/* db[c] = sum_r dz[r][c] (bias gradient of a convolution whose output gradient is dz).  dz: (M, C), db: (C). */
+int isx_colsum_rows(const float* dz, int64_t M, int C, float* db, isx_stream_t stream);
+
+/* Chain rule of the BatchNorm fold: from the gradients (dwp, db) of the folded convolution to the gradients of the convolution
+ * weight and the BatchNorm affine parameters: gw (+)= dwp * scale, ggamma (+)= (<dwp, w> - mean * db) * istd, gbeta (+)= db, with
+ * scale = gamma * istd, istd = 1 / sqrt(running_var + eps).  dwp: (Cout,taps,Cin); w, gw: (Cout,Cin,taps) (nn.Conv2d's layout);
+ * scale, mean, istd, db, ggamma, gbeta: (Cout); accumulate != 0 adds into gw / ggamma / gbeta (gradient accumulation). */
+int isx_bn_fold_backward(const float* dwp, const float* w, const float* scale, const float* mean, const float* istd,
+                         const float* db, int Cout, int Cin, int taps, int accumulate, float* gw, float* ggamma, float* gbeta,
+                         isx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

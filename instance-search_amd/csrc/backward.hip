@@ -1,0 +1,252 @@
+// backward.hip -- the backward pass of the TRAINABLE trunk suffix of siamese training (reference
+// train/siamese_descriptor_p.py:14-17,48: layer4 of the ResNet is trained, model/nn_utils.py:5-23) on channels-last activations.
+// The reference leaves these to torch autograd (cuDNN there; MIOpen here runs the 24-image micro-batches as per-image im2col +
+// GEMM loops: ~150 launches per micro-batch).  Forward reuses the inference kernels with the BatchNorm folded into the
+// convolution (conv.hip); this file adds
+//
+//   isx_conv1x1_dgrad_nhwc   dX = (dZ . W' (+ add)) (. [mask > 0])     the NT GEMM of cosine.hip, epilogue mode 3
+//   isx_conv3x3_dgrad_nhwc   the same for a 3x3 convolution: conv3x3 of dZ with the flipped / transposed weight, mask epilogue
+//   isx_conv_wgrad_nhwc      dW'[co][tap][ci] = sum_p dZ[p][co] * X[src(p, tap)][ci]   (1x1, strided 1x1 and 3x3: a TN GEMM over the
+//                            pixels; both operands are K-major in memory, so tiles go to LDS without a transpose)
+//   isx_relu_grad_colsum     dZ = dY . [y > 0] and db = column sums of dZ in one pass;  isx_colsum_rows: db alone
+//   isx_bn_fold_backward     chain rule of the fold  w' = w * s, b' = beta - mean * s,  s = gamma / sqrt(var + eps):
+//                            dw (+)= dW' * s,  dgamma (+)= (<dW', w> - mean * db) / sqrt(var + eps),  dbeta (+)= db
+//
+// Every sum runs in a fixed order (k-ordered MFMA chains over the pixels, fixed-shape block reductions): the gradient of a
+// micro-batch does not depend on what else is in flight, which the canonical gradient tree of isx/dp.py relies on.
+#include "gemm_tile.hpp"
+
+namespace isx {
+
+int launch_gemm_masked(const float* A, int64_t M, const float* Bt, int64_t N, int D, float* C, const float* mask, const float* add, hipStream_t st);
+
+// ---- weight gradient: TN GEMM over the pixels ---------------------------------------------------------------------------------
+// pixel p of dZ -> row of X that meets it under filter tap (dh, dw): identity for a 1x1 convolution, (ho * s + dh, wo * s + dw) otherwise
+struct WgradGeom { int ident, H, W, Ho, Wo, stride; };
+
+__device__ __forceinline__ int64_t wgrad_src_row(const WgradGeom& g, int64_t p, int dh, int dw) {
+    if (g.ident) return p;
+    const int hw = g.Ho * g.Wo;
+    const int b = (int)(p / hw), rem = (int)(p - (int64_t)b * hw);
+    const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+    const int h = ho * g.stride + dh, w = wo * g.stride + dw;
+    if (h < 0 || h >= g.H || w < 0 || w >= g.W) return -1;
+    return ((int64_t)b * g.H + h) * g.W + w;
+}
+
+// C[n1][tap * N2 + n2] = sum_p A[p][n1] * B[src(p, tap)][n2];  block tile (64 TM) x (64 TN), BK = 32 pixels per k-tile.
+// grid.x = tiles, grid.y = taps (1 or 9).  N1 % (64 TM) == 0, N2 % (64 TN) == 0.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict__ A, int64_t K, int N1, const float* __restrict__ Bm, int N2,
+                                                         WgradGeom g, int taps, float* __restrict__ C, int64_t ldc, int tiles_n) {
+    constexpr int BK = 32, BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + 4;       // +4: rows stay 16-B aligned for the float4 stores
+    constexpr int CA = BM / 4, CB = BN / 4, NA = BK * CA / 256, NB = BK * CB / 256;
+    __shared__ float lds[BK * (LDA + LDB)];
+    float* As = lds;
+    float* Bs = lds + BK * LDA;
+    const int tile_m = (int)blockIdx.x / tiles_n, tile_n = (int)blockIdx.x % tiles_n;
+    const int tap = (int)blockIdx.y;
+    const int dh = taps == 9 ? tap / 3 - 1 : 0, dw = taps == 9 ? tap % 3 - 1 : 0;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    float4 ra[NA], rb[NB];
+    auto load = [&](int64_t k0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            const int64_t p = k0 + idx / CA;
+            ra[j] = p < K ? *reinterpret_cast<const float4*>(A + p * N1 + m0 + ((idx % CA) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            const int64_t p = k0 + idx / CB;
+            const int64_t s = p < K ? wgrad_src_row(g, p, dh, dw) : -1;
+            rb[j] = s >= 0 ? *reinterpret_cast<const float4*>(Bm + s * N2 + n0 + ((idx % CB) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            *reinterpret_cast<float4*>(As + (idx / CA) * LDA + ((idx % CA) << 2)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            *reinterpret_cast<float4*>(Bs + (idx / CB) * LDB + ((idx % CB) << 2)) = rb[j];
+        }
+    };
+
+    const int64_t nk = (K + BK - 1) / BK;
+    load(0);
+    store();
+    __syncthreads();
+    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
+    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+    for (int64_t kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) load((kt + 1) * BK);
+        mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+        __syncthreads();
+        if (more) {
+            store();
+            __syncthreads();
+        }
+    }
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    float* Ct = C + (int64_t)tap * N2;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (32 * TN) + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                Ct[(int64_t)row * ldc + col] = acc[i][j][e];
+            }
+        }
+}
+
+// ---- dZ = dY . [y > 0], db = column sums --------------------------------------------------------------------------------------
+// block = 64 columns x 4 row phases; every thread walks its rows in order, the four phase sums are added in phase order.
+template <bool MASK>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y, int64_t M, int C, float* __restrict__ dz,
+                                                     float* __restrict__ db) {
+    __shared__ float part[4][64];
+    const int c = (int)blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    float s = 0.0f;
+    if (c < C) {
+        for (int64_t r = ph; r < M; r += 4) {
+            float v = dy[r * C + c];
+            if (MASK) {
+                v = y[r * C + c] > 0.0f ? v : 0.0f;
+                dz[r * C + c] = v;
+            }
+            s += v;
+        }
+    }
+    part[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0 && c < C) db[c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+}
+
+// ---- chain rule of the BatchNorm fold -----------------------------------------------------------------------------------------
+// one block per output channel.  dwp: (Cout, taps, Cin) [the wgrad layout]; w / gw: (Cout, Cin, taps) [the nn.Conv2d parameter layout]
+__global__ __launch_bounds__(256) void bn_fold_backward_kernel(const float* __restrict__ dwp, const float* __restrict__ w, const float* __restrict__ scale,
+                                                               const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ db,
+                                                               int Cin, int taps, int accumulate, float* __restrict__ gw, float* __restrict__ ggamma,
+                                                               float* __restrict__ gbeta) {
+    __shared__ float red[4];
+    const int co = (int)blockIdx.x;
+    const int K = Cin * taps;
+    const float s = scale[co];
+    float dot = 0.0f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const int tap = k / Cin, ci = k - tap * Cin;
+        const int64_t iw = (int64_t)co * K + (int64_t)ci * taps + tap;
+        const float d = dwp[(int64_t)co * K + k];
+        dot += d * w[iw];
+        const float g = d * s;
+        gw[iw] = accumulate ? gw[iw] + g : g;
+    }
+    dot = block_sum<256>(dot, red);
+    if (threadIdx.x == 0) {
+        const float ds = dot - mean[co] * db[co];
+        const float gg = ds * istd[co];
+        ggamma[co] = accumulate ? ggamma[co] + gg : gg;
+        gbeta[co] = accumulate ? gbeta[co] + db[co] : db[co];
+    }
+}
+
+}  // namespace isx
+
+using namespace isx;
+
+// dX = (dZ . W (+ add)) . [mask > 0]:  dz (M, Cout), wt = W^T as (Cin, Cout) row-major, add / mask (M, Cin) or NULL.
+// The gradient of a 1x1 convolution wrt its input, with the ReLU of the layer below (mask = that layer's output) and the sum with the
+// identity-shortcut gradient (add) fused into the GEMM's epilogue.
+ISX_API int isx_conv1x1_dgrad_nhwc(const float* dz, int64_t M, int Cout, const float* wt, int Cin, const float* add, const float* mask, float* dx,
+                                   isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && Cin > 0 && Cout > 0 && Cin <= (1 << 20), "isx_conv1x1_dgrad_nhwc: bad shape M=%lld Cout=%d Cin=%d", (long long)M, Cout, Cin);
+    if (M == 0) return ISX_OK;
+    ISX_REQUIRE(dz && wt && dx, "isx_conv1x1_dgrad_nhwc: null pointer");
+    ISX_REQUIRE(dx != dz && dx != add && dx != mask, "isx_conv1x1_dgrad_nhwc: dx must not alias an input");
+    return launch_gemm_masked(dz, M, wt, Cin, Cout, dx, mask, add, (hipStream_t)stream);
+}
+
+// dW'[co][tap][ci] = sum over the output pixels p of dz[p][co] * x[src(p, tap)][ci].  taps = 1: a 1x1 convolution with `stride` (x: (B,H,W,Cin),
+// dz: (B,Ho,Wo,Cout)); taps = 9: 3x3, padding 1.  dw: (Cout, taps, Cin) -- the OHWI layout of the forward kernels.  Cout % 64 == 0, Cin % 64 == 0.
+ISX_API int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int H, int W, int Cin, int Cout, int taps, int stride, float* dw,
+                                isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 9) && (stride == 1 || stride == 2),
+                "isx_conv_wgrad_nhwc: bad shape B=%lld H=%d W=%d Cin=%d Cout=%d taps=%d stride=%d", (long long)B, H, W, Cin, Cout, taps, stride);
+    ISX_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "isx_conv_wgrad_nhwc: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
+    ISX_REQUIRE(B * H * W < (1ll << 31), "isx_conv_wgrad_nhwc: too many pixels for 32-bit pixel indices");
+    ISX_REQUIRE(dw, "isx_conv_wgrad_nhwc: null pointer");
+    WgradGeom g;
+    g.H = H; g.W = W; g.stride = stride;
+    g.Ho = (H - 1) / stride + 1;
+    g.Wo = (W - 1) / stride + 1;
+    g.ident = (taps == 1 && stride == 1) ? 1 : 0;
+    const int64_t K = B * g.Ho * g.Wo;
+    ISX_REQUIRE(K == 0 || (dz && x), "isx_conv_wgrad_nhwc: null pointer");
+    ISX_REQUIRE((((uintptr_t)dz | (uintptr_t)x | (uintptr_t)dw) % 16) == 0, "isx_conv_wgrad_nhwc: dz, x and dw must be 16-B aligned");
+    const int64_t ldc = (int64_t)taps * Cin;
+    hipStream_t st = (hipStream_t)stream;
+    // 128x128 tiles once they fill the chip, 64x64 below (layer4 of ResNet-50: 2048 x 512 = 64 big tiles, 256 small ones)
+    const int64_t big = (int64_t)(Cout / 128) * (Cin / 128) * taps;
+    if (Cout % 128 == 0 && Cin % 128 == 0 && big >= 512) {
+        hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2>), dim3((unsigned)((Cout / 128) * (Cin / 128)), (unsigned)taps), dim3(256), 0, st, dz, K, Cout, x, Cin, g, taps, dw,
+                           ldc, Cin / 128);
+    } else {
+        hipLaunchKernelGGL((wgrad_gemm_kernel<1, 1>), dim3((unsigned)((Cout / 64) * (Cin / 64)), (unsigned)taps), dim3(256), 0, st, dz, K, Cout, x, Cin, g, taps, dw,
+                           ldc, Cin / 64);
+    }
+    ISX_CHECK_LAUNCH("isx_conv_wgrad_nhwc");
+    return ISX_OK;
+}
+
+// dz = dy . [y > 0] (written) and db[c] = sum over the rows of dz[.][c].  dy, y, dz: (M, C); dz == dy allowed.
+ISX_API int isx_relu_grad_colsum(const float* dy, const float* y, int64_t M, int C, float* dz, float* db, isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && C > 0, "isx_relu_grad_colsum: bad shape M=%lld C=%d", (long long)M, C);
+    ISX_REQUIRE(db && (M == 0 || (dy && y && dz)), "isx_relu_grad_colsum: null pointer");
+    hipLaunchKernelGGL((colsum_kernel<true>), dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dy, y, M, C, dz, db);
+    ISX_CHECK_LAUNCH("isx_relu_grad_colsum");
+    return ISX_OK;
+}
+
+// db[c] = sum over the rows of dz[.][c]  (bias gradient of a convolution whose output gradient is dz).
+ISX_API int isx_colsum_rows(const float* dz, int64_t M, int C, float* db, isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && C > 0, "isx_colsum_rows: bad shape M=%lld C=%d", (long long)M, C);
+    ISX_REQUIRE(db && (M == 0 || dz), "isx_colsum_rows: null pointer");
+    hipLaunchKernelGGL((colsum_kernel<false>), dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dz, nullptr, M, C, nullptr, db);
+    ISX_CHECK_LAUNCH("isx_colsum_rows");
+    return ISX_OK;
+}
+
+// Gradients of (conv weight, BN gamma, BN beta) from the gradients of the FOLDED convolution (dwp, db):
+// gw (+)= dwp * scale, ggamma (+)= (<dwp, w> - mean * db) * istd, gbeta (+)= db;  scale = gamma * istd, istd = 1 / sqrt(var + eps).
+// dwp: (Cout, taps, Cin); w, gw: (Cout, Cin, taps) (nn.Conv2d's OIHW); accumulate != 0 adds into gw / ggamma / gbeta.
+ISX_API int isx_bn_fold_backward(const float* dwp, const float* w, const float* scale, const float* mean, const float* istd, const float* db, int Cout,
+                                 int Cin, int taps, int accumulate, float* gw, float* ggamma, float* gbeta, isx_stream_t stream) {
+    ISX_REQUIRE(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9), "isx_bn_fold_backward: bad shape Cout=%d Cin=%d taps=%d", Cout, Cin, taps);
+    ISX_REQUIRE(dwp && w && scale && mean && istd && db && gw && ggamma && gbeta, "isx_bn_fold_backward: null pointer");
+    hipLaunchKernelGGL(bn_fold_backward_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, dwp, w, scale, mean, istd, db, Cin, taps,
+                       accumulate ? 1 : 0, gw, ggamma, gbeta);
+    ISX_CHECK_LAUNCH("isx_bn_fold_backward");
+    return ISX_OK;
+}

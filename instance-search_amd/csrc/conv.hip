@@ -20,22 +20,22 @@ namespace isx {
 template <int TM, int TN, int BK>
 __device__ __forceinline__ void conv3x3_tile(float* __restrict__ lds, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
                                              const Conv3x3Geom& g, float* __restrict__ C, int64_t m0, int64_t n0,
-                                             const float* __restrict__ bias, const float* __restrict__ res, int relu) {
+                                             const float* __restrict__ bias, const float* __restrict__ res, int relu, const float* __restrict__ mask = nullptr) {
     f32x16 acc[TM][TN];
     conv3x3_mainloop<TM, TN, BK>(lds, x, M, Wt, N, g, m0, n0, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm_u = __builtin_amdgcn_readfirstlane(wave >> 1), wn_u = __builtin_amdgcn_readfirstlane(wave & 1);
-    conv_epilogue_buffers<TM, TN>(acc, C, res, bias, relu, m0, M, n0, N, N, 64 * TM, wm_u * (32 * TM), wn_u * (32 * TN), lane & 31, lane >> 5);
+    conv_epilogue_buffers<TM, TN>(acc, C, res, bias, relu, m0, M, n0, N, N, 64 * TM, wm_u * (32 * TM), wn_u * (32 * TN), lane & 31, lane >> 5, mask);
 }
 
 template <int TM, int TN, int BK>
 __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
                                                            Conv3x3Geom g, float* __restrict__ C, TileMap tm,
-                                                           const float* __restrict__ bias, const float* __restrict__ res, int relu) {
+                                                           const float* __restrict__ bias, const float* __restrict__ res, int relu, const float* __restrict__ mask) {
     __shared__ float lds[BK * (64 * TM + 64 * TN + 2 * lds_pad(BK))];
     int tile_m, tile_n;
     tile_of_block(tm, tile_m, tile_n);
-    conv3x3_tile<TM, TN, BK>(lds, x, M, Wt, N, g, C, (int64_t)tile_m * (64 * TM), (int64_t)tile_n * (64 * TN), bias, res, relu);
+    conv3x3_tile<TM, TN, BK>(lds, x, M, Wt, N, g, C, (int64_t)tile_m * (64 * TM), (int64_t)tile_n * (64 * TN), bias, res, relu, mask);
 }
 
 // 128x128 tiles with a 64x64 TAIL.  A launch whose tile count is a little above a whole number of rounds (1024 resident workgroups) ends
@@ -60,12 +60,12 @@ __global__ __launch_bounds__(256, 4) void conv3x3_tail_kernel(const float* __res
 
 template <int TM, int TN, int BK>
 static void launch_conv3x3(const float* x, int64_t M, const float* w, int64_t N, const Conv3x3Geom& g, float* y, const float* bias,
-                           const float* res, int relu, hipStream_t st) {
+                           const float* res, int relu, hipStream_t st, const float* mask = nullptr) {
     TileMap tm;
     tm.m_active = nullptr;
     tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
     tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
-    const int64_t split = (TM == 2 && TN == 2) ? gemm_tail_split_rows(M, N) : 0;
+    const int64_t split = (TM == 2 && TN == 2 && !mask) ? gemm_tail_split_rows(M, N) : 0;
     if (split > 0) {
         TileMap small;
         small.m_active = nullptr;
@@ -77,7 +77,7 @@ static void launch_conv3x3(const float* x, int64_t M, const float* w, int64_t N,
         return;
     }
     hipLaunchKernelGGL((conv3x3_nhwc_kernel<TM, TN, BK>), dim3((unsigned)(tm.tiles_m * tm.tiles_n)), dim3(256), 0, st, x, M, w, N, g, y, tm, bias,
-                       res, relu);
+                       res, relu, mask);
 }
 
 
@@ -276,6 +276,33 @@ ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, c
         default: launch_conv3x3<1, 1, 32>(x, M, w_ohwi, N, g, y, bias, residual, relu ? 1 : 0, st); break;
     }
     ISX_CHECK_LAUNCH("isx_conv3x3_nhwc");
+    return ISX_OK;
+}
+
+// Gradient of a 3x3 convolution (padding 1) wrt its input, as a stride-1 3x3 convolution of dz with the TRANSPOSED, FLIPPED weight
+// wt[ci][kh][kw][co] = w'[co][2-kh][2-kw][ci] (a stride-2 layer hands in dz zero-upsampled to the input grid), with the ReLU of the layer
+// below fused: dx = conv(dz, wt) . [mask > 0].  dz: (B,H,W,Cout), wt: (Cin,3,3,Cout), mask / dx: (B,H,W,Cin).  Cout % 32 == 0.
+ISX_API int isx_conv3x3_dgrad_nhwc(const float* dz, int64_t B, int H, int W, int Cout, const float* wt, int Cin, const float* mask, float* dx,
+                                   isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "isx_conv3x3_dgrad_nhwc: bad shape B=%lld H=%d W=%d Cout=%d Cin=%d", (long long)B, H, W, Cout, Cin);
+    ISX_REQUIRE(Cout % 32 == 0, "isx_conv3x3_dgrad_nhwc: Cout=%d must be a multiple of 32", Cout);
+    ISX_REQUIRE(Cin <= (1 << 20) && H < 32767 && W < 32767 && B * H * W < (1ll << 31), "isx_conv3x3_dgrad_nhwc: shape out of the 32-bit index range");
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(dz && wt && dx, "isx_conv3x3_dgrad_nhwc: null pointer");
+    ISX_REQUIRE((((uintptr_t)dz | (uintptr_t)wt) % 16) == 0, "isx_conv3x3_dgrad_nhwc: dz and wt must be 16-B aligned");
+    ISX_REQUIRE(dx != dz && dx != mask, "isx_conv3x3_dgrad_nhwc: dx must not alias an input");
+    Conv3x3Geom g;
+    g.H = H; g.W = W; g.Cin = Cout; g.stride = 1; g.Ho = H; g.Wo = W;
+    const int64_t M = B * H * W, N = Cin;
+    static const float eff3x3[4] = {0.90f, 0.0f, 0.865f, 0.87f};
+    const int best = pick_tile_cfg(M, N, 0, eff3x3, 0xD);
+    hipStream_t st = (hipStream_t)stream;
+    switch (best) {
+        case 0: launch_conv3x3<2, 2, 16>(dz, M, wt, N, g, dx, nullptr, nullptr, 0, st, mask); break;
+        case 2: launch_conv3x3<2, 1, 32>(dz, M, wt, N, g, dx, nullptr, nullptr, 0, st, mask); break;
+        default: launch_conv3x3<1, 1, 32>(dz, M, wt, N, g, dx, nullptr, nullptr, 0, st, mask); break;
+    }
+    ISX_CHECK_LAUNCH("isx_conv3x3_dgrad_nhwc");
     return ISX_OK;
 }
 

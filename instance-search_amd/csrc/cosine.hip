@@ -101,6 +101,12 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
     }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    if (EPI == 3) {
+        // backward.hip: C = (acc (+ add)) . [mask > 0];  thr = mask (M x N, layout of C) or null, gflag = add (float, layout of C) or null
+        conv_epilogue_buffers<TM, TN>(acc, C, reinterpret_cast<const float*>(gflag), nullptr, 0, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31,
+                                      half, thr);
+        return;
+    }
     if (EPI == 2) {
         // Convolution epilogue through BUFFER instructions: a wave-uniform descriptor of the tile's rows (clipped at row M by the
         // hardware), one 32-bit lane offset per 32x32 MFMA tile (a column >= N gets an offset outside the descriptor: its loads return
@@ -263,6 +269,9 @@ static void launch_cfg(bool aligned, const float* Q, int64_t M, const float* G, 
     if (epi == 2) {
         if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, 2, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, relu);
         else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, 2, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, relu);
+    } else if (epi == 3) {
+        if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, 3, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, 0);
+        else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, 3, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, 0);
     } else if (gmax) {
         if (aligned) hipLaunchKernelGGL((cosine_gemm_kernel<true, TM, TN, true, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
         else hipLaunchKernelGGL((cosine_gemm_kernel<false, TM, TN, true, BK>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tm, thr, gmax, ngrp);
@@ -323,6 +332,11 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     return ISX_OK;
 }
 
+
+// gradient of a 1x1 convolution wrt its input (backward.hip): C = (A . Bt^T (+ add)) . [mask > 0], epilogue mode 3
+int launch_gemm_masked(const float* A, int64_t M, const float* Bt, int64_t N, int D, float* C, const float* mask, const float* add, hipStream_t st) {
+    return launch_gemm_any(A, M, Bt, N, D, C, N, mask, (uint8_t*)add, st, nullptr, 3, 0);
+}
 
 // 1x1 convolution = the same GEMM with the bias / residual / ReLU epilogue (conv.hip)
 int launch_conv1x1_gemm(const float* x, int64_t M, const float* w, int64_t N, int D, float* y, const float* bias, const float* residual, int relu,

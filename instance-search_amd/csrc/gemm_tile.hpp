@@ -138,27 +138,35 @@ __device__ __forceinline__ unsigned conv_lane_off(int64_t ncol, int64_t N, int r
 template <int TM, int TN>
 __device__ __forceinline__ void conv_epilogue_buffers(const f32x16 (&acc)[TM][TN], float* __restrict__ C, const float* __restrict__ res,
                                                       const float* __restrict__ bias, int relu, int64_t m0, int64_t M, int64_t n0, int64_t N,
-                                                      int64_t ldc, int BM, int row0, int col0, int l31, int half) {
+                                                      int64_t ldc, int BM, int row0, int col0, int l31, int half, const float* __restrict__ mask = nullptr) {
+    // bias == nullptr: no bias;  mask (same layout as C): y = mask > 0 ? y : 0 (backward of the ReLU whose OUTPUT is `mask`, backward.hip)
     const auto rc = conv_tile_rsrc(C, m0, M, ldc, BM);
     const auto rr = conv_tile_rsrc(res ? res : C, m0, M, ldc, BM);
+    const auto rm = conv_tile_rsrc(mask ? mask : C, m0, M, ldc, BM);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int ncol = (int)n0 + col0 + j * 32 + l31;
-            const float bias_v = ncol < N ? bias[ncol] : 0.0f;
+            const float bias_v = (bias && ncol < N) ? bias[ncol] : 0.0f;
             const unsigned lo = conv_lane_off(ncol, N, row0 + i * 32 + 4 * half, ldc);
-            float rv[16];
+            float rv[16], mv[16];
             if (res) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0));
+            }
+            if (mask) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    mv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rm, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0));
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float y = acc[i][j][e] + bias_v;
                 if (res) y += rv[e];
                 if (relu) y = fmaxf(y, 0.0f);
+                if (mask) y = mv[e] > 0.0f ? y : 0.0f;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rc, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0);
             }
         }

@@ -124,6 +124,8 @@ class TuneClassifSub(TuneClassif):
 # A/B switch: ISX_SPLIT_TRUNK=0 (or model.siamese.SPLIT_TRUNK = False) runs the training trunk as plain `features(x)` -- the
 # "plain torch run" the split trunk is tested against.
 SPLIT_TRUNK = os.environ.get("ISX_SPLIT_TRUNK", "1") != "0"
+# A/B switch: ISX_SUFFIX_ENGINE=0 keeps the trainable suffix on the plain modules + torch autograd (MIOpen) behind the HIP prefix.
+SUFFIX_ENGINE = os.environ.get("ISX_SUFFIX_ENGINE", "1") != "0"
 
 
 def first_trainable(features):
@@ -174,9 +176,26 @@ class _SplitTrunk(object):
         with torch.no_grad():
             return self.folded(x.contiguous(memory_format=torch.channels_last)), split
 
-    @staticmethod
-    def suffix(features, f, split):
-        for m in list(features)[split:]:
+    _engines = {}
+
+    @classmethod
+    def suffix(cls, features, f, split):
+        """trainable suffix on the prefix output f (no graph).  Bottleneck blocks on the GPU run as ONE autograd node over libisx
+        (isx/suffix.py: folded forward kernels, dgrad / wgrad GEMMs, gradients accumulated straight into .grad); anything else -- other
+        block types, CPU, BatchNorm learning, SUFFIX_ENGINE off -- as the plain modules under torch autograd."""
+        mods = list(features)[split:]
+        if (SUFFIX_ENGINE and mods and f.is_cuda and f.dtype == torch.float32 and torch.is_grad_enabled() and not f.requires_grad
+                and any(p.requires_grad for m in mods for p in m.parameters())):
+            from isx.suffix import SuffixEngine
+            key = (id(features), split)
+            eng = cls._engines.get(key)
+            if eng is None or eng.blocks != mods:
+                eng = cls._engines[key] = SuffixEngine(mods) if SuffixEngine.applicable(mods) else False
+                if len(cls._engines) > 8:
+                    cls._engines.pop(next(iter(cls._engines)))
+            if eng and SuffixEngine.applicable(mods):
+                return eng(f)
+        for m in mods:
             f = m(f)
         return f
 

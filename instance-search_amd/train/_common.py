@@ -125,6 +125,80 @@ def stage_images(ims, device):
     return x
 
 
+class BatchStager(object):
+    """The consecutive batches of a (tensor, label, path) dataset on the device, in dataset order -- what fold_batches hands to a
+    get_embeddings `run` function.  Three regimes:
+
+      resident      the set lives in HBM (make_resident): a batch is a device-side row gather                     (stage_images)
+      streaming     GPU, same-shaped untransformed images, set NOT resident (beyond RESIDENT_BUDGET_BYTES: a 1 M-image gallery is
+                    150 GB as uint8): two reusable PINNED host buffers + two device buffers + a copy stream.  `get(i)` returns batch i
+                    (already in flight) and, before returning, stacks batch i + 1 into the other pinned buffer and enqueues its H2D copy
+                    on the copy stream -- host stacking and PCIe of batch i + 1 overlap the trunk of batch i (and of i - 1, still running
+                    when get(i) is called).  The reference stacks + copies every batch on the compute path
+                    (train/classif_finetune.py:92-104).  uint8 images are normalised on the device after the copy (isx_images_u8_to_f32).
+      plain         CPU runs, transformed or ragged images: stage_batch as before.
+
+    Same values whatever the regime (tests/test_gpu_dropin.py: streamed descriptors == resident descriptors, bit for bit)."""
+
+    def __init__(self, dataset, batch_size, trans, device, force_streaming=None):
+        self.dataset, self.bs, self.trans, self.device = dataset, int(batch_size), trans, device
+        self.streaming = False
+        if device >= 0 and trans is None and self.bs > 0 and len(dataset) > 0 and torch.cuda.is_available():
+            ims = [im for im, _, _ in dataset]
+            first = ims[0]
+            uniform = not any(im.shape != first.shape or im.dtype != first.dtype or im.is_cuda for im in ims)
+            resident = any(r.covers(ims) for r in _RESIDENT)
+            self.streaming = uniform and not resident if force_streaming is None else bool(force_streaming) and uniform
+        if self.streaming:
+            dev = torch.device('cuda', device)
+            n = min(self.bs, len(dataset))
+            shape, dtype = (n,) + tuple(first.shape), first.dtype
+            self.dev = dev
+            self.copy_stream = torch.cuda.Stream(device=dev)
+            self.host = [torch.empty(shape, dtype=dtype).pin_memory() for _ in range(2)]
+            self.devbuf = [torch.empty(shape, dtype=dtype, device=dev) for _ in range(2)]
+            self.copied = [None, None]          # copy-stream event: the H2D copy out of host[b] into devbuf[b] has completed
+            self.consumed = [None, None]        # compute-stream event: the kernels reading devbuf[b] have been enqueued (and, once reached, run)
+            self.inflight = {}                  # batch start index -> (slot, rows)
+
+    def _submit(self, start):
+        slot = (start // self.bs) & 1
+        chunk = [im for im, _, _ in self.dataset[start:start + self.bs]]
+        if self.copied[slot] is not None:
+            self.copied[slot].synchronize()                      # the pinned buffer is free once its previous copy has left it
+        _parallel_stack(chunk, self.host[slot])
+        with torch.cuda.stream(self.copy_stream):
+            if self.consumed[slot] is not None:
+                self.copy_stream.wait_event(self.consumed[slot])  # the device buffer is free once its previous readers have run
+            self.devbuf[slot][:len(chunk)].copy_(self.host[slot][:len(chunk)], non_blocking=True)
+            self.copied[slot] = torch.cuda.Event()
+            self.copied[slot].record(self.copy_stream)
+        self.inflight[start] = (slot, len(chunk))
+
+    def get(self, start, batch):
+        """Device batch of dataset[start:start + len(batch)] (normalised fp32; channels-last for the uint8 ingest)."""
+        if not self.streaming:
+            return stage_batch(batch, self.trans, self.device)
+        cur = torch.cuda.current_stream(self.dev)
+        prev = start - self.bs
+        if prev >= 0:                                             # the consumers of the previous batch are enqueued by now: its device buffer may be refilled behind them
+            pslot = (prev // self.bs) & 1
+            self.consumed[pslot] = torch.cuda.Event()
+            self.consumed[pslot].record(cur)
+        if start not in self.inflight:
+            self._submit(start)
+        nxt = start + self.bs
+        if nxt < len(self.dataset) and nxt not in self.inflight:
+            self._submit(nxt)                                     # look-ahead: stacked + copied while batch `start` (and start - bs) compute
+        slot, rows = self.inflight.pop(start)
+        assert rows == len(batch)
+        cur.wait_event(self.copied[slot])
+        x = self.devbuf[slot][:rows]
+        if x.dtype == torch.uint8:
+            return normalise_u8_batch(x, self.device)             # reads the device buffer into a fresh fp32 tensor
+        return x
+
+
 def stage_batch(batch, trans, device):
     """Stack the (already normalised unless `trans` is given) images of a batch and move them."""
     if trans is None:

@@ -7,7 +7,7 @@ import torch.nn as nn
 from model.custom_modules import l2_normalize_rows
 from model.siamese import TuneClassif
 from utils import fold_batches, move_device, tensor
-from ._common import base_model, device_batch_size, load_weights, make_resident, stage_batch, test_transform
+from ._common import BatchStager, base_model, device_batch_size, load_weights, make_resident, stage_batch, test_transform
 from .classif_finetune_p import P
 
 labels = []   # filled by the entry point once the reference set is listed, then constant
@@ -68,9 +68,11 @@ def get_embeddings(net, dataset, device, out_size):
     elif fc7:
         net.classifier = fc7_tap(classifier)                # extension: the 4096-d activation behind the second ReLU (eval mode: Dropout = identity)
     slab = tensor(device, len(dataset), out_size)
+    bs = device_batch_size(P, dataset)
+    stager = BatchStager(dataset, bs, trans, P.cuda_device)    # resident: row gathers; beyond the HBM budget: double-buffered pinned staging on a copy stream
 
     def run(slab, i, is_final, batch):
-        x = stage_batch(batch, trans, P.cuda_device)
+        x = stager.get(i, batch)
         rows = slab[i:i + len(batch)]
         with torch.no_grad():
             if stripped and x.is_cuda and slab.is_cuda:
@@ -87,7 +89,7 @@ def get_embeddings(net, dataset, device, out_size):
         return slab
 
     try:
-        return fold_batches(run, slab, dataset, device_batch_size(P, dataset))
+        return fold_batches(run, slab, dataset, bs)
     finally:
         net.classifier = classifier
 

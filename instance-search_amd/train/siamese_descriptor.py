@@ -13,7 +13,7 @@ from model.siamese import DescriptorNet, TuneClassif
 from model.custom_modules import TripletLoss
 from utils import (choose_rand_neg, choose_rand_neg_index, embeddings_device_dim, fold_batches, get_pos_couples, get_similarities, log, move_device,
                    tensor, test_print_descriptor, train_gen)
-from ._common import base_model, device_batch_size, load_weights, make_resident, stage_batch, stage_images, test_transform
+from ._common import BatchStager, base_model, device_batch_size, load_weights, make_resident, stage_batch, stage_images, test_transform
 from .siamese_descriptor_p import P
 
 labels = []
@@ -25,12 +25,15 @@ def get_embeddings(net, dataset, device, out_size):
     if trans is None:
         make_resident(dataset, P.cuda_device)
 
+    bs = device_batch_size(P, dataset)
+    stager = BatchStager(dataset, bs, trans, P.cuda_device)    # resident: row gathers; beyond the HBM budget: double-buffered pinned staging on a copy stream
+
     def run(slab, i, is_final, batch):
         with torch.no_grad():
-            slab[i:i + len(batch)].copy_(net(stage_batch(batch, trans, P.cuda_device)))
+            slab[i:i + len(batch)].copy_(net(stager.get(i, batch)))
         return slab
 
-    return fold_batches(run, slab, dataset, device_batch_size(P, dataset))
+    return fold_batches(run, slab, dataset, bs)
 
 
 def get_siamese_net():

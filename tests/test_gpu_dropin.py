@@ -430,3 +430,49 @@ def test_folded_trunk_follows_load_state_dict():
             p.data.copy_(q.data)
         invalidate_derived_weights(fa)
         assert torch.equal(fa(x), folded(2)(x))
+
+
+def test_streaming_ingest_matches_resident_path(monkeypatch):
+    """A set beyond the HBM residency budget (a 1 M-image gallery is 150 GB of uint8) streams through two pinned buffers and a copy stream
+    (train/_common.BatchStager): batch i + 1 is stacked and copied while batch i runs.  The descriptors must be the resident path's, bit for
+    bit -- uint8 ingest (normalised on the device) and fp32 ingest, 11 batches (every buffer reused five times), ragged last batch."""
+    from isx import backbones
+    from model.nn_utils import fold_batch_norm
+    from model.siamese import TuneClassif
+    from train import _common as TC
+    from train import classif_finetune as cf
+    torch.manual_seed(0)
+    net = TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5).eval()
+    net.features = fold_batch_norm(net.features)
+    net = net.cuda().to(memory_format=torch.channels_last)
+    g = torch.Generator().manual_seed(5)
+    n = 64 * 10 + 23
+    raw = [(torch.randint(0, 256, (224, 224, 3), generator=g, dtype=torch.uint8), "l%d" % (i % 5), "p%d" % i) for i in range(n)]
+    f32 = [(torch.randn(3, 224, 224, generator=g), "l%d" % (i % 5), "q%d" % i) for i in range(200)]
+    P = cf.P
+    old = (P.test_batch_size, P.cuda_device, P.embeddings_classify, P.test_pre_proc)
+    monkeypatch.setattr(TC, "_MIN_DEVICE_BATCH_PIXELS", 0)
+    stagers = []
+    real_stager = TC.BatchStager
+    monkeypatch.setattr(cf, "BatchStager", lambda *a, **k: (stagers.append(real_stager(*a, **k)) or stagers[-1]))
+    TC.RAW_INGEST["mean"], TC.RAW_INGEST["std"] = [0.4, 0.5, 0.6], [0.2, 0.25, 0.3]
+    try:
+        P.cuda_device, P.embeddings_classify, P.test_pre_proc, P.test_batch_size = 0, False, True, 64
+        out = {}
+        for name, data in (("u8", raw), ("f32", f32)):
+            TC.drop_resident()
+            monkeypatch.setattr(TC, "RESIDENT_BUDGET_BYTES", 48 << 30)
+            out[name, "resident"] = cf.get_embeddings(net, data, 0, 2048).clone()
+            assert not stagers[-1].streaming
+            TC.drop_resident()
+            monkeypatch.setattr(TC, "RESIDENT_BUDGET_BYTES", 0)          # nothing fits: the set stays on the host
+            out[name, "streamed"] = cf.get_embeddings(net, data, 0, 2048).clone()
+            assert stagers[-1].streaming and not stagers[-1].inflight
+    finally:
+        TC.drop_resident()
+        TC.RAW_INGEST["mean"] = TC.RAW_INGEST["std"] = None
+        P.test_batch_size, P.cuda_device, P.embeddings_classify, P.test_pre_proc = old
+    for name in ("u8", "f32"):
+        a, b = out[name, "resident"], out[name, "streamed"]
+        assert torch.isfinite(a).all() and float((a.norm(dim=1) - 1).abs().max()) < 1e-5
+        assert torch.equal(a, b), name

@@ -1,0 +1,162 @@
+"""The trainable trunk suffix on the hand-written kernels (isx/suffix.py, csrc/backward.hip) against torch autograd on the plain
+modules (fp32, MIOpen): outputs and every parameter gradient.  Floating-point kernels: the reference here is torch fp32, the tolerance
+is stated per check (summation order differs: k-ordered fp32 MFMA chains vs MIOpen's blocked sums)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise_bn(mods, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in mods.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            with torch.no_grad():
+                m.weight.copy_(0.5 + torch.rand(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+
+
+def _blocks(which):
+    from isx import backbones
+    net = backbones.resnet50(pretrained=True, seed=0)
+    if which == "layer4":
+        blocks, cin, hw = list(net.layer4), 1024, 14
+    else:                                                    # last block of layer3 + the projection block of layer4: a projection shortcut above the first block
+        blocks, cin, hw = [net.layer3[-1], net.layer4[0]], 1024, 14
+    seq = nn.Sequential(*blocks).cuda()
+    _randomise_bn(seq, 3)
+    seq.train()
+    for m in seq.modules():
+        if isinstance(m, nn.BatchNorm2d):
+            m.eval()
+    return seq, cin, hw
+
+
+def _rel(a, b):
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+@pytest.mark.parametrize("which,B", [("layer4", 3), ("layer4", 24), ("layer3+4", 2)])
+def test_suffix_engine_matches_torch_autograd(which, B):
+    from isx.suffix import SuffixEngine
+    seq, cin, hw = _blocks(which)
+    ref = copy.deepcopy(seq)
+    assert SuffixEngine.applicable(list(seq))
+    eng = SuffixEngine(list(seq))
+    g = torch.Generator(device="cuda").manual_seed(B)
+    x = torch.relu(torch.randn(B, cin, hw, hw, device="cuda", generator=g)).contiguous(memory_format=torch.channels_last)
+    y = eng(x)
+    y_ref = ref(x)
+    assert y.shape == y_ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    assert _rel(y, y_ref) <= 2e-5                             # folded vs unfolded BatchNorm + another summation order
+    r = torch.randn(y.shape, device="cuda", generator=g)
+    (y * r).sum().backward()
+    (y_ref * r).sum().backward()
+    worst = 0.0
+    for (n, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and p.grad.shape == q.grad.shape, n
+        e = _rel(p.grad, q.grad)
+        worst = max(worst, e)
+        assert e <= 2e-4, (n, e)
+    print("suffix engine %s B=%d: max relative gradient deviation %.2e, output %.2e" % (which, B, worst, _rel(y, y_ref)))
+    # a second micro-batch ACCUMULATES in place into the existing .grad tensors (no new tensors, no autograd add pass)
+    ptrs = [p.grad.data_ptr() for p in seq.parameters()]
+    first = [p.grad.clone() for p in seq.parameters()]
+    (eng(x) * r).sum().backward()
+    for p, g0, ptr in zip(seq.parameters(), first, ptrs):
+        assert p.grad.data_ptr() == ptr
+        assert _rel(p.grad, 2 * g0) <= 1e-6
+
+
+def test_suffix_engine_follows_the_optimizer():
+    """The folded weights are derived per step from the parameters' version counters: after an optimizer step the engine computes with the new
+    weights (same output as the plain modules), and a BatchNorm put into training mode makes it inapplicable."""
+    from isx.suffix import SuffixEngine
+    seq, cin, hw = _blocks("layer4")
+    eng = SuffixEngine(list(seq))
+    x = torch.relu(torch.randn(2, cin, hw, hw, device="cuda")).contiguous(memory_format=torch.channels_last)
+    opt = torch.optim.SGD(seq.parameters(), lr=0.05)
+    y0 = eng(x).detach().clone()
+    eng(x).square().mean().backward()
+    opt.step()
+    y1 = eng(x)
+    assert not torch.equal(y0, y1)
+    with torch.no_grad():
+        assert _rel(y1, seq(x)) <= 2e-5
+    seq[0].bn1.train()
+    assert not SuffixEngine.applicable(list(seq))
+
+
+def test_backward_kernels_vs_torch():
+    """The individual entry points of csrc/backward.hip on small ragged shapes against torch fp32."""
+    from isx._lib import check, lib
+    L = lib()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    # relu_grad_colsum / colsum_rows: M not a multiple of 4, C not a multiple of 64
+    M, C = 1177, 200
+    dy, y = rn(M, C), rn(M, C)
+    dz, db = torch.empty_like(dy), torch.empty(C, device="cuda")
+    check(L.isx_relu_grad_colsum(dy.data_ptr(), y.data_ptr(), M, C, dz.data_ptr(), db.data_ptr(), st), "x")
+    want = dy * (y > 0)
+    assert torch.equal(dz, want)
+    np.testing.assert_allclose(db.cpu().numpy(), want.double().sum(0).float().cpu().numpy(), rtol=1e-5, atol=1e-4)
+    db2 = torch.empty(C, device="cuda")
+    check(L.isx_colsum_rows(dz.data_ptr(), M, C, db2.data_ptr(), st), "x")
+    assert torch.equal(db, db2)
+    # 1x1 dgrad with add + mask
+    M, Co, Ci = 333, 192, 128
+    dzz, w, add, mask = rn(M, Co), rn(Co, Ci), rn(M, Ci), rn(M, Ci)
+    dx = torch.empty(M, Ci, device="cuda")
+    check(L.isx_conv1x1_dgrad_nhwc(dzz.data_ptr(), M, Co, w.t().contiguous().data_ptr(), Ci, add.data_ptr(), mask.data_ptr(), dx.data_ptr(), st), "x")
+    want = (dzz.double() @ w.double() + add.double()) * (mask > 0)
+    np.testing.assert_allclose(dx.cpu().numpy(), want.float().cpu().numpy(), rtol=1e-4, atol=1e-3)
+    check(L.isx_conv1x1_dgrad_nhwc(dzz.data_ptr(), M, Co, w.t().contiguous().data_ptr(), Ci, None, None, dx.data_ptr(), st), "x")
+    np.testing.assert_allclose(dx.cpu().numpy(), (dzz.double() @ w.double()).float().cpu().numpy(), rtol=1e-4, atol=1e-3)
+    # wgrad: 1x1, strided 1x1, 3x3 stride 1 and 2 against torch's convolution_backward
+    for taps, stride, B, H, W, Ci, Co in ((1, 1, 3, 5, 7, 64, 128), (1, 2, 2, 7, 6, 128, 64), (9, 1, 2, 6, 5, 64, 64), (9, 2, 3, 7, 7, 128, 64)):
+        k = 3 if taps == 9 else 1
+        x = rn(B, Ci, H, W).contiguous(memory_format=torch.channels_last)
+        wt = rn(Co, Ci, k, k)
+        out = torch.nn.functional.conv2d(x, wt, None, stride, k // 2)
+        dz_ = rn(*out.shape).contiguous(memory_format=torch.channels_last)
+        _, gw, _ = torch.ops.aten.convolution_backward(dz_, x, wt, None, [stride, stride], [k // 2, k // 2], [1, 1], False, [0, 0], 1, [False, True, False])
+        dw = torch.empty(Co, taps, Ci, device="cuda")
+        check(L.isx_conv_wgrad_nhwc(dz_.permute(0, 2, 3, 1).contiguous().data_ptr(), x.permute(0, 2, 3, 1).contiguous().data_ptr(), B, H, W, Ci, Co, taps, stride,
+                                    dw.data_ptr(), st), "x")
+        got = dw.view(Co, k, k, Ci).permute(0, 3, 1, 2)
+        assert _rel(got, gw) <= 2e-5, (taps, stride, _rel(got, gw))
+        if taps == 9:                                           # 3x3 dgrad (with mask) against torch
+            gx, _, _ = torch.ops.aten.convolution_backward(dz_, x, wt, None, [stride, stride], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])
+            d = dz_.permute(0, 2, 3, 1).contiguous()
+            if stride == 2:
+                up = torch.zeros(B, H, W, Co, device="cuda")
+                up[:, ::2, ::2] = d
+                d = up
+            wd = wt.flip(2, 3).permute(1, 2, 3, 0).contiguous()
+            m = rn(B, H, W, Ci)
+            dxx = torch.empty(B, H, W, Ci, device="cuda")
+            check(L.isx_conv3x3_dgrad_nhwc(d.data_ptr(), B, H, W, Co, wd.data_ptr(), Ci, m.data_ptr(), dxx.data_ptr(), st), "x")
+            want = gx.permute(0, 2, 3, 1) * (m > 0)
+            assert _rel(dxx, want) <= 2e-5, (stride, _rel(dxx, want))
+    # chain rule of the fold against autograd through the fold itself
+    Co, Ci, taps = 64, 128, 9
+    w = rn(Co, Ci, 3, 3).requires_grad_()
+    gam, bet = (0.5 + torch.rand(Co, device="cuda", generator=g)).requires_grad_(), rn(Co).requires_grad_()
+    mean, var = rn(Co), 0.5 + torch.rand(Co, device="cuda", generator=g)
+    istd = torch.rsqrt(var + 1e-5)
+    s = gam * istd
+    wf, bf = w * s.view(-1, 1, 1, 1), bet - mean * s
+    dwp, dbb = rn(Co, 3, 3, Ci), rn(Co)                          # gradient of the folded weight in OHWI, of the folded bias
+    ((wf.permute(0, 2, 3, 1) * dwp).sum() + (bf * dbb).sum()).backward()
+    gw, gg, gb = torch.ones_like(w), torch.ones_like(gam), torch.ones_like(bet)      # accumulate into ones
+    check(L.isx_bn_fold_backward(dwp.data_ptr(), w.detach().data_ptr(), s.detach().contiguous().data_ptr(), mean.data_ptr(), istd.data_ptr(), dbb.data_ptr(),
+                                 Co, Ci, taps, 1, gw.data_ptr(), gg.data_ptr(), gb.data_ptr(), st), "x")
+    assert _rel(gw - 1, w.grad) <= 1e-5 and _rel(gg - 1, gam.grad) <= 1e-4 and _rel(gb - 1, bet.grad) <= 1e-6

@@ -484,9 +484,17 @@ def test_reference_config_split_trunk_matches_plain_torch_training():
     tr = synthetic_image_set(32, 4, seed=1, structure=0.5)
     te = synthetic_image_set(8, 4, seed=2, structure=0.5)
     out, init = {}, None
+    # hard-negative mining is an arg-max over similarities: a 1e-6 difference between the two runs' weights can pick another negative and
+    # send the runs down different roads.  The comparison is about arithmetic, so the second run replays the first run's mined negatives.
+    real_mine, mined = sd.mine_epoch_negatives, []
     try:
         for split in (True, False):
             ms.SPLIT_TRUNK = split
+            if split:
+                sd.mine_epoch_negatives = lambda *a, **k: (mined.append(real_mine(*a, **k)) or mined[-1])
+            else:
+                replay = iter(mined)
+                sd.mine_epoch_negatives = lambda *a, **k: next(replay)
             torch.manual_seed(0); random.seed(0)
             P = sd.P
             P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), 32
@@ -502,21 +510,28 @@ def test_reference_config_split_trunk_matches_plain_torch_training():
             out[split] = {k: v.detach().clone() for k, v in net.state_dict().items()}
     finally:
         ms.SPLIT_TRUNK = True
+        sd.mine_epoch_negatives = real_mine
         sd.P.__dict__.clear(); sd.P.__dict__.update(saved)
     a, b = out[True], out[False]
     worst, moved4, moved_head = 0.0, 0.0, 0.0
+    table = []
     for k in a:
         if not a[k].dtype.is_floating_point:
             continue
         scale = float(b[k].abs().max()) + 1e-12
-        worst = max(worst, float((a[k] - b[k]).abs().max()) / scale)
         d = float((b[k] - init[k].to(b[k].device)).abs().max())
+        err = float((a[k] - b[k]).abs().max())
+        if d > 0:
+            table.append((err / scale, k, err, scale, d))
+        worst = max(worst, err / scale)
         if k.startswith("features.17.") or k.startswith("features.18.") or k.startswith("features.19."):
             moved4 = max(moved4, d)
         elif k.startswith("features."):
             assert d == 0.0, k                                          # frozen prefix untouched
         else:
             moved_head = max(moved_head, d)
+    for row in sorted(table, reverse=True)[:8]:
+        print("  %.3g  %s: max|dw| %.3g, max|w| %.3g, moved %.3g" % row)
     print("reference-config training, split trunk vs plain torch: max |dw| / max|w| = %.3g; layer4 moved %.3g, head moved %.3g" % (worst, moved4, moved_head))
     assert moved4 > 0 and moved_head > 0
     assert worst <= 1e-6
