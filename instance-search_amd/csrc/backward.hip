@@ -8,9 +8,10 @@
 //   isx_conv3x3_dgrad_nhwc   the same for a 3x3 convolution: conv3x3 of dZ with the flipped / transposed weight, mask epilogue
 //   isx_conv_wgrad_nhwc      dW'[co][tap][ci] = sum_p dZ[p][co] * X[src(p, tap)][ci]   (1x1, strided 1x1 and 3x3: a TN GEMM over the
 //                            pixels; both operands are K-major in memory, so tiles go to LDS without a transpose)
-//   isx_relu_grad_colsum     dZ = dY . [y > 0] and db = column sums of dZ in one pass;  isx_colsum_rows: db alone
-//   isx_bn_fold_backward     chain rule of the fold  w' = w * s, b' = beta - mean * s,  s = gamma / sqrt(var + eps):
-//                            dw (+)= dW' * s,  dgamma (+)= (<dW', w> - mean * db) / sqrt(var + eps),  dbeta (+)= db
+//                            -- split over the pixels into partials, with the bias gradient db[co] = sum_p dZ[p][co] as a by-product
+//   isx_relu_grad            dZ = dY . [y > 0] at the output of the last block
+//   isx_bn_fold_backward     sums the partials in order, then the chain rule of the fold  w' = w * s, b' = beta - mean * s,
+//                            s = gamma / sqrt(var + eps):  dw (+)= dW' * s,  dgamma (+)= (<dW', w> - mean * db) / sqrt(var + eps),  dbeta (+)= db
 //
 // Every sum runs in a fixed order (k-ordered MFMA chains over the pixels, fixed-shape block reductions): the gradient of a
 // micro-batch does not depend on what else is in flight, which the canonical gradient tree of isx/dp.py relies on.
@@ -34,20 +35,25 @@ __device__ __forceinline__ int64_t wgrad_src_row(const WgradGeom& g, int64_t p, 
     return ((int64_t)b * g.H + h) * g.W + w;
 }
 
-// C[n1][tap * N2 + n2] = sum_p A[p][n1] * B[src(p, tap)][n2];  block tile (64 TM) x (64 TN), BK = 32 pixels per k-tile.
-// grid.x = tiles, grid.y = taps (1 or 9).  N1 % (64 TM) == 0, N2 % (64 TN) == 0.
+// C[s][n1][tap * N2 + n2] = sum over the pixels p of split s of A[p][n1] * B[src(p, tap)][n2];  block tile (64 TM) x (64 TN), BK = 32
+// pixels per k-tile.  grid = (tiles, taps, splits): split s owns the k-tiles [s * kt_per, (s + 1) * kt_per) and writes its own partial
+// (the consumer, bn_fold_backward_kernel, adds the partials in split order: a fixed summation tree, no atomics).  The blocks of
+// (tile_n = 0, tap = 0) also produce the partial COLUMN SUMS of A (the bias gradient) from the A tiles they stage anyway.
+// N1 % (64 TM) == 0, N2 % (64 TN) == 0.
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict__ A, int64_t K, int N1, const float* __restrict__ Bm, int N2,
-                                                         WgradGeom g, int taps, float* __restrict__ C, int64_t ldc, int tiles_n) {
+                                                         WgradGeom g, int taps, float* __restrict__ C, int64_t ldc, int tiles_n, int kt_per,
+                                                         float* __restrict__ colsum) {
     constexpr int BK = 32, BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + 4;       // +4: rows stay 16-B aligned for the float4 stores
     constexpr int CA = BM / 4, CB = BN / 4, NA = BK * CA / 256, NB = BK * CB / 256;
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
     float* Bs = lds + BK * LDA;
     const int tile_m = (int)blockIdx.x / tiles_n, tile_n = (int)blockIdx.x % tiles_n;
-    const int tap = (int)blockIdx.y;
+    const int tap = (int)blockIdx.y, split = (int)blockIdx.z;
     const int dh = taps == 9 ? tap / 3 - 1 : 0, dw = taps == 9 ? tap % 3 - 1 : 0;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bool sums = colsum != nullptr && tile_n == 0 && tap == 0 && (int)threadIdx.x < BM;      // (uniform per wave: BM is 64 or 128)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -90,24 +96,34 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict
         }
     };
 
-    const int64_t nk = (K + BK - 1) / BK;
-    load(0);
-    store();
-    __syncthreads();
-    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
-    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
-    for (int64_t kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) load((kt + 1) * BK);
-        mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+    const int64_t nk_all = (K + BK - 1) / BK;
+    const int64_t kt0 = (int64_t)split * kt_per;
+    const int64_t kt1 = kt0 + kt_per < nk_all ? kt0 + kt_per : nk_all;
+    float csum = 0.0f;
+    if (kt0 < kt1) {
+        load(kt0 * BK);
+        store();
         __syncthreads();
-        if (more) {
-            store();
+        const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
+        const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+        for (int64_t kt = kt0; kt < kt1; ++kt) {
+            const bool more = kt + 1 < kt1;
+            if (more) load((kt + 1) * BK);
+            if (sums) {
+#pragma unroll
+                for (int k = 0; k < BK; ++k) csum += As[k * LDA + threadIdx.x];           // pixel order
+            }
+            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
             __syncthreads();
+            if (more) {
+                store();
+                __syncthreads();
+            }
         }
     }
+    if (sums) colsum[(int64_t)split * N1 + m0 + threadIdx.x] = csum;
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    float* Ct = C + (int64_t)tap * N2;
+    float* Ct = C + (int64_t)split * N1 * ldc + (int64_t)tap * N2;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -121,54 +137,56 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict
         }
 }
 
-// ---- dZ = dY . [y > 0], db = column sums --------------------------------------------------------------------------------------
-// block = 64 columns x 4 row phases; every thread walks its rows in order, the four phase sums are added in phase order.
-template <bool MASK>
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dy, const float* __restrict__ y, int64_t M, int C, float* __restrict__ dz,
-                                                     float* __restrict__ db) {
-    __shared__ float part[4][64];
-    const int c = (int)blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
-    float s = 0.0f;
-    if (c < C) {
-        for (int64_t r = ph; r < M; r += 4) {
-            float v = dy[r * C + c];
-            if (MASK) {
-                v = y[r * C + c] > 0.0f ? v : 0.0f;
-                dz[r * C + c] = v;
-            }
-            s += v;
-        }
-    }
-    part[ph][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (ph == 0 && c < C) db[c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+// number of pixel splits of a weight-gradient launch: enough workgroups to fill the chip (~4 per CU), at least 4 k-tiles each; a function of
+// the SHAPE only, so the summation tree of a micro-batch is the same whatever runs around it
+static int wgrad_splits(int64_t K, int Cin, int Cout, int taps) {
+    const bool big = Cout % 128 == 0 && Cin % 128 == 0 && (int64_t)(Cout / 128) * (Cin / 128) * taps >= 512;
+    const int64_t tiles = (big ? (int64_t)(Cout / 128) * (Cin / 128) : (int64_t)(Cout / 64) * (Cin / 64)) * taps;
+    const int64_t nk = (K + 31) / 32;
+    int64_t s = (1024 + tiles - 1) / tiles;
+    if (s > nk / 4) s = nk / 4;
+    if (s > 16) s = 16;
+    return (int)(s < 1 ? 1 : s);
+}
+
+// ---- dZ = dY . [y > 0] ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void relu_grad_kernel(const float4* __restrict__ dy, const float4* __restrict__ y, int64_t n4, float4* __restrict__ dz) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 g = dy[i], v = y[i];
+    dz[i] = make_float4(v.x > 0.0f ? g.x : 0.0f, v.y > 0.0f ? g.y : 0.0f, v.z > 0.0f ? g.z : 0.0f, v.w > 0.0f ? g.w : 0.0f);
 }
 
 // ---- chain rule of the BatchNorm fold -----------------------------------------------------------------------------------------
-// one block per output channel.  dwp: (Cout, taps, Cin) [the wgrad layout]; w / gw: (Cout, Cin, taps) [the nn.Conv2d parameter layout]
-__global__ __launch_bounds__(256) void bn_fold_backward_kernel(const float* __restrict__ dwp, const float* __restrict__ w, const float* __restrict__ scale,
-                                                               const float* __restrict__ mean, const float* __restrict__ istd, const float* __restrict__ db,
-                                                               int Cin, int taps, int accumulate, float* __restrict__ gw, float* __restrict__ ggamma,
-                                                               float* __restrict__ gbeta) {
+// one block per output channel.  dwp: `splits` partials of (Cout, taps, Cin) [the wgrad layout], added in split order; db: `splits`
+// partials of (Cout); w / gw: (Cout, Cin, taps) [the nn.Conv2d parameter layout]
+__global__ __launch_bounds__(256) void bn_fold_backward_kernel(const float* __restrict__ dwp, int splits, const float* __restrict__ w,
+                                                               const float* __restrict__ scale, const float* __restrict__ mean,
+                                                               const float* __restrict__ istd, const float* __restrict__ db, int Cout, int Cin, int taps,
+                                                               int accumulate, float* __restrict__ gw, float* __restrict__ ggamma, float* __restrict__ gbeta) {
     __shared__ float red[4];
     const int co = (int)blockIdx.x;
     const int K = Cin * taps;
     const float s = scale[co];
+    const int64_t part = (int64_t)Cout * K;
     float dot = 0.0f;
     for (int k = threadIdx.x; k < K; k += 256) {
         const int tap = k / Cin, ci = k - tap * Cin;
         const int64_t iw = (int64_t)co * K + (int64_t)ci * taps + tap;
-        const float d = dwp[(int64_t)co * K + k];
+        float d = dwp[(int64_t)co * K + k];
+        for (int sp = 1; sp < splits; ++sp) d += dwp[sp * part + (int64_t)co * K + k];
         dot += d * w[iw];
         const float g = d * s;
         gw[iw] = accumulate ? gw[iw] + g : g;
     }
     dot = block_sum<256>(dot, red);
     if (threadIdx.x == 0) {
-        const float ds = dot - mean[co] * db[co];
+        float dbs = db[co];
+        for (int sp = 1; sp < splits; ++sp) dbs += db[(int64_t)sp * Cout + co];
+        const float ds = dot - mean[co] * dbs;
         const float gg = ds * istd[co];
         ggamma[co] = accumulate ? ggamma[co] + gg : gg;
-        gbeta[co] = accumulate ? gbeta[co] + db[co] : db[co];
+        gbeta[co] = accumulate ? gbeta[co] + dbs : dbs;
     }
 }
 
@@ -188,9 +206,17 @@ ISX_API int isx_conv1x1_dgrad_nhwc(const float* dz, int64_t M, int Cout, const f
     return launch_gemm_masked(dz, M, wt, Cin, Cout, dx, mask, add, (hipStream_t)stream);
 }
 
-// dW'[co][tap][ci] = sum over the output pixels p of dz[p][co] * x[src(p, tap)][ci].  taps = 1: a 1x1 convolution with `stride` (x: (B,H,W,Cin),
-// dz: (B,Ho,Wo,Cout)); taps = 9: 3x3, padding 1.  dw: (Cout, taps, Cin) -- the OHWI layout of the forward kernels.  Cout % 64 == 0, Cin % 64 == 0.
-ISX_API int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int H, int W, int Cin, int Cout, int taps, int stride, float* dw,
+// Number of pixel splits isx_conv_wgrad_nhwc uses for this shape (host arithmetic; sizes the partial buffers).
+ISX_API int isx_conv_wgrad_splits(int64_t pixels, int Cin, int Cout, int taps) {
+    if (pixels < 0 || Cin <= 0 || Cout <= 0 || (taps != 1 && taps != 9) || Cin % 64 != 0 || Cout % 64 != 0) return 0;
+    return wgrad_splits(pixels, Cin, Cout, taps);
+}
+
+// dW'[s][co][tap][ci] = sum over the output pixels p of split s of dz[p][co] * x[src(p, tap)][ci], db[s][co] = sum over the same pixels of
+// dz[p][co];  s < S = isx_conv_wgrad_splits(B * Ho * Wo, Cin, Cout, taps): the consumer (isx_bn_fold_backward) adds the S partials in order.
+// taps = 1: a 1x1 convolution with `stride` (x: (B,H,W,Cin), dz: (B,Ho,Wo,Cout)); taps = 9: 3x3, padding 1.  dw: (S, Cout, taps, Cin) -- per
+// partial the OHWI layout of the forward kernels; db: (S, Cout) or NULL.  Cout % 64 == 0, Cin % 64 == 0.
+ISX_API int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int H, int W, int Cin, int Cout, int taps, int stride, float* dw, float* db,
                                 isx_stream_t stream) {
     ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 9) && (stride == 1 || stride == 2),
                 "isx_conv_wgrad_nhwc: bad shape B=%lld H=%d W=%d Cin=%d Cout=%d taps=%d stride=%d", (long long)B, H, W, Cin, Cout, taps, stride);
@@ -206,46 +232,43 @@ ISX_API int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int 
     ISX_REQUIRE(K == 0 || (dz && x), "isx_conv_wgrad_nhwc: null pointer");
     ISX_REQUIRE((((uintptr_t)dz | (uintptr_t)x | (uintptr_t)dw) % 16) == 0, "isx_conv_wgrad_nhwc: dz, x and dw must be 16-B aligned");
     const int64_t ldc = (int64_t)taps * Cin;
+    const int S = wgrad_splits(K, Cin, Cout, taps);
+    const int kt_per = (int)((((K + 31) / 32) + S - 1) / S);
     hipStream_t st = (hipStream_t)stream;
     // 128x128 tiles once they fill the chip, 64x64 below (layer4 of ResNet-50: 2048 x 512 = 64 big tiles, 256 small ones)
     const int64_t big = (int64_t)(Cout / 128) * (Cin / 128) * taps;
     if (Cout % 128 == 0 && Cin % 128 == 0 && big >= 512) {
-        hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2>), dim3((unsigned)((Cout / 128) * (Cin / 128)), (unsigned)taps), dim3(256), 0, st, dz, K, Cout, x, Cin, g, taps, dw,
-                           ldc, Cin / 128);
+        hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2>), dim3((unsigned)((Cout / 128) * (Cin / 128)), (unsigned)taps, (unsigned)S), dim3(256), 0, st, dz, K, Cout, x, Cin,
+                           g, taps, dw, ldc, Cin / 128, kt_per, db);
     } else {
-        hipLaunchKernelGGL((wgrad_gemm_kernel<1, 1>), dim3((unsigned)((Cout / 64) * (Cin / 64)), (unsigned)taps), dim3(256), 0, st, dz, K, Cout, x, Cin, g, taps, dw,
-                           ldc, Cin / 64);
+        hipLaunchKernelGGL((wgrad_gemm_kernel<1, 1>), dim3((unsigned)((Cout / 64) * (Cin / 64)), (unsigned)taps, (unsigned)S), dim3(256), 0, st, dz, K, Cout, x, Cin,
+                           g, taps, dw, ldc, Cin / 64, kt_per, db);
     }
     ISX_CHECK_LAUNCH("isx_conv_wgrad_nhwc");
     return ISX_OK;
 }
 
-// dz = dy . [y > 0] (written) and db[c] = sum over the rows of dz[.][c].  dy, y, dz: (M, C); dz == dy allowed.
-ISX_API int isx_relu_grad_colsum(const float* dy, const float* y, int64_t M, int C, float* dz, float* db, isx_stream_t stream) {
-    ISX_REQUIRE(M >= 0 && C > 0, "isx_relu_grad_colsum: bad shape M=%lld C=%d", (long long)M, C);
-    ISX_REQUIRE(db && (M == 0 || (dy && y && dz)), "isx_relu_grad_colsum: null pointer");
-    hipLaunchKernelGGL((colsum_kernel<true>), dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dy, y, M, C, dz, db);
-    ISX_CHECK_LAUNCH("isx_relu_grad_colsum");
+// dz = dy . [y > 0]  (backward of the ReLU whose output is y).  dy, y, dz: n floats, n % 4 == 0, 16-B aligned; dz == dy allowed.
+ISX_API int isx_relu_grad(const float* dy, const float* y, int64_t n, float* dz, isx_stream_t stream) {
+    ISX_REQUIRE(n >= 0 && n % 4 == 0, "isx_relu_grad: n=%lld must be a non-negative multiple of 4", (long long)n);
+    if (n == 0) return ISX_OK;
+    ISX_REQUIRE(dy && y && dz, "isx_relu_grad: null pointer");
+    ISX_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)dz) % 16) == 0, "isx_relu_grad: pointers must be 16-B aligned");
+    hipLaunchKernelGGL(relu_grad_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)dy, (const float4*)y, n / 4,
+                       (float4*)dz);
+    ISX_CHECK_LAUNCH("isx_relu_grad");
     return ISX_OK;
 }
 
-// db[c] = sum over the rows of dz[.][c]  (bias gradient of a convolution whose output gradient is dz).
-ISX_API int isx_colsum_rows(const float* dz, int64_t M, int C, float* db, isx_stream_t stream) {
-    ISX_REQUIRE(M >= 0 && C > 0, "isx_colsum_rows: bad shape M=%lld C=%d", (long long)M, C);
-    ISX_REQUIRE(db && (M == 0 || dz), "isx_colsum_rows: null pointer");
-    hipLaunchKernelGGL((colsum_kernel<false>), dim3((unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, dz, nullptr, M, C, nullptr, db);
-    ISX_CHECK_LAUNCH("isx_colsum_rows");
-    return ISX_OK;
-}
-
-// Gradients of (conv weight, BN gamma, BN beta) from the gradients of the FOLDED convolution (dwp, db):
-// gw (+)= dwp * scale, ggamma (+)= (<dwp, w> - mean * db) * istd, gbeta (+)= db;  scale = gamma * istd, istd = 1 / sqrt(var + eps).
-// dwp: (Cout, taps, Cin); w, gw: (Cout, Cin, taps) (nn.Conv2d's OIHW); accumulate != 0 adds into gw / ggamma / gbeta.
-ISX_API int isx_bn_fold_backward(const float* dwp, const float* w, const float* scale, const float* mean, const float* istd, const float* db, int Cout,
-                                 int Cin, int taps, int accumulate, float* gw, float* ggamma, float* gbeta, isx_stream_t stream) {
-    ISX_REQUIRE(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9), "isx_bn_fold_backward: bad shape Cout=%d Cin=%d taps=%d", Cout, Cin, taps);
+// Gradients of (conv weight, BN gamma, BN beta) from the `splits` partial gradients of the FOLDED convolution (dwp, db) that
+// isx_conv_wgrad_nhwc wrote: with d = sum_s dwp[s], b = sum_s db[s] (split order):
+// gw (+)= d * scale, ggamma (+)= (<d, w> - mean * b) * istd, gbeta (+)= b;  scale = gamma * istd, istd = 1 / sqrt(var + eps).
+// dwp: (splits, Cout, taps, Cin); db: (splits, Cout); w, gw: (Cout, Cin, taps) (nn.Conv2d's OIHW); accumulate != 0 adds into gw / ggamma / gbeta.
+ISX_API int isx_bn_fold_backward(const float* dwp, const float* db, int splits, const float* w, const float* scale, const float* mean, const float* istd,
+                                 int Cout, int Cin, int taps, int accumulate, float* gw, float* ggamma, float* gbeta, isx_stream_t stream) {
+    ISX_REQUIRE(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9) && splits >= 1, "isx_bn_fold_backward: bad shape Cout=%d Cin=%d taps=%d splits=%d", Cout, Cin, taps, splits);
     ISX_REQUIRE(dwp && w && scale && mean && istd && db && gw && ggamma && gbeta, "isx_bn_fold_backward: null pointer");
-    hipLaunchKernelGGL(bn_fold_backward_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, dwp, w, scale, mean, istd, db, Cin, taps,
+    hipLaunchKernelGGL(bn_fold_backward_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, dwp, splits, w, scale, mean, istd, db, Cout, Cin, taps,
                        accumulate ? 1 : 0, gw, ggamma, gbeta);
     ISX_CHECK_LAUNCH("isx_bn_fold_backward");
     return ISX_OK;

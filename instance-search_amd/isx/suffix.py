@@ -9,9 +9,9 @@ autograd node over libisx:
             (isx_conv1x1_nhwc, isx_conv3x3_nhwc, isx_conv1x1_dual_nhwc: bias / shortcut / ReLU fused), activations kept channels-last
   backward  per convolution one dgrad GEMM with the ReLU mask of the layer below and the shortcut gradient fused into its epilogue
             (isx_conv1x1_dgrad_nhwc / isx_conv3x3_dgrad_nhwc), one weight-gradient GEMM over the pixels (isx_conv_wgrad_nhwc), the
-            bias gradient (isx_relu_grad_colsum / isx_colsum_rows) and the chain rule of the fold (isx_bn_fold_backward), which
-            ACCUMULATES straight into the parameters' .grad -- ~30 launches per micro-batch where MIOpen's per-image im2col + GEMM
-            loops took ~150.
+            bias gradient as its by-product, both split over the pixels into partials) and the chain rule of the fold
+            (isx_bn_fold_backward: adds the partials in order and ACCUMULATES straight into the parameters' .grad) -- ~45 launches per
+            micro-batch where MIOpen's per-image im2col + GEMM loops took ~150.
 
 The folded weights and their re-layouts are derived once per optimizer step (version counters of the parameters) -- the weights do not
 change between the micro-batches of a step.
@@ -146,22 +146,18 @@ class SuffixEngine(object):
 
     @staticmethod
     def _wgrad(dz, x, f):
-        """(Cout, taps, Cin) gradient of the FOLDED weight: dz (B,Ho,Wo,Cout), x (B,H,W,Cin)."""
+        """Partial gradients of the FOLDED weight and bias: ((S, Cout, taps, Cin), (S, Cout)); dz (B,Ho,Wo,Cout), x (B,H,W,Cin)."""
         B, H, W, _ = x.shape
-        dw = torch.empty((f.cout, f.taps, f.cin), device=x.device, dtype=torch.float32)
-        check(lib().isx_conv_wgrad_nhwc(dz.data_ptr(), x.data_ptr(), B, H, W, f.cin, f.cout, f.taps, f.stride, dw.data_ptr(), _stream()), "isx_conv_wgrad_nhwc")
-        return dw
-
-    @staticmethod
-    def _colsum(dz):
-        C = dz.shape[-1]
-        db = torch.empty((C,), device=dz.device, dtype=torch.float32)
-        check(lib().isx_colsum_rows(dz.data_ptr(), dz.numel() // C, C, db.data_ptr(), _stream()), "isx_colsum_rows")
-        return db
+        S = lib().isx_conv_wgrad_splits(dz.numel() // f.cout, f.cin, f.cout, f.taps)
+        dw = torch.empty((S, f.cout, f.taps, f.cin), device=x.device, dtype=torch.float32)
+        db = torch.empty((S, f.cout), device=x.device, dtype=torch.float32)
+        check(lib().isx_conv_wgrad_nhwc(dz.data_ptr(), x.data_ptr(), B, H, W, f.cin, f.cout, f.taps, f.stride, dw.data_ptr(), db.data_ptr(), _stream()),
+              "isx_conv_wgrad_nhwc")
+        return dw, db
 
     @staticmethod
     def _fold_backward(f, dwp, db, grads):
-        """Accumulate the gradients of (conv.weight, bn.weight, bn.bias) from those of the folded convolution.  Parameters that already
+        """Accumulate the gradients of (conv.weight, bn.weight, bn.bias) from the partials of the folded convolution.  Parameters that already
         hold a .grad are accumulated IN PLACE (no autograd add pass); the others get a fresh tensor handed back to autograd."""
         outs = []
         for p in (f.conv.weight, f.bn.weight, f.bn.bias):
@@ -173,8 +169,9 @@ class SuffixEngine(object):
                 g = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 outs.append(g)
                 grads.append(g)
-        check(lib().isx_bn_fold_backward(dwp.data_ptr(), f.conv.weight.data_ptr(), f.scale.data_ptr(), f.mean.data_ptr(), f.istd.data_ptr(), db.data_ptr(),
-                                         f.cout, f.cin, f.taps, 1, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream()), "isx_bn_fold_backward")
+        check(lib().isx_bn_fold_backward(dwp.data_ptr(), db.data_ptr(), dwp.shape[0], f.conv.weight.data_ptr(), f.scale.data_ptr(), f.mean.data_ptr(),
+                                         f.istd.data_ptr(), f.cout, f.cin, f.taps, 1, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream()),
+              "isx_bn_fold_backward")
 
     # ---- forward / backward of the whole suffix -------------------------------------------------------------------------------------
     def forward(self, x_nchw):
@@ -214,22 +211,21 @@ class SuffixEngine(object):
             B, H, W, _ = x.shape
             Ho, Wo = t2.shape[1], t2.shape[2]
             M2 = B * Ho * Wo
-            if dS is None:                                    # the last block: backward of its output ReLU + bias gradient in one pass
+            if dS is None:                                    # the last block: backward of its output ReLU
                 dS = torch.empty_like(y)
-                db3 = torch.empty((f3.cout,), device=y.device, dtype=torch.float32)
-                check(L.isx_relu_grad_colsum(dy.data_ptr(), y.data_ptr(), M2, f3.cout, dS.data_ptr(), db3.data_ptr(), st), "isx_relu_grad_colsum")
-            else:                                             # the mask was fused into the dgrad of the block above
-                db3 = self._colsum(dS)
+                check(L.isx_relu_grad(dy.data_ptr(), y.data_ptr(), y.numel(), dS.data_ptr(), st), "isx_relu_grad")
+            # (further down the mask is fused into the dgrad of the block above)
             g1, g2, g3, gd = [], [], [], []
-            # conv3 (+ projection): weight gradients, then the gradient wrt t2 with t2's ReLU fused
-            self._fold_backward(f3, self._wgrad(dS, t2, f3), db3, g3)
+            # conv3 (+ projection): weight gradients (the bias gradient = column sums of dS comes with them), then the gradient wrt t2 with t2's ReLU fused
+            dw3, db3 = self._wgrad(dS, t2, f3)
+            self._fold_backward(f3, dw3, db3, g3)
             if fd is not None:
-                self._fold_backward(fd, self._wgrad(dS, x, fd), db3, gd)
+                self._fold_backward(fd, *self._wgrad(dS, x, fd), gd)
             dT2 = torch.empty_like(t2)
             check(L.isx_conv1x1_dgrad_nhwc(dS.data_ptr(), M2, f3.cout, f3.w_dgrad.data_ptr(), f3.cin, None, t2.data_ptr(), dT2.data_ptr(), st),
                   "isx_conv1x1_dgrad_nhwc")
             # conv2 (3x3)
-            self._fold_backward(f2, self._wgrad(dT2, t1, f2), self._colsum(dT2), g2)
+            self._fold_backward(f2, *self._wgrad(dT2, t1, f2), g2)
             if f2.stride == 2:                                # zero-upsample to the input grid: the gradient becomes a stride-1 convolution
                 up = torch.zeros((B, H, W, f2.cout), device=x.device, dtype=torch.float32)
                 up[:, ::2, ::2] = dT2
@@ -238,7 +234,7 @@ class SuffixEngine(object):
             check(L.isx_conv3x3_dgrad_nhwc(dT2.data_ptr(), B, H, W, f2.cout, f2.w_dgrad.data_ptr(), f2.cin, t1.data_ptr(), dT1.data_ptr(), st),
                   "isx_conv3x3_dgrad_nhwc")
             # conv1
-            self._fold_backward(f1, self._wgrad(dT1, x, f1), self._colsum(dT1), g1)
+            self._fold_backward(f1, *self._wgrad(dT1, x, f1), g1)
             grads_rev.append(g1 + g2 + g3 + gd)
             if bi == 0:
                 break                                         # the prefix below is frozen and carries no graph: no gradient wrt x

@@ -189,7 +189,7 @@ class _SplitTrunk(object):
             from isx.suffix import SuffixEngine
             key = (id(features), split)
             eng = cls._engines.get(key)
-            if eng is None or eng.blocks != mods:
+            if eng is None or (eng is not False and eng.blocks != mods):
                 eng = cls._engines[key] = SuffixEngine(mods) if SuffixEngine.applicable(mods) else False
                 if len(cls._engines) > 8:
                     cls._engines.pop(next(iter(cls._engines)))
