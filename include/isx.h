@@ -345,27 +345,30 @@ int isx_conv1x1_dgrad_nhwc(const float* dz, int64_t M, int Cout, const float* wt
 int isx_conv3x3_dgrad_nhwc(const float* dz, int64_t B, int H, int W, int Cout, const float* wt, int Cin, const float* mask,
                            float* dx, isx_stream_t stream);
 
-/* Weight gradient, split over the pixels: dw[s][co][tap][ci] = sum over the output pixels p of split s of dz[p][co] * x[src(p, tap)][ci]
- * and db[s][co] = sum over the same pixels of dz[p][co] (the bias gradient, a by-product of the staged dz tiles), for
- * s < S = isx_conv_wgrad_splits(B*Ho*Wo, Cin, Cout, taps) -- a function of the shape only.  isx_bn_fold_backward adds the S partials in
- * split order: a fixed summation tree, no atomics.  taps = 1: 1x1 convolution with `stride` (no padding); taps = 9: 3x3, padding 1,
- * `stride`.  x: (B,H,W,Cin), dz: (B,Ho,Wo,Cout), dw: (S,Cout,taps,Cin) -- per partial the layout of the forward kernels' weights;
- * db: (S,Cout) or NULL.  Pixels are summed in index order (k-ordered fp32 fma chain).  Cin, Cout % 64 == 0. */
+/* Weight gradient of `leaves` micro-batches in one launch, each split over its pixels: the B images are `leaves` consecutive groups;
+ * dw[l][s][co][tap][ci] = sum over the output pixels p of split s of leaf l of dz[p][co] * x[src(p, tap)][ci] and db[l][s][co] = sum over
+ * the same pixels of dz[p][co] (the bias gradient, a by-product of the staged dz tiles), s < S = isx_conv_wgrad_splits(pixels of ONE
+ * leaf, Cin, Cout, taps).  A leaf's partials are the same bits whether it is launched alone or with its siblings (its k-tiles start at
+ * its first pixel; S and the tile shape depend on the leaf's shape only); isx_bn_fold_backward adds them in split order: a fixed
+ * summation tree, no atomics.  taps = 1: 1x1 convolution with `stride` (no padding); taps = 9: 3x3, padding 1, `stride`.
+ * x: (B,H,W,Cin), dz: (B,Ho,Wo,Cout), dw: (leaves,S,Cout,taps,Cin) -- per partial the layout of the forward kernels' weights;
+ * db: (leaves,S,Cout) or NULL.  Pixels are summed in index order (k-ordered fp32 fma chain).  Cin, Cout % 64 == 0; B % leaves == 0. */
 int isx_conv_wgrad_splits(int64_t pixels, int Cin, int Cout, int taps);
-int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int H, int W, int Cin, int Cout, int taps, int stride,
+int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int leaves, int H, int W, int Cin, int Cout, int taps, int stride,
                         float* dw, float* db, isx_stream_t stream);
 
 /* Backward of y = relu(.) at a block output: dz = dy . [y > 0].  n floats (n % 4 == 0, 16-B aligned); dz == dy allowed. */
 int isx_relu_grad(const float* dy, const float* y, int64_t n, float* dz, isx_stream_t stream);
 
-/* Chain rule of the BatchNorm fold: from the `splits` partial gradients (dwp, db) of the folded convolution (as written by
- * isx_conv_wgrad_nhwc; d = sum_s dwp[s], b = sum_s db[s]) to the gradients of the convolution weight and the BatchNorm affine
- * parameters: gw (+)= d * scale, ggamma (+)= (<d, w> - mean * b) * istd, gbeta (+)= b, with scale = gamma * istd,
- * istd = 1 / sqrt(running_var + eps).  dwp: (splits,Cout,taps,Cin); db: (splits,Cout); w, gw: (Cout,Cin,taps) (nn.Conv2d's layout);
- * scale, mean, istd, ggamma, gbeta: (Cout); accumulate != 0 adds into gw / ggamma / gbeta (gradient accumulation). */
-int isx_bn_fold_backward(const float* dwp, const float* db, int splits, const float* w, const float* scale, const float* mean,
-                         const float* istd, int Cout, int Cin, int taps, int accumulate, float* gw, float* ggamma, float* gbeta,
-                         isx_stream_t stream);
+/* Chain rule of the BatchNorm fold, per leaf: from the partial gradients (dwp, db) of the folded convolution (as written by
+ * isx_conv_wgrad_nhwc; d = sum_s dwp[l][s], b = sum_s db[l][s]) to the gradients of the convolution weight and the BatchNorm affine
+ * parameters: gw_l (+)= d * scale, ggamma_l (+)= (<d, w> - mean * b) * istd, gbeta_l (+)= b, with scale = gamma * istd,
+ * istd = 1 / sqrt(running_var + eps).  dwp: (leaves,splits,Cout,taps,Cin); db: (leaves,splits,Cout); w: (Cout,Cin,taps) (nn.Conv2d's
+ * layout); gw / ggamma / gbeta: the gradient tensors of leaf 0 (parameter layouts), leaf l at + l * leaf_stride floats (one flat gradient
+ * buffer per leaf; leaves == 1: plain tensors); scale, mean, istd: (Cout); accumulate != 0 adds into them (gradient accumulation). */
+int isx_bn_fold_backward(const float* dwp, const float* db, int leaves, int splits, const float* w, const float* scale, const float* mean,
+                         const float* istd, int Cout, int Cin, int taps, int accumulate, int64_t leaf_stride, float* gw, float* ggamma,
+                         float* gbeta, isx_stream_t stream);
 
 #ifdef __cplusplus
 }

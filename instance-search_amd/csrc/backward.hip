@@ -43,14 +43,17 @@ __device__ __forceinline__ int64_t wgrad_src_row(const WgradGeom& g, int64_t p, 
 template <int TM, int TN>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict__ A, int64_t K, int N1, const float* __restrict__ Bm, int N2,
                                                          WgradGeom g, int taps, float* __restrict__ C, int64_t ldc, int tiles_n, int kt_per,
-                                                         float* __restrict__ colsum) {
+                                                         int splits, float* __restrict__ colsum) {
     constexpr int BK = 32, BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + 4;       // +4: rows stay 16-B aligned for the float4 stores
     constexpr int CA = BM / 4, CB = BN / 4, NA = BK * CA / 256, NB = BK * CB / 256;
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
     float* Bs = lds + BK * LDA;
     const int tile_m = (int)blockIdx.x / tiles_n, tile_n = (int)blockIdx.x % tiles_n;
-    const int tap = (int)blockIdx.y, split = (int)blockIdx.z;
+    // blockIdx.z = leaf * splits + sub: K is the pixel count of ONE leaf (micro-batch); leaf l owns the pixels [l * K, (l + 1) * K) of dz and its
+    // k-tiles restart at its first pixel, so a leaf's partials are the same bits whether it is launched alone or with its siblings
+    const int tap = (int)blockIdx.y, split = (int)blockIdx.z, sub = split % splits;
+    const int64_t pix0 = (int64_t)(split / splits) * K;
     const int dh = taps == 9 ? tap / 3 - 1 : 0, dw = taps == 9 ? tap % 3 - 1 : 0;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bool sums = colsum != nullptr && tile_n == 0 && tap == 0 && (int)threadIdx.x < BM;      // (uniform per wave: BM is 64 or 128)
@@ -73,13 +76,13 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict
         for (int j = 0; j < NA; ++j) {
             const int idx = j * 256 + threadIdx.x;
             const int64_t p = k0 + idx / CA;
-            ra[j] = p < K ? *reinterpret_cast<const float4*>(A + p * N1 + m0 + ((idx % CA) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ra[j] = p < K ? *reinterpret_cast<const float4*>(A + (pix0 + p) * N1 + m0 + ((idx % CA) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int idx = j * 256 + threadIdx.x;
             const int64_t p = k0 + idx / CB;
-            const int64_t s = p < K ? wgrad_src_row(g, p, dh, dw) : -1;
+            const int64_t s = p < K ? wgrad_src_row(g, pix0 + p, dh, dw) : -1;
             rb[j] = s >= 0 ? *reinterpret_cast<const float4*>(Bm + s * N2 + n0 + ((idx % CB) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict
     };
 
     const int64_t nk_all = (K + BK - 1) / BK;
-    const int64_t kt0 = (int64_t)split * kt_per;
+    const int64_t kt0 = (int64_t)sub * kt_per;
     const int64_t kt1 = kt0 + kt_per < nk_all ? kt0 + kt_per : nk_all;
     float csum = 0.0f;
     if (kt0 < kt1) {
@@ -158,17 +161,22 @@ __global__ __launch_bounds__(256) void relu_grad_kernel(const float4* __restrict
 }
 
 // ---- chain rule of the BatchNorm fold -----------------------------------------------------------------------------------------
-// one block per output channel.  dwp: `splits` partials of (Cout, taps, Cin) [the wgrad layout], added in split order; db: `splits`
-// partials of (Cout); w / gw: (Cout, Cin, taps) [the nn.Conv2d parameter layout]
+// one block per (output channel, leaf).  dwp: leaves x splits partials of (Cout, taps, Cin) [the wgrad layout], a leaf's partials added in
+// split order; db: leaves x splits partials of (Cout); w: (Cout, Cin, taps) [the nn.Conv2d parameter layout]; gw / ggamma / gbeta: leaf l
+// writes at + l * leaf_stride floats (the leaf's own flat gradient buffer), same layouts as the parameters
 __global__ __launch_bounds__(256) void bn_fold_backward_kernel(const float* __restrict__ dwp, int splits, const float* __restrict__ w,
                                                                const float* __restrict__ scale, const float* __restrict__ mean,
                                                                const float* __restrict__ istd, const float* __restrict__ db, int Cout, int Cin, int taps,
-                                                               int accumulate, float* __restrict__ gw, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+                                                               int accumulate, int64_t leaf_stride, float* __restrict__ gw, float* __restrict__ ggamma,
+                                                               float* __restrict__ gbeta) {
     __shared__ float red[4];
-    const int co = (int)blockIdx.x;
+    const int co = (int)blockIdx.x, leaf = (int)blockIdx.y;
     const int K = Cin * taps;
     const float s = scale[co];
     const int64_t part = (int64_t)Cout * K;
+    dwp += (int64_t)leaf * splits * part;
+    db += (int64_t)leaf * splits * Cout;
+    gw += leaf * leaf_stride; ggamma += leaf * leaf_stride; gbeta += leaf * leaf_stride;
     float dot = 0.0f;
     for (int k = threadIdx.x; k < K; k += 256) {
         const int tap = k / Cin, ci = k - tap * Cin;
@@ -212,14 +220,17 @@ ISX_API int isx_conv_wgrad_splits(int64_t pixels, int Cin, int Cout, int taps) {
     return wgrad_splits(pixels, Cin, Cout, taps);
 }
 
-// dW'[s][co][tap][ci] = sum over the output pixels p of split s of dz[p][co] * x[src(p, tap)][ci], db[s][co] = sum over the same pixels of
-// dz[p][co];  s < S = isx_conv_wgrad_splits(B * Ho * Wo, Cin, Cout, taps): the consumer (isx_bn_fold_backward) adds the S partials in order.
-// taps = 1: a 1x1 convolution with `stride` (x: (B,H,W,Cin), dz: (B,Ho,Wo,Cout)); taps = 9: 3x3, padding 1.  dw: (S, Cout, taps, Cin) -- per
-// partial the OHWI layout of the forward kernels; db: (S, Cout) or NULL.  Cout % 64 == 0, Cin % 64 == 0.
-ISX_API int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int H, int W, int Cin, int Cout, int taps, int stride, float* dw, float* db,
-                                isx_stream_t stream) {
-    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 9) && (stride == 1 || stride == 2),
-                "isx_conv_wgrad_nhwc: bad shape B=%lld H=%d W=%d Cin=%d Cout=%d taps=%d stride=%d", (long long)B, H, W, Cin, Cout, taps, stride);
+// Weight gradient of `leaves` micro-batches in one launch.  The B images are `leaves` consecutive groups of B / leaves; for leaf l and
+// split s < S = isx_conv_wgrad_splits(pixels of ONE leaf, Cin, Cout, taps):
+//   dw[l][s][co][tap][ci] = sum over the output pixels p of split s of leaf l of dz[p][co] * x[src(p, tap)][ci],  db[l][s][co] = sum of dz[p][co]
+// -- a leaf's partials are the same bits whether it is launched alone or with its siblings; isx_bn_fold_backward adds them in split order.
+// taps = 1: a 1x1 convolution with `stride` (x: (B,H,W,Cin), dz: (B,Ho,Wo,Cout)); taps = 9: 3x3, padding 1.  dw: (leaves, S, Cout, taps, Cin) -- per
+// partial the OHWI layout of the forward kernels; db: (leaves, S, Cout) or NULL.  Cout % 64 == 0, Cin % 64 == 0.
+ISX_API int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int leaves, int H, int W, int Cin, int Cout, int taps, int stride, float* dw,
+                                float* db, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 9) && (stride == 1 || stride == 2) && leaves >= 1 && leaves <= 4096,
+                "isx_conv_wgrad_nhwc: bad shape B=%lld leaves=%d H=%d W=%d Cin=%d Cout=%d taps=%d stride=%d", (long long)B, leaves, H, W, Cin, Cout, taps, stride);
+    ISX_REQUIRE(B % leaves == 0, "isx_conv_wgrad_nhwc: B=%lld is not a multiple of leaves=%d", (long long)B, leaves);
     ISX_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "isx_conv_wgrad_nhwc: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
     ISX_REQUIRE(B * H * W < (1ll << 31), "isx_conv_wgrad_nhwc: too many pixels for 32-bit pixel indices");
     ISX_REQUIRE(dw, "isx_conv_wgrad_nhwc: null pointer");
@@ -228,21 +239,23 @@ ISX_API int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int 
     g.Ho = (H - 1) / stride + 1;
     g.Wo = (W - 1) / stride + 1;
     g.ident = (taps == 1 && stride == 1) ? 1 : 0;
-    const int64_t K = B * g.Ho * g.Wo;
+    const int64_t K = (B / leaves) * g.Ho * g.Wo;               // pixels of one leaf
     ISX_REQUIRE(K == 0 || (dz && x), "isx_conv_wgrad_nhwc: null pointer");
     ISX_REQUIRE((((uintptr_t)dz | (uintptr_t)x | (uintptr_t)dw) % 16) == 0, "isx_conv_wgrad_nhwc: dz, x and dw must be 16-B aligned");
     const int64_t ldc = (int64_t)taps * Cin;
     const int S = wgrad_splits(K, Cin, Cout, taps);
     const int kt_per = (int)((((K + 31) / 32) + S - 1) / S);
+    ISX_REQUIRE((int64_t)leaves * S <= 65535, "isx_conv_wgrad_nhwc: leaves x splits exceeds the grid's z extent");
     hipStream_t st = (hipStream_t)stream;
-    // 128x128 tiles once they fill the chip, 64x64 below (layer4 of ResNet-50: 2048 x 512 = 64 big tiles, 256 small ones)
+    // 128x128 tiles once they fill the chip, 64x64 below (layer4 of ResNet-50: 2048 x 512 = 64 big tiles, 256 small ones); chosen from the
+    // shape of ONE leaf, like S: the arithmetic of a leaf must not depend on how many leaves share the launch
     const int64_t big = (int64_t)(Cout / 128) * (Cin / 128) * taps;
     if (Cout % 128 == 0 && Cin % 128 == 0 && big >= 512) {
-        hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2>), dim3((unsigned)((Cout / 128) * (Cin / 128)), (unsigned)taps, (unsigned)S), dim3(256), 0, st, dz, K, Cout, x, Cin,
-                           g, taps, dw, ldc, Cin / 128, kt_per, db);
+        hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2>), dim3((unsigned)((Cout / 128) * (Cin / 128)), (unsigned)taps, (unsigned)(leaves * S)), dim3(256), 0, st, dz, K,
+                           Cout, x, Cin, g, taps, dw, ldc, Cin / 128, kt_per, S, db);
     } else {
-        hipLaunchKernelGGL((wgrad_gemm_kernel<1, 1>), dim3((unsigned)((Cout / 64) * (Cin / 64)), (unsigned)taps, (unsigned)S), dim3(256), 0, st, dz, K, Cout, x, Cin,
-                           g, taps, dw, ldc, Cin / 64, kt_per, db);
+        hipLaunchKernelGGL((wgrad_gemm_kernel<1, 1>), dim3((unsigned)((Cout / 64) * (Cin / 64)), (unsigned)taps, (unsigned)(leaves * S)), dim3(256), 0, st, dz, K,
+                           Cout, x, Cin, g, taps, dw, ldc, Cin / 64, kt_per, S, db);
     }
     ISX_CHECK_LAUNCH("isx_conv_wgrad_nhwc");
     return ISX_OK;
@@ -260,16 +273,19 @@ ISX_API int isx_relu_grad(const float* dy, const float* y, int64_t n, float* dz,
     return ISX_OK;
 }
 
-// Gradients of (conv weight, BN gamma, BN beta) from the `splits` partial gradients of the FOLDED convolution (dwp, db) that
-// isx_conv_wgrad_nhwc wrote: with d = sum_s dwp[s], b = sum_s db[s] (split order):
-// gw (+)= d * scale, ggamma (+)= (<d, w> - mean * b) * istd, gbeta (+)= b;  scale = gamma * istd, istd = 1 / sqrt(var + eps).
-// dwp: (splits, Cout, taps, Cin); db: (splits, Cout); w, gw: (Cout, Cin, taps) (nn.Conv2d's OIHW); accumulate != 0 adds into gw / ggamma / gbeta.
-ISX_API int isx_bn_fold_backward(const float* dwp, const float* db, int splits, const float* w, const float* scale, const float* mean, const float* istd,
-                                 int Cout, int Cin, int taps, int accumulate, float* gw, float* ggamma, float* gbeta, isx_stream_t stream) {
-    ISX_REQUIRE(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9) && splits >= 1, "isx_bn_fold_backward: bad shape Cout=%d Cin=%d taps=%d splits=%d", Cout, Cin, taps, splits);
+// Gradients of (conv weight, BN gamma, BN beta) of `leaves` micro-batches from the partial gradients of the FOLDED convolution (dwp, db) that
+// isx_conv_wgrad_nhwc wrote: per leaf l, with d = sum_s dwp[l][s], b = sum_s db[l][s] (split order):
+// gw_l (+)= d * scale, ggamma_l (+)= (<d, w> - mean * b) * istd, gbeta_l (+)= b;  scale = gamma * istd, istd = 1 / sqrt(var + eps).
+// dwp: (leaves, splits, Cout, taps, Cin); db: (leaves, splits, Cout); w: (Cout, Cin, taps) (nn.Conv2d's OIHW); gw / ggamma / gbeta: the
+// gradient tensors of leaf 0, leaf l at + l * leaf_stride floats (one flat gradient buffer per leaf); accumulate != 0 adds into them.
+ISX_API int isx_bn_fold_backward(const float* dwp, const float* db, int leaves, int splits, const float* w, const float* scale, const float* mean,
+                                 const float* istd, int Cout, int Cin, int taps, int accumulate, int64_t leaf_stride, float* gw, float* ggamma, float* gbeta,
+                                 isx_stream_t stream) {
+    ISX_REQUIRE(Cout > 0 && Cin > 0 && (taps == 1 || taps == 9) && splits >= 1 && leaves >= 1 && leaves <= 65535 && leaf_stride >= 0,
+                "isx_bn_fold_backward: bad shape Cout=%d Cin=%d taps=%d splits=%d leaves=%d", Cout, Cin, taps, splits, leaves);
     ISX_REQUIRE(dwp && w && scale && mean && istd && db && gw && ggamma && gbeta, "isx_bn_fold_backward: null pointer");
-    hipLaunchKernelGGL(bn_fold_backward_kernel, dim3((unsigned)Cout), dim3(256), 0, (hipStream_t)stream, dwp, splits, w, scale, mean, istd, db, Cout, Cin, taps,
-                       accumulate ? 1 : 0, gw, ggamma, gbeta);
+    hipLaunchKernelGGL(bn_fold_backward_kernel, dim3((unsigned)Cout, (unsigned)leaves), dim3(256), 0, (hipStream_t)stream, dwp, splits, w, scale, mean, istd, db, Cout,
+                       Cin, taps, accumulate ? 1 : 0, leaf_stride, gw, ggamma, gbeta);
     ISX_CHECK_LAUNCH("isx_bn_fold_backward");
     return ISX_OK;
 }

@@ -145,22 +145,35 @@ class SuffixEngine(object):
         return y
 
     @staticmethod
-    def _wgrad(dz, x, f):
-        """Partial gradients of the FOLDED weight and bias: ((S, Cout, taps, Cin), (S, Cout)); dz (B,Ho,Wo,Cout), x (B,H,W,Cin)."""
+    def _wgrad(dz, x, f, leaves=1):
+        """Partial gradients of the FOLDED weight and bias per leaf: ((leaves, S, Cout, taps, Cin), (leaves, S, Cout)); dz (B,Ho,Wo,Cout), x (B,H,W,Cin)."""
         B, H, W, _ = x.shape
-        S = lib().isx_conv_wgrad_splits(dz.numel() // f.cout, f.cin, f.cout, f.taps)
-        dw = torch.empty((S, f.cout, f.taps, f.cin), device=x.device, dtype=torch.float32)
-        db = torch.empty((S, f.cout), device=x.device, dtype=torch.float32)
-        check(lib().isx_conv_wgrad_nhwc(dz.data_ptr(), x.data_ptr(), B, H, W, f.cin, f.cout, f.taps, f.stride, dw.data_ptr(), db.data_ptr(), _stream()),
+        S = lib().isx_conv_wgrad_splits(dz.numel() // f.cout // leaves, f.cin, f.cout, f.taps)
+        dw = torch.empty((leaves, S, f.cout, f.taps, f.cin), device=x.device, dtype=torch.float32)
+        db = torch.empty((leaves, S, f.cout), device=x.device, dtype=torch.float32)
+        check(lib().isx_conv_wgrad_nhwc(dz.data_ptr(), x.data_ptr(), B, leaves, H, W, f.cin, f.cout, f.taps, f.stride, dw.data_ptr(), db.data_ptr(), _stream()),
               "isx_conv_wgrad_nhwc")
         return dw, db
 
     @staticmethod
-    def _fold_backward(f, dwp, db, grads):
-        """Accumulate the gradients of (conv.weight, bn.weight, bn.bias) from the partials of the folded convolution.  Parameters that already
-        hold a .grad are accumulated IN PLACE (no autograd add pass); the others get a fresh tensor handed back to autograd."""
+    def _fold_backward(f, dwp, db, grads, leaf_grads=None):
+        """Gradients of (conv.weight, bn.weight, bn.bias) from the partials of the folded convolution.
+        leaf_grads = (flat_all (L, total), slices): leaf l's gradients are WRITTEN into row l of flat_all at the parameters' slices (the
+        training step's per-leaf flat gradient buffers).  Otherwise (one leaf): parameters that already hold a .grad are accumulated IN PLACE
+        (no autograd add pass); the others get a fresh tensor handed back to autograd."""
+        params = (f.conv.weight, f.bn.weight, f.bn.bias)
+        leaves, S = dwp.shape[0], dwp.shape[1]
+        if leaf_grads is not None:
+            flat_all, slices = leaf_grads
+            base = flat_all.data_ptr()
+            ptrs = [base + 4 * slices[p][0] for p in params]
+            grads += [None, None, None]
+            check(lib().isx_bn_fold_backward(dwp.data_ptr(), db.data_ptr(), leaves, S, f.conv.weight.data_ptr(), f.scale.data_ptr(), f.mean.data_ptr(),
+                                             f.istd.data_ptr(), f.cout, f.cin, f.taps, 0, flat_all.stride(0), ptrs[0], ptrs[1], ptrs[2], _stream()),
+                  "isx_bn_fold_backward")
+            return
         outs = []
-        for p in (f.conv.weight, f.bn.weight, f.bn.bias):
+        for p in params:
             g = p.grad
             if g is not None and g.is_contiguous() and g.dtype == torch.float32:
                 outs.append(g)
@@ -169,8 +182,8 @@ class SuffixEngine(object):
                 g = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 outs.append(g)
                 grads.append(g)
-        check(lib().isx_bn_fold_backward(dwp.data_ptr(), db.data_ptr(), dwp.shape[0], f.conv.weight.data_ptr(), f.scale.data_ptr(), f.mean.data_ptr(),
-                                         f.istd.data_ptr(), f.cout, f.cin, f.taps, 1, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream()),
+        check(lib().isx_bn_fold_backward(dwp.data_ptr(), db.data_ptr(), 1, S, f.conv.weight.data_ptr(), f.scale.data_ptr(), f.mean.data_ptr(),
+                                         f.istd.data_ptr(), f.cout, f.cin, f.taps, 1, 0, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream()),
               "isx_bn_fold_backward")
 
     # ---- forward / backward of the whole suffix -------------------------------------------------------------------------------------
@@ -197,7 +210,13 @@ class SuffixEngine(object):
             x = y
         return x.permute(0, 3, 1, 2), saved
 
-    def backward(self, saved, dy_nchw):
+    def backward(self, saved, dy_nchw, leaves=1, leaf_grads=None):
+        """Backward of forward().  leaves > 1: the batch is `leaves` consecutive micro-batches of equal size whose parameter gradients are
+        kept APART (leaf_grads = (flat_all, slices), see _fold_backward) -- forward and dgrad kernels compute every row as they would in a
+        launch of its own, the weight-gradient kernel restarts its pixel sum at every leaf, so leaf l's gradient is bit for bit what a
+        launch of leaf l alone produces."""
+        if leaves > 1 and leaf_grads is None:
+            raise _lib.IsxError("suffix engine: per-leaf gradients need leaf_grads")
         dy = dy_nchw.permute(0, 2, 3, 1)
         if not dy.is_contiguous():
             dy = dy.contiguous()
@@ -217,15 +236,14 @@ class SuffixEngine(object):
             # (further down the mask is fused into the dgrad of the block above)
             g1, g2, g3, gd = [], [], [], []
             # conv3 (+ projection): weight gradients (the bias gradient = column sums of dS comes with them), then the gradient wrt t2 with t2's ReLU fused
-            dw3, db3 = self._wgrad(dS, t2, f3)
-            self._fold_backward(f3, dw3, db3, g3)
+            self._fold_backward(f3, *self._wgrad(dS, t2, f3, leaves), g3, leaf_grads)
             if fd is not None:
-                self._fold_backward(fd, *self._wgrad(dS, x, fd), gd)
+                self._fold_backward(fd, *self._wgrad(dS, x, fd, leaves), gd, leaf_grads)
             dT2 = torch.empty_like(t2)
             check(L.isx_conv1x1_dgrad_nhwc(dS.data_ptr(), M2, f3.cout, f3.w_dgrad.data_ptr(), f3.cin, None, t2.data_ptr(), dT2.data_ptr(), st),
                   "isx_conv1x1_dgrad_nhwc")
             # conv2 (3x3)
-            self._fold_backward(f2, *self._wgrad(dT2, t1, f2), g2)
+            self._fold_backward(f2, *self._wgrad(dT2, t1, f2, leaves), g2, leaf_grads)
             if f2.stride == 2:                                # zero-upsample to the input grid: the gradient becomes a stride-1 convolution
                 up = torch.zeros((B, H, W, f2.cout), device=x.device, dtype=torch.float32)
                 up[:, ::2, ::2] = dT2
@@ -234,7 +252,7 @@ class SuffixEngine(object):
             check(L.isx_conv3x3_dgrad_nhwc(dT2.data_ptr(), B, H, W, f2.cout, f2.w_dgrad.data_ptr(), f2.cin, t1.data_ptr(), dT1.data_ptr(), st),
                   "isx_conv3x3_dgrad_nhwc")
             # conv1
-            self._fold_backward(f1, *self._wgrad(dT1, x, f1), g1)
+            self._fold_backward(f1, *self._wgrad(dT1, x, f1, leaves), g1, leaf_grads)
             grads_rev.append(g1 + g2 + g3 + gd)
             if bi == 0:
                 break                                         # the prefix below is frozen and carries no graph: no gradient wrt x

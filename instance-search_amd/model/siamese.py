@@ -274,6 +274,34 @@ class DescriptorNet(nn.Module):
         f, _ = self._trunk.prefix(self.features, torch.cat(xs, 0))
         return tuple(f.split(sizes, 0))
 
+    def suffix_engine(self):
+        """The libisx engine of the trainable trunk suffix when a training step may drive it directly (whole-slice forward / backward with
+        per-micro-batch gradients, utils/train_general._Stepper), else None."""
+        if not (self.trunk_precomputable() and SUFFIX_ENGINE and self._trunk.folded is not None):
+            return None
+        mods = list(self.features)[self._trunk.split:]
+        if not mods or not any(p.requires_grad for m in mods for p in m.parameters()):
+            return None
+        from isx.suffix import SuffixEngine
+        key = (id(self.features), self._trunk.split)
+        eng = _SplitTrunk._engines.get(key)
+        if eng is None or (eng is not False and eng.blocks != mods):
+            eng = _SplitTrunk._engines[key] = SuffixEngine(mods) if SuffixEngine.applicable(mods) else False
+        return eng if eng and SuffixEngine.applicable(mods) else None
+
+    def head_features(self, f1, f2=None, f3=None):
+        """descriptor head + final L2 on the SUFFIX output of the branches (together, as forward_features sends them through suffix + head)"""
+        return _many(self._head_only, [f for f in (f1, f2, f3) if f is not None])
+
+    def _head_only(self, f):
+        return self.feature_reduc2(_apply_head(self.feature_reduc1, f.reshape(f.size(0), -1)))
+
+    def head_rows(self, f, n_branches):
+        """head_features on the branches ALREADY concatenated along the batch dimension ((n_branches * n) rows): the descriptors, split per branch"""
+        out = self._head_only(f)
+        n = out.size(0) // n_branches
+        return tuple(out[i * n:(i + 1) * n] for i in range(n_branches))
+
     def forward_features(self, f1, f2=None, f3=None):
         """forward() of training mode on precomputed prefix features: the branches go through suffix + head together, exactly as forward()
         sends them through the whole net together (same rows in the same batch: same bits)."""

@@ -112,7 +112,7 @@ class _Stepper(object):
     def _precompute(self, local, n_leaves, batch_args):
         """Frozen trunk prefix: ONE batch construction for the whole local slice (same image order as micro-batch by micro-batch) and one
         prefix launch; the micro-batches then run suffix + head on their rows of the features."""
-        if not (getattr(self.P, 'train_trunk_per_minibatch', True) and n_leaves > 1 and getattr(self.net, 'trunk_precomputable', lambda: False)()):
+        if not (getattr(self.P, 'train_trunk_per_minibatch', True) and n_leaves >= 1 and getattr(self.net, 'trunk_precomputable', lambda: False)()):
             return None
         rng_state = random.getstate()
         inputs, targets = self.make_batch(local, len(local), **batch_args)
@@ -121,6 +121,40 @@ class _Stepper(object):
             random.setstate(rng_state)
             return None
         return feats, targets
+
+    def _leaves_batched(self, eng, mine, offsets, mini_size, pre):
+        """All local micro-batches through the trainable trunk suffix in ONE forward and ONE backward of the libisx engine (isx/suffix.py),
+        their gradients kept apart: the head (host-bound: ~40 small launches) still runs micro-batch by micro-batch on its rows of the suffix
+        output, the engine's kernels see 8 x the rows.  Every row is computed exactly as in a launch of its own and the weight-gradient
+        kernel restarts its pixel sum at every micro-batch, so each leaf's flat gradient is bit for bit the per-leaf path's -- and the
+        P-rank run's.  Returns (flat_all (L, total), losses)."""
+        P = self.P
+        feats, targets_all = pre
+        nb, k, L = len(feats), len(mine[0]), len(mine)
+        x_all = torch.cat([f[o:o + k] for o in offsets for f in feats], 0)          # leaf-major: [a_0; p_0; n_0; a_1; ...]
+        y_all, saved = eng.forward(x_all)                                            # no graph: the engine's backward is driven by hand below
+        dy_all = torch.empty_like(y_all)
+        flat = self.flat.flat
+        flat_all = torch.zeros((L, flat.numel()), dtype=flat.dtype, device=flat.device)
+        rows, losses = nb * k, []
+        for j in range(L):
+            z = y_all[j * rows:(j + 1) * rows].detach().requires_grad_(True)
+            out = self.net.head_rows(z, nb)
+            o = offsets[j]
+            targets = [t[o:o + k] if torch.is_tensor(t) and t.dim() > 0 and t.size(0) == feats[0].size(0) else t for t in targets_all]
+            loss, loss2 = self.make_loss(out, targets)
+            share = k / float(mini_size)
+            obj = loss * share if P.train_loss_avg else loss
+            if loss2 is not None:
+                obj = obj + P.train_loss2_alpha * (loss2 * share if P.train_loss2_avg else loss2)
+            obj.backward()
+            losses.append(obj.detach().reshape(-1)[0])
+            dy_all[j * rows:(j + 1) * rows].copy_(z.grad)
+            self.flat.attach_all()
+            flat_all[j].copy_(flat)                                                  # the head's small parameters; the suffix slots are still zero
+            flat.zero_()
+        eng.backward(saved, dy_all, leaves=L, leaf_grads=(flat_all, self.flat.slices))
+        return flat_all, losses
 
     def step(self, optimizer, mini_batch, batch_args):
         from isx import dp
@@ -140,7 +174,15 @@ class _Stepper(object):
         self.flat.zero_grad()
         losses = []
         with dp.RowSink(self.deferred) as sink:
-            if self.mode == 'tree':
+            eng = None
+            if self.mode == 'tree' and pre is not None and len(set(len(l) for l in mine)) == 1 and getattr(self.P, 'train_suffix_batched', True):
+                eng = getattr(self.net, 'suffix_engine', lambda: None)()
+            if eng is not None:
+                flat_all, losses = self._leaves_batched(eng, mine, offsets, n, pre)
+                self.flat.put(dp.tree_sum(lo, hi, lambda i: flat_all[i - lo]))
+                if self.exchange is not None:
+                    self.exchange.allreduce_(self.flat.flat)
+            elif self.mode == 'tree':
                 def leaf(i):
                     losses.append(self._forward_backward(mine[i - lo], offsets[i - lo], n, batch_args, pre))
                     return self.flat.take()

@@ -470,7 +470,7 @@ def test_untrained_blocks_follow_the_reference_table():
     assert first_trainable(frozen.features) == len(frozen.features)
 
 
-def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch, micro, mined, replay):
+def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch, micro, mined, replay, batched=True):
     """One run of train.siamese_descriptor.main on the reference configuration (ResNet-50, untrained_blocks from the table).  `mined`:
     list receiving the mined negatives per epoch; `replay`: a previous run's list to use instead of mining."""
     import copy
@@ -494,6 +494,7 @@ def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch,
         P.train_epochs, P.train_batch_size, P.train_micro_batch, P.test_batch_size = epochs, batch, micro, 16
         P.train_loss_int, P.train_epoch_switch, P.train_lr, P.train_pre_proc = 1000, 1, 1e-3, True
         P.untrained_blocks = None                                  # the reference's table: 15 for ResNet-50
+        P.train_suffix_batched = batched
         assert P.untrained_blocks == 15
         torch.manual_seed(0); random.seed(0)
         init = {k: v.detach().clone() for k, v in sd.get_siamese_net().state_dict().items()}
@@ -537,8 +538,8 @@ def test_reference_config_one_step_matches_plain_torch_training():
     torch run (whole trunk = features(x) under autograd, MIOpen).  After ONE optimizer step (6 micro-batches accumulated, SGD with momentum
     and weight decay) every weight agrees to <= 1e-6 of its tensor's scale."""
     mined = []
-    init, a = _train_reference_config(True, True, 1, 8, 24, 4, mined, None)
-    _, b = _train_reference_config(False, False, 1, 8, 24, 4, None, mined)
+    init, a = _train_reference_config(True, True, 1, 16, 48, 8, mined, None)     # 16 images, 4 labels: 48 ordered positive couples = ONE mini-batch of 6 micro-batches
+    _, b = _train_reference_config(False, False, 1, 16, 48, 8, None, mined)
     worst, name, moved4, moved_head = _weight_deviation(a, b, init)
     print("reference config, one step, HIP prefix + suffix engine vs plain torch: max |dw| / scale = %.3g (%s); layer4 moved %.3g, head moved %.3g"
           % (worst, name, moved4, moved_head))
@@ -563,3 +564,20 @@ def test_reference_config_two_epochs_track_plain_torch_training():
           "head moved %.3g" % (worst, name, worst_plain, name_plain, moved4, moved_head))
     assert moved4 > 0 and moved_head > 0
     assert worst <= 1e-2
+
+
+@pytest.mark.gpu
+def test_batched_suffix_is_bit_identical_to_leaf_by_leaf():
+    """utils/train_general._Stepper._leaves_batched: all micro-batches of a step through the suffix engine in ONE forward / backward, their
+    gradients kept apart, against the same engine driven micro-batch by micro-batch (what a rank of an 8-GPU run does with its single leaf).
+    Two epochs of SGD on the reference configuration (NO replay of mined negatives: the runs must not differ at all): every tensor of the
+    state dict bit-identical -- the property that makes the update independent of the number of ranks."""
+    mined = []
+    init, a = _train_reference_config(True, True, 2, 32, 12, 4, mined, None, batched=True)
+    _, b = _train_reference_config(True, True, 2, 32, 12, 4, [], None, batched=False)
+    moved = 0.0
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k].float() - b[k].float()).abs().max()))
+        if a[k].dtype.is_floating_point:
+            moved = max(moved, float((a[k] - init[k].to(a[k].device)).abs().max()))
+    assert moved > 0
