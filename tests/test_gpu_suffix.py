@@ -157,8 +157,20 @@ def test_backward_kernels_vs_torch():
         assert S >= 1
         dw, dbp = torch.empty(S, Co, taps, Ci, device="cuda"), torch.empty(S, Co, device="cuda")
         dzc = dz_.permute(0, 2, 3, 1).contiguous()
-        check(L.isx_conv_wgrad_nhwc(dzc.data_ptr(), x.permute(0, 2, 3, 1).contiguous().data_ptr(), B, H, W, Ci, Co, taps, stride, dw.data_ptr(), dbp.data_ptr(), st), "x")
+        xc = x.permute(0, 2, 3, 1).contiguous()
+        check(L.isx_conv_wgrad_nhwc(dzc.data_ptr(), xc.data_ptr(), B, 1, H, W, Ci, Co, taps, stride, dw.data_ptr(), dbp.data_ptr(), st), "x")
         got = dw.sum(0).view(Co, k, k, Ci).permute(0, 3, 1, 2)
+        if B % 2 == 0:                                           # two leaves in one launch: each leaf's partials are the bits of a launch of its own
+            S2 = L.isx_conv_wgrad_splits(out.shape[0] // 2 * out.shape[2] * out.shape[3], Ci, Co, taps)
+            both, dbb2 = torch.empty(2, S2, Co, taps, Ci, device="cuda"), torch.empty(2, S2, Co, device="cuda")
+            check(L.isx_conv_wgrad_nhwc(dzc.data_ptr(), xc.data_ptr(), B, 2, H, W, Ci, Co, taps, stride, both.data_ptr(), dbb2.data_ptr(), st), "x")
+            for l in range(2):
+                one, db1 = torch.empty(1, S2, Co, taps, Ci, device="cuda"), torch.empty(1, S2, Co, device="cuda")
+                h = B // 2
+                check(L.isx_conv_wgrad_nhwc(dzc[l * h:(l + 1) * h].contiguous().data_ptr(), xc[l * h:(l + 1) * h].contiguous().data_ptr(), h, 1, H, W, Ci, Co, taps,
+                                            stride, one.data_ptr(), db1.data_ptr(), st), "x")
+                assert torch.equal(one[0], both[l]) and torch.equal(db1[0], dbb2[l]), (taps, stride, l)
+            assert _rel(both.sum((0, 1)).view(Co, k, k, Ci).permute(0, 3, 1, 2), gw) <= 2e-5
         assert _rel(got, gw) <= 2e-5, (taps, stride, S, _rel(got, gw))
         assert _rel(dbp.sum(0).double(), dzc.double().sum((0, 1, 2))) <= 1e-5, (taps, stride, S)
         if taps == 9:                                           # 3x3 dgrad (with mask) against torch
@@ -187,6 +199,6 @@ def test_backward_kernels_vs_torch():
     gw, gg, gb = torch.ones_like(w), torch.ones_like(gam), torch.ones_like(bet)      # accumulate into ones
     parts = torch.stack([0.25 * dwp, 0.5 * dwp, 0.25 * dwp]).contiguous()             # three partials that add up to dwp (exactly: powers of two)
     dparts = torch.stack([0.5 * dbb, 0.25 * dbb, 0.25 * dbb]).contiguous()
-    check(L.isx_bn_fold_backward(parts.data_ptr(), dparts.data_ptr(), 3, w.detach().data_ptr(), s.detach().contiguous().data_ptr(), mean.data_ptr(),
-                                 istd.data_ptr(), Co, Ci, taps, 1, gw.data_ptr(), gg.data_ptr(), gb.data_ptr(), st), "x")
+    check(L.isx_bn_fold_backward(parts.data_ptr(), dparts.data_ptr(), 1, 3, w.detach().data_ptr(), s.detach().contiguous().data_ptr(), mean.data_ptr(),
+                                 istd.data_ptr(), Co, Ci, taps, 1, 0, gw.data_ptr(), gg.data_ptr(), gb.data_ptr(), st), "x")
     assert _rel(gw - 1, w.grad) <= 1e-5 and _rel(gg - 1, gam.grad) <= 1e-4 and _rel(gb - 1, bet.grad) <= 1e-6
