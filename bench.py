@@ -76,6 +76,8 @@ def parse():
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1: keep the search stage of a step (query all-gather, GEMM, top-k, result exchange) on the main stream "
                          "(default: on a second stream behind the next step's trunk)")
+    ap.add_argument("--ingest-images", type=int, default=65536,
+                    help="images of the non-resident streaming-ingest side measurement (0 = skip); host memory: 4096 distinct uint8 images, the rest views")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -284,6 +286,10 @@ def compact_line(full, detail_file=None):
                                                                               "cosine_sim_frac_of_f32_mfma_peak", "mAP"))
         c["workload"] = "BASELINE configs[2]: ResNet-50 TuneClassifSub @448x448 -> best-location descriptors"
         line["extraction_regions"] = c
+    ig = full.get("ingest_streaming")
+    if isinstance(ig, dict):
+        line["ingest_streaming"] = _pick(ig, ("error", "images", "resident_images_per_s", "extract_pcie_inclusive_images_per_s", "streamed_over_resident",
+                                              "descriptors_identical"))
     if "exchange_ms" in full:
         line["exchange_ms"] = full["exchange_ms"]
         line["exchange"] = _pick(full.get("exchange") or {}, ("query_allgather_ms", "result_allgather_merge_ms", "exposed_when_serialised_frac_of_step",
@@ -301,7 +307,7 @@ def compact_line(full, detail_file=None):
     for key in ("value", "ms_per_step", "dist_per_s"):          # the contract's scalars keep their digits
         if key in full:
             line[key] = full[key]
-    for victim in ("families", "exchange", "extraction_regions", "retrieval_shard", "roofline_step"):      # never expected: a safety net
+    for victim in ("families", "ingest_streaming", "exchange", "extraction_regions", "retrieval_shard", "roofline_step"):      # never expected: a safety net
         if len(json.dumps(line)) <= MAX_LINE_BYTES:
             break
         line.pop(victim, None)
@@ -667,6 +673,53 @@ def main():
                 shard_result = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
 
+    # side measurement: PCIe-inclusive extraction of a set that is NOT resident in HBM (train/_common.BatchStager: two pinned
+    # buffers + a copy stream, batch i + 1 stacked and copied while batch i runs) against the same set resident -- rank 0 only, no collective
+    ingest_result = None
+
+    def ingest_bench():
+        from train import _common as TC
+        from train import classif_finetune as cf
+        n, blk = args.ingest_images, 4096
+        gi = torch.Generator().manual_seed(7)
+        block = torch.randint(0, 256, (min(blk, n), 224, 224, 3), dtype=torch.uint8, generator=gi)      # decoded RGB images as the raw ingest carries them
+        data = [(block[i % block.size(0)], "l%d" % (i % 100), "p%d" % i) for i in range(n)]              # n per-image host tensors (the reference's dataset form)
+        P = cf.P
+        saved, budget = dict(P.__dict__), TC.RESIDENT_BUDGET_BYTES
+        TC.RAW_INGEST["mean"], TC.RAW_INGEST["std"] = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+        try:
+            P.cuda_device, P.embeddings_classify, P.embeddings_fc7, P.test_pre_proc, P.test_batch_size = local, False, False, True, 64
+
+            def timed_pass():
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                slab = cf.get_embeddings(net, data, local, 2048)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0_, slab
+            TC.drop_resident()
+            t_up, _ = timed_pass()                      # uploads the set (one-time) + extracts
+            t_res, slab_res = timed_pass()              # resident: batches are device-side row gathers
+            TC.drop_resident()
+            TC.RESIDENT_BUDGET_BYTES = 0                # nothing may stay in HBM: every batch crosses PCIe
+            t_str, slab_str = timed_pass()
+            same = bool(torch.equal(slab_res, slab_str))
+        finally:
+            TC.drop_resident()
+            TC.RESIDENT_BUDGET_BYTES = budget
+            TC.RAW_INGEST["mean"] = TC.RAW_INGEST["std"] = None
+            P.__dict__.clear(); P.__dict__.update(saved)
+        return {"images": n, "image_bytes": 224 * 224 * 3, "ingest": "uint8 (H,W,3) host tensors, normalised on the device (isx_images_u8_to_f32)",
+                "resident_images_per_s": n / t_res, "extract_pcie_inclusive_images_per_s": n / t_str, "streamed_over_resident": t_res / t_str,
+                "first_pass_with_upload_images_per_s": n / t_up, "descriptors_identical": same,
+                "path": "train.classif_finetune.get_embeddings -> train._common.BatchStager (2 pinned buffers, copy stream, look-ahead 1)"}
+
+    if args.ingest_images > 0 and rank == 0 and args.backbone_dtype == "f32" and not args.no_fold_bn:
+        try:
+            ingest_result = ingest_bench()
+        except Exception as e:
+            ingest_result = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
     regions_result = None
     if not args.no_regions_bench:
         try:
@@ -783,6 +836,8 @@ def main():
             line["retrieval_shard"] = shard_result
         if regions_result is not None:
             line["extraction_regions"] = regions_result
+        if ingest_result is not None:
+            line["ingest_streaming"] = ingest_result
         if world > 1:
             ex = exchange_legs or {}
             tot = sum(ex.values()) if ex else None

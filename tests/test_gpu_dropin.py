@@ -300,16 +300,20 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "32",
-           "--gallery", "2000", "--cpu-seconds", "2", "--no-shard-bench", "--no-regions-bench"]
+           "--gallery", "2000", "--cpu-seconds", "2", "--no-shard-bench", "--no-regions-bench", "--ingest-images", "0"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1                                     # rank 0 only
-    d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 2
+    assert len(lines) == 2                                     # rank 0 only: the full record, then the driver's compact line (LAST on stdout)
+    assert out.stdout.rstrip().splitlines()[-1] == lines[1] and len(lines[1]) <= 6144
+    full = json.loads(lines[0])["bench_detail"]
+    d = json.loads(lines[1])
+    assert json.loads(json.dumps(d)) == d
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and d["steps"] == 2 and d["value"] == full["value"]
     assert d["config"]["gallery_rows_per_gpu"] == 2000 and d["config"]["ranks"] == 2 and d["config"]["collective_backend"] == "gloo"
-    assert d["roofline"] is not None and d["roofline"]["frac"] > 0 and "roofline_cosine_gemm" in d and "roofline_step" in d
-    assert d["roofline_cosine_gemm"]["shape"] == [64, 2000, 2048]          # the gathered query block of both ranks
+    assert d["roofline"] is not None and d["roofline"]["frac"] > 0 and "roofline_step" in d and "cosine_gemm" in d["families"]["rows"]
+    assert full["roofline_cosine_gemm"]["shape"] == [64, 2000, 2048]       # the gathered query block of both ranks
+    assert os.path.exists(os.path.join(root, d["detail_file"]))
     # round 3: the N > 1 line is complete -- the CPU path timed in the same run (rank 0), the exchange legs priced with nothing hiding
     # them, and the result exchange riding behind the next step's trunk on a second stream returns the bits of the in-line schedule
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
@@ -318,7 +322,7 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     # the serialised schedule stays available and prints the same fields
     out2 = subprocess.run(cmd + ["--no-overlap-exchange", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out2.returncode == 0, out2.stderr[-2000:]
-    d2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][0])
+    d2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][-1])
     assert d2["exchange"]["overlapped"] is False and d2["exchange"]["overlap_identical"] is True and "cpu_baseline" not in d2
 
 

@@ -119,20 +119,44 @@ def _check(res_gpu, res_cpu, emb_gpu, emb_cpu, labs, what, cos_tol=COS_TOL):
             bad += 1
     print("%s: %d of %d top-%d positions differ, %d beyond 2 x max|dcos|" % (what, swaps, rank_c.numel(), kk, bad))
     assert bad == 0, "%s: %d ranked positions differ beyond the arithmetic's resolution" % (what, bad)
-    if bool((top_g == top_c).all()):
+    # P@1: every top-1 flip was shown above to lie inside the arithmetic's resolution.  A flip can only move P@1 when the two gallery items
+    # carry different labels: P@1 must be EQUAL unless such a flip exists, and then differ by at most that many queries.
+    flips = (top_g != top_c).nonzero().flatten().tolist()
+    label_flips = sum(1 for q in flips if gl[int(top_g[q])] != gl[int(top_c[q])])
+    print("%s: %d of %d queries rank another gallery item first (all inside 2 x max|dcos|), %d of them across labels" % (what, len(flips), len(ql), label_flips))
+    if label_flips == 0:
         assert res_gpu[0] == res_cpu[0], "%s: P@1 %r vs %r" % (what, res_gpu[0], res_cpu[0])
+    else:
+        assert abs(res_gpu[0] - res_cpu[0]) <= label_flips / float(len(ql)) + 1e-12, "%s: P@1 %r vs %r with %d label flips" % (what, res_gpu[0], res_cpu[0], label_flips)
     assert abs(res_gpu[1] - res_cpu[1]) <= MAP_TOL, "%s: mAP %r vs %r" % (what, res_gpu[1], res_cpu[1])
     assert 0.0 < res_cpu[1] <= 1.0
 
 
+ARBITER_RATIO = 1.6     # the HIP path may sit at most this much further from a float64 evaluation than the reference's fp32 CPU path does (measured: 1.5)
+
+
+def _arbiter(arch, w, n_labels, spec, r):
+    """max|cos - cos_f64| of the HIP path and of the torch-CPU fp32 path, against the same net evaluated in float64"""
+    (qg, gg), (qc, gc) = r[2], r[3]
+    q64, g64 = _fp64_descriptors(arch, w, n_labels, spec)
+    cos64 = q64 @ g64.t()
+    e_gpu = float(((qg.double() @ gg.double().t()) - cos64).abs().max())
+    e_cpu = float(((qc.double() @ gc.double().t()) - cos64).abs().max())
+    return e_gpu, e_cpu
+
+
 def test_classif_finetune_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
-    """BASELINE configs[1] end to end: ResNet-50 global descriptors."""
+    """BASELINE configs[1] end to end: ResNet-50 global descriptors, 200 queries x 1000 gallery images, with the float64 arbiter: the k-ordered
+    fp32 fma chains of the HIP trunk (K up to 4608) may not drift further from float64 than ARBITER_RATIO x the reference's own fp32 CPU path."""
     from test import classif_finetune_test as T
-    w = _calibrated_weights("classif", 20, str(tmp_path / "w.pth"))
-    spec = "synthetic:CLICIDE_video_224sq:n=200:q=40:labels=20:struct=70"
+    w = _calibrated_weights("classif", 50, str(tmp_path / "w.pth"))
+    spec = "synthetic:CLICIDE_video_224sq:n=1000:q=200:labels=50:struct=70"
     r = _run(T.main, (spec, "resnet50", w, 0, False, 64, 0), (spec, "resnet50", w, -1, False, 64, 0), monkeypatch)
+    e_gpu, e_cpu = _arbiter("resnet50", w, 50, spec, r)
     with capsys.disabled():
-        _check(*r, what="classif_finetune_test resnet50")
+        print("resnet50: max|cos - cos_f64|: HIP path %.3g, torch-CPU fp32 path %.3g (ratio %.2f)" % (e_gpu, e_cpu, e_gpu / e_cpu))
+        _check(*r, what="classif_finetune_test resnet50 200 x 1000")
+    assert e_gpu <= COS_TOL and e_gpu <= ARBITER_RATIO * e_cpu, "HIP path is %.3g from the float64 result, the CPU fp32 path %.3g" % (e_gpu, e_cpu)
 
 
 def test_classif_finetune_main_classify_scores_gpu_vs_cpu(monkeypatch, capsys):
@@ -149,20 +173,20 @@ def test_classif_regions_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
     from test import classif_regions_test as T
     from train import classif_regions as cr
     monkeypatch.setattr(cr.P, "test_batch_size", 16)
-    w = _calibrated_weights("classif_sub", 10, str(tmp_path / "w.pth"))
-    spec = "synthetic:CLICIDE_video_224sq:n=60:q=20:labels=10:size=448:struct=70"
+    w = _calibrated_weights("classif_sub", 30, str(tmp_path / "w.pth"))
+    spec = "synthetic:CLICIDE_video_224sq:n=300:q=100:labels=30:size=448:struct=70"
     r = _run(T.main, (spec, "resnet50", w, 0, 0), (spec, "resnet50", w, -1, 0), monkeypatch)
     with capsys.disabled():
-        _check(*r, what="classif_regions_test resnet50 @448")
+        _check(*r, what="classif_regions_test resnet50 @448 100 x 300")
 
 
 def test_siamese_descriptor_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
     from test import siamese_descriptor_test as T
-    w = _calibrated_weights("descriptor", 12, str(tmp_path / "w.pth"), feature_dim=256)
-    spec = "synthetic:CLICIDE_video_224sq:n=120:q=30:labels=12:struct=70"
+    w = _calibrated_weights("descriptor", 50, str(tmp_path / "w.pth"), feature_dim=256)
+    spec = "synthetic:CLICIDE_video_224sq:n=1000:q=200:labels=50:struct=70"
     r = _run(T.main, (spec, "resnet50", w, 0, 256, 32, 0), (spec, "resnet50", w, -1, 256, 32, 0), monkeypatch)
     with capsys.disabled():
-        _check(*r, what="siamese_descriptor_test resnet50")
+        _check(*r, what="siamese_descriptor_test resnet50 200 x 1000")
 
 
 def test_siamese_regions_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
@@ -192,8 +216,11 @@ def _fp64_descriptors(arch, weights, n_labels, spec):
         out = []
         with torch.no_grad():
             for ds in (qs, rs):
-                p = net.features(torch.stack([t for t, _, _ in ds]).double().cuda()).mean((2, 3))
-                out.append((p / (p.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()).cpu())
+                rows = []
+                for i in range(0, len(ds), 100):
+                    p = net.features(torch.stack([t for t, _, _ in ds[i:i + 100]]).double().cuda()).mean((2, 3))
+                    rows.append((p / (p.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()).cpu())
+                out.append(torch.cat(rows, 0))
     finally:
         torch.backends.cudnn.enabled = was
     return out
@@ -204,22 +231,18 @@ def test_classif_finetune_main_resnet152_gpu_vs_cpu(monkeypatch, capsys, tmp_pat
     global descriptors through `--device=0` (36-block stage 3: the tile picker / tail split decide most launches) against `--device=-1`.
     P@1, ranked lists and mAP (1e-4) are held to the same asserts as ResNet-50.  Cosine scores: on this seeded random-init network
     (50 residual blocks amplify every rounding) the reference's OWN fp32 CPU path is ~1.3e-5 away from a float64 evaluation of the same
-    weights, so no fp32 implementation can be held to 1e-5 against it; the assert is instead that the HIP path stays within twice the
-    CPU path's own distance from the float64 result (measured: 2.0e-5 vs 1.3e-5; ResNet-50: 7.5e-7 vs 5.0e-7, under 1e-5 as asserted
-    in the ResNet-50 tests)."""
+    weights, so no fp32 implementation can be held to 1e-5 against it; the assert is instead that the HIP path stays within ARBITER_RATIO x the
+    CPU path's own distance from the float64 result (measured: 1.9e-5 vs 1.3e-5; ResNet-50: 7.5e-7 vs 5.0e-7, under 1e-5 and held to the same
+    ratio in test_classif_finetune_main_gpu_vs_cpu)."""
     from test import classif_finetune_test as T
     w = _calibrated_weights("classif", 10, str(tmp_path / "w.pth"), arch="resnet152")
     spec = "synthetic:CLICIDE_video_224sq:n=60:q=20:labels=10:struct=70"
     r = _run(T.main, (spec, "resnet152", w, 0, False, 64, 0), (spec, "resnet152", w, -1, False, 64, 0), monkeypatch)
-    (qg, gg), (qc, gc) = r[2], r[3]
-    q64, g64 = _fp64_descriptors("resnet152", w, 10, spec)
-    cos64 = q64 @ g64.t()
-    e_gpu = float(((qg.double() @ gg.double().t()) - cos64).abs().max())
-    e_cpu = float(((qc.double() @ gc.double().t()) - cos64).abs().max())
+    e_gpu, e_cpu = _arbiter("resnet152", w, 10, spec, r)
     with capsys.disabled():
-        print("resnet152: max|cos - cos_f64|: HIP path %.3g, torch-CPU fp32 path %.3g" % (e_gpu, e_cpu))
+        print("resnet152: max|cos - cos_f64|: HIP path %.3g, torch-CPU fp32 path %.3g (ratio %.2f)" % (e_gpu, e_cpu, e_gpu / e_cpu))
         _check(*r, what="classif_finetune_test resnet152", cos_tol=max(COS_TOL, e_gpu + e_cpu))
-    assert e_gpu <= max(COS_TOL, 2.0 * e_cpu), "HIP path is %.3g from the float64 result, the CPU fp32 path %.3g" % (e_gpu, e_cpu)
+    assert e_gpu <= max(COS_TOL, ARBITER_RATIO * e_cpu), "HIP path is %.3g from the float64 result, the CPU fp32 path %.3g" % (e_gpu, e_cpu)
 
 
 def test_classif_finetune_main_fc7_gpu_vs_cpu(monkeypatch, capsys):
