@@ -42,6 +42,15 @@ def _parallel_stack(chunk, out):
     """out[:len(chunk)] = stack(chunk): the copy is one memcpy per image, spread over a few threads (torch releases the GIL inside)."""
     global _STACK_POOL
     k = len(chunk)
+    first = chunk[0]
+    if first.dtype == torch.uint8 and first.numel() % 8 == 0:
+        # decoded uint8 images (the raw ingest): torch's byte-wise copy loop moves ~1.9 GB/s (40 ms per 512 images of 224 x 224 x 3: more than
+        # the trunk needs for them); the same bytes viewed as int64 words go at memcpy speed (15 ms, per-tensor overhead included)
+        try:
+            torch.stack([im.reshape(-1).view(torch.int64) for im in chunk], 0, out=out[:k].view(k, -1).view(torch.int64))
+            return
+        except RuntimeError:
+            pass                                    # unaligned storage offset / non-contiguous image: the plain path below
     workers = min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     if workers <= 1 or k < 64:
         torch.stack(chunk, 0, out=out[:k])
