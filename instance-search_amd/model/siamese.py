@@ -205,6 +205,24 @@ class _SplitTrunk(object):
         f, split = self.prefix(features, x)
         return self.suffix(features, f, split)
 
+    def inference(self, features, x):
+        """Eval-mode forward WITHOUT a graph (the embedding pass of every training epoch, the evaluation between epochs): frozen prefix on its
+        cached folded copy, the trainable suffix on a folded copy re-derived when its weights change (once per epoch) -- the whole trunk in
+        libisx, as after train._common.prepare_for_inference, without MIOpen's per-shape kernel search on the first pass of a training run."""
+        if (torch.is_grad_enabled() or not SPLIT_TRUNK or not (x.is_cuda and x.dtype == torch.float32) or _bn_training(features)
+                or not any(isinstance(m, nn.BatchNorm2d) for m in features.modules())):
+            return features(x)
+        f, split = self.prefix(features, x) if first_trainable(features) > 0 else (x, 0)
+        mods = list(features)[split:]
+        if not mods:
+            return f
+        key = (id(features), str(x.device), split,
+               tuple((id(t), t._version) for m in mods for t in m.parameters()), tuple((id(t), t._version) for m in mods for t in m.buffers()))
+        if getattr(self, "_tail", None) is None or self._tail[0] != key:
+            from .nn_utils import fold_batch_norm
+            self._tail = (key, fold_batch_norm(nn.Sequential(*mods)).to(x.device).to(memory_format=torch.channels_last))
+        return self._tail[1](f)
+
 
 def _bn_training(features):
     return any(isinstance(m, nn.BatchNorm2d) and m.training for m in features.modules())
@@ -246,7 +264,7 @@ class DescriptorNet(nn.Module):
         self._trunk = _SplitTrunk()
 
     def forward_single(self, x):
-        x = self._trunk(self.features, x) if self.training else self.features(x)
+        x = self._trunk(self.features, x) if self.training else self._trunk.inference(self.features, x)
         x = x.reshape(x.size(0), -1)
         return self.feature_reduc2(_apply_head(self.feature_reduc1, x))
 

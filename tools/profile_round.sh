@@ -48,7 +48,7 @@ with open("$OUT/summaries/${TAG}_train_kernel_stats.csv", "w") as o:
     for r in rows[:60]:
         w.writerow([r.get("Name")[:160], r.get("Calls"), float(r.get("TotalDurationNs", 0)) / 1e3, float(r.get("AverageNs", 0)) / 1e3, r.get("Percentage")])
 PY
-tail -1 $OUT/train.log > $OUT/summaries/${TAG}_bench_train.json
+grep '^{' $OUT/train.log | tail -1 > $OUT/summaries/${TAG}_bench_train.json
 cp $OUT/bench_detail_full.json $OUT/summaries/${TAG}_bench_detail.json 2>/dev/null || true
 tail -1 $OUT/bench_line.json > $OUT/summaries/${TAG}_bench_line.json
 rm -rf $OUT/stats $OUT/regions $OUT/fetch $OUT/write $OUT/mfma $OUT/rfetch $OUT/rwrite $OUT/train
