@@ -17,17 +17,18 @@ struct Conv3x3Geom { int H, W, Cin, Ho, Wo, stride; };
 // lds: BK * (64 TM + 64 TN + 2 pads) floats
 // AHEAD2 (64x64 tiles only): operands requested two k-tiles ahead instead of one (16 more VGPRs: the fused expand kernel has them, the plain
 // 64x64 kernel at six workgroups per CU does not).
-template <int TM, int TN, int BK, bool AHEAD2 = false>
+// WM: waves along M (2: the 2x2 arrangement of every other kernel; 4: four waves stacked along the pixels, each TM x TN tiles of the FULL width)
+template <int TM, int TN, int BK, bool AHEAD2 = false, int WM = 2>
 __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
                                                  const Conv3x3Geom& g, int64_t m0, int64_t n0, f32x16 (&acc)[TM][TN]) {
-    constexpr int BM = 64 * TM, BN = 64 * TN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
+    constexpr int WN = 4 / WM, BM = 32 * TM * WM, BN = 32 * TN * WN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
     constexpr int CH = BK / 4, NA = BM * CH / 256;
     float* As = lds;
     float* Bs = lds + BK * LDA;
     const int D = 9 * g.Cin;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
 #pragma unroll

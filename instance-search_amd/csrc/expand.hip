@@ -3,6 +3,8 @@
 // (-0.3 ms each on the bench) and costs this kernel 4 % (Makefile).
 // Reference call sites: the torchvision ResNet `features` trunk built by model/ModelDefinition.py, split by model/nn_utils.py:56-71 and run from
 // model/siamese.py:20,107,151.
+#include <stdlib.h>
+
 #include "expand_kernel.hpp"
 
 using namespace isx;
@@ -26,6 +28,16 @@ ISX_API int isx_conv3x3_expand_nhwc(const float* x, int64_t B, int H, int W, int
     g.Wo = (W - 1) / stride + 1;
     const int64_t M = B * g.Ho * g.Wo;
     ISX_REQUIRE((M + 63) / 64 < (1ll << 31), "isx_conv3x3_expand_nhwc: too many tiles");
+    // ISX_EXPAND_TILE=256: the 256-pixel variant (four independent accumulators per wave in the 3x3 loop, round 4).  Bit-identical results; measured
+    // 5 % SLOWER on the two identity-shortcut launches of the bench step (10.38 vs 10.02 ms for the family): at two workgroups per CU the HBM-heavy
+    // epilogue (7.4 GB per launch) finds too few waves to hide behind, and the family already sits at busy x clock = 0.84 x 2.17 / 2.4 = 0.76 of nominal.
+    static const int forced = [] { const char* e = getenv("ISX_EXPAND_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 256) {
+        hipLaunchKernelGGL((conv3x3_expand256_kernel<4>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, M, w2_ohwi, g, b2, w3t, b3, residual,
+                           relu ? 1 : 0, y);
+        ISX_CHECK_LAUNCH("isx_conv3x3_expand_nhwc");
+        return ISX_OK;
+    }
     hipLaunchKernelGGL((conv3x3_expand_kernel<4, false>), dim3((unsigned)((M + 63) / 64)), dim3(256), 0, (hipStream_t)stream, x, M, w2_ohwi, g, b2, w3t, b3, residual,
                        relu ? 1 : 0, y);
     ISX_CHECK_LAUNCH("isx_conv3x3_expand_nhwc");

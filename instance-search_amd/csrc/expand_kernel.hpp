@@ -94,4 +94,65 @@ __global__ __launch_bounds__(256, 4) void conv3x3_expand_kernel(const float* __r
     if (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(4); }
 }
 
+// ---- the same fusion on a 256-PIXEL tile (round 4) ------------------------------------------------------------------------------
+// The 64-pixel kernel above gives every wave ONE accumulator in the 3x3 loop: all its MFMAs depend on each other and the matrix pipe is fed
+// by wave switches (0.84 busy; the kernels with four independent accumulators per wave reach 0.90).  Here the four waves are stacked along the
+// pixels: wave w owns pixels 64 w .. 64 w + 63 of the tile and ALL 64 mid channels = 2 x 2 independent accumulator tiles, the weight k-tile in
+// the LDS is shared by the four waves (a quarter of the B traffic per MFMA).  A wave's mid tile is exactly the A operand of ITS OWN rows of the
+// expansion, so it goes to a wave-private LDS region and the 1x1 expansion needs no workgroup barrier: four passes of 64 output channels, 2 x 2
+// accumulators each, the epilogue of pass p in flight while other waves run their MFMAs.  Same fma chain per output element as the 64-pixel
+// kernel (and as conv3x3 followed by conv1x1).  LDS: max(operand stages 41 KB, four mid tiles 66.6 KB): two workgroups per CU.
+template <int TN2>
+__global__ __launch_bounds__(256, 2) void conv3x3_expand256_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ W2, Conv3x3Geom g,
+                                                                   const float* __restrict__ b2, const float* __restrict__ W3t, const float* __restrict__ b3,
+                                                                   const float* __restrict__ res, int relu, float* __restrict__ y) {
+    constexpr int COUT = 64 * TN2, LDY = 64 + 1, STAGES_F = 32 * (256 + 64 + 2 * lds_pad(32)), MID_F = 4 * 64 * LDY;
+    __shared__ float lds[STAGES_F > MID_F ? STAGES_F : MID_F];
+    const int nwg = (int)gridDim.x, b = (int)blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int64_t m0 = (int64_t)((xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3)) * 256;
+
+    f32x16 acc[2][2];
+    conv3x3_mainloop<2, 2, 32, false, 4>(lds, x, M, W2, 64, g, m0, 0, acc);          // every wave has left the operand stages when this returns
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float* mid = lds + wave_u * (64 * LDY);                                          // this wave's Y[k = mid channel][pixel], K-major
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float bv = b2[j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                mid[(j * 32 + l31) * LDY + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half] = fmaxf(acc[i][j][e] + bv, 0.0f);
+    }
+    __syncthreads();                                                                 // (only the wave's own region is read below; one cheap barrier keeps the LDS ordering explicit)
+
+    const float* a_base = mid + half * LDY + l31;
+    const auto wr = uniform_rsrc(W3t, (int64_t)64 * COUT * 4);
+    const unsigned wvo = (unsigned)((half * COUT + l31) * 4);
+#pragma unroll 1
+    for (int p = 0; p < COUT / 64; ++p) {
+        f32x16 acc2[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc2[i][j][e] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            const float a0 = a_base[2 * s * LDY], a1 = a_base[2 * s * LDY + 32];
+            const float q0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, wvo, (unsigned)((2 * s * COUT + p * 64) * 4), 0));
+            const float q1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, wvo, (unsigned)((2 * s * COUT + p * 64 + 32) * 4), 0));
+            acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q0, acc2[0][0], 0, 0, 0);
+            acc2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q1, acc2[0][1], 0, 0, 0);
+            acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q0, acc2[1][0], 0, 0, 0);
+            acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q1, acc2[1][1], 0, 0, 0);
+        }
+        conv_epilogue_buffers<2, 2>(acc2, y, res, b3, relu, m0, M, 0, COUT, COUT, 256, wave_u * 64, p * 64, l31, half);
+    }
+}
+
 }  // namespace isx
