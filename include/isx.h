@@ -327,6 +327,10 @@ int isx_triplet_loss_bwd_dev(const float* anchor, const float* pos, const float*
                              float scale, const float* scale_dev, int normalized, float* g_anchor, float* g_pos, float* g_neg,
                              isx_stream_t stream);
 
+/* model/custom_modules.py:59-67 NormalizeL2Fun.backward: with n2 = sum_j x_j^2 + eps and c = sum_j x_j dy_j,
+ * dx = (n2 dy - x c) / (n2 sqrt(n2)).  x, dy, dx: (B, D). */
+int isx_l2norm_rows_bwd(const float* x, const float* dy, int64_t B, int64_t D, float eps, float* dx, isx_stream_t stream);
+
 /* ---- backward pass of the TRAINABLE trunk suffix (siamese training, reference configuration) ---------------------------------
  * The reference trains layer4 of the ResNet (train/siamese_descriptor_p.py:14-17,48 -> model/nn_utils.py:5-23) and leaves the
  * backward pass to torch autograd: `loss.backward()` in utils/train_general.py:51-61.  These entries are that backward pass for

@@ -247,9 +247,10 @@ ISX_API int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int 
     const int kt_per = (int)((((K + 31) / 32) + S - 1) / S);
     ISX_REQUIRE((int64_t)leaves * S <= 65535, "isx_conv_wgrad_nhwc: leaves x splits exceeds the grid's z extent");
     hipStream_t st = (hipStream_t)stream;
-    // 128x128 tiles once they fill the chip, 64x64 below (layer4 of ResNet-50: 2048 x 512 = 64 big tiles, 256 small ones); chosen from the
-    // shape of ONE leaf, like S: the arithmetic of a leaf must not depend on how many leaves share the launch
-    const int64_t big = (int64_t)(Cout / 128) * (Cin / 128) * taps;
+    // 128x128 tiles once the LAUNCH fills the chip twice over, 64x64 below (layer4 of ResNet-50, 2048 x 512: 64 big tiles x 4 splits for one leaf,
+    // x 8 leaves in the batched step).  The tile shape only groups output elements: every element is the same k-ordered chain over the same
+    // pixels of its split in either shape, so -- unlike S and the k-tile boundaries -- it may depend on how many leaves share the launch.
+    const int64_t big = (int64_t)(Cout / 128) * (Cin / 128) * taps * leaves * S;
     if (Cout % 128 == 0 && Cin % 128 == 0 && big >= 512) {
         hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2>), dim3((unsigned)((Cout / 128) * (Cin / 128)), (unsigned)taps, (unsigned)(leaves * S)), dim3(256), 0, st, dz, K,
                            Cout, x, Cin, g, taps, dw, ldc, Cin / 128, kt_per, S, db);

@@ -329,6 +329,39 @@ ISX_API int isx_l2norm_shift_rows(const float* x, const float* shift, int64_t B,
     return launch_l2norm(x, shift, B, F, eps, y, (hipStream_t)stream);
 }
 
+// ---- backward of y = x / sqrt(sum_j x_j^2 + eps) (reference model/custom_modules.py:59-67 NormalizeL2Fun.backward) ----
+//   n2 = sum x^2 + eps, c = sum x dy:   dx = (n2 dy - x c) / (n2 sqrt(n2))
+// one workgroup per row, both sums by the fixed-order block reduction, one elementwise pass; replaces six torch kernels per call
+// (two calls per micro-batch of the siamese training step, whose head is host-bound).
+namespace isx {
+__global__ __launch_bounds__(1024) void l2norm_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int64_t D, float eps,
+                                                               float* __restrict__ dx) {
+    __shared__ float red[16];
+    const float* xr = x + (int64_t)blockIdx.x * D;
+    const float* gr = dy + (int64_t)blockIdx.x * D;
+    float* o = dx + (int64_t)blockIdx.x * D;
+    float s2 = 0.0f, sc = 0.0f;
+    for (int64_t j = threadIdx.x; j < D; j += 1024) {
+        const float v = xr[j];
+        s2 += v * v;
+        sc += v * gr[j];
+    }
+    const float n2 = block_sum<1024>(s2, red) + eps;
+    const float c = block_sum<1024>(sc, red);
+    const float inv = 1.0f / (n2 * sqrtf(n2));
+    for (int64_t j = threadIdx.x; j < D; j += 1024) o[j] = (n2 * gr[j] - xr[j] * c) * inv;
+}
+}  // namespace isx
+
+ISX_API int isx_l2norm_rows_bwd(const float* x, const float* dy, int64_t B, int64_t D, float eps, float* dx, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && D >= 0 && B < (1ll << 31), "isx_l2norm_rows_bwd: bad shape B=%lld D=%lld", (long long)B, (long long)D);
+    if (B * D == 0) return ISX_OK;
+    ISX_REQUIRE(x && dy && dx, "isx_l2norm_rows_bwd: null pointer");
+    hipLaunchKernelGGL(isx::l2norm_rows_bwd_kernel, dim3((unsigned)B), dim3(1024), 0, (hipStream_t)stream, x, dy, D, eps, dx);
+    ISX_CHECK_LAUNCH("isx_l2norm_rows_bwd");
+    return ISX_OK;
+}
+
 ISX_API int isx_gap_l2(const float* fmap, int64_t B, int C, int H, int W, float eps, float* y, isx_stream_t stream) {
     ISX_REQUIRE(B >= 0 && C > 0 && H > 0 && W > 0 && B < (1ll << 31), "isx_gap_l2: bad shape B=%lld C=%d H=%d W=%d", (long long)B, C, H, W);
     ISX_REQUIRE(fmap && y, "isx_gap_l2: null pointer");

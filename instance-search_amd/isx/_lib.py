@@ -19,6 +19,7 @@ _SIGNATURES = {
     "isx_version": (C.c_int, []),
     "isx_last_error": (C.c_char_p, []),
     "isx_l2norm_rows": (C.c_int, [VP, I64, I64, F32, VP, VP]),
+    "isx_l2norm_rows_bwd": (C.c_int, [VP, VP, I64, I64, F32, VP, VP]),
     "isx_l2norm_shift_rows": (C.c_int, [VP, VP, I64, I64, F32, VP, VP]),
     "isx_gap_l2": (C.c_int, [VP, I64, I32, I32, I32, F32, VP, VP]),
     "isx_gap_l2_nhwc": (C.c_int, [VP, I64, I32, I32, I32, F32, VP, VP]),

@@ -46,6 +46,18 @@ def l2norm_rows(x, eps=EPS, out=None):
     return y
 
 
+def l2norm_rows_bwd(x, dy, eps=EPS):
+    """Gradient of l2norm_rows wrt x: (n2 dy - x <x, dy>) / (n2 sqrt(n2)), n2 = sum x^2 + eps, per row."""
+    x = _f32(x, "x")
+    dy = _f32(dy, "dy")
+    if x.shape != dy.shape:
+        raise _lib.IsxError("l2norm_rows_bwd: x and dy must have the same shape")
+    B, D = x.shape
+    dx = torch.empty_like(x)
+    check(lib().isx_l2norm_rows_bwd(x.data_ptr(), dy.data_ptr(), B, D, eps, dx.data_ptr(), _stream()), "isx_l2norm_rows_bwd")
+    return dx
+
+
 def l2norm_shift_rows(x, shift=None, eps=EPS):
     x = _f32(x, "x")
     B, F = x.shape

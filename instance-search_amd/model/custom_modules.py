@@ -35,6 +35,9 @@ class _NormalizeL2(Function):
     @staticmethod
     def backward(ctx, grad_output):
         (x,) = ctx.saved_tensors
+        if x.is_cuda and grad_output.is_cuda and x.dtype == torch.float32 and x.dim() == 2:
+            from isx import ops
+            return ops.l2norm_rows_bwd(x, grad_output, ctx.eps), None
         norm2 = x.pow(2).sum(1, keepdim=True) + ctx.eps
         norm = norm2.sqrt()
         cross = (x * grad_output).sum(1, keepdim=True)

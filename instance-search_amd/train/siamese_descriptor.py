@@ -135,13 +135,12 @@ train_type = 'Siamese descriptor'
 
 def main(train_set, test_train_set, test_set):
     """Training entry (reference :165-207) on already loaded (tensor, label, path) datasets."""
-    import torch.optim as optim
+    from utils.train_general import make_sgd
     del labels[:]
     labels.extend(sorted(set(l for _, l, _ in train_set)))
     P.num_classes = len(labels)
     net = get_siamese_net()
-    optimizer = optim.SGD((p for p in net.parameters() if p.requires_grad), lr=P.train_lr, momentum=P.train_momentum,
-                          weight_decay=P.train_weight_decay)
+    optimizer = make_sgd((p for p in net.parameters() if p.requires_grad), P.train_lr, P.train_momentum, P.train_weight_decay)
     criterion = TripletLoss(P.triplet_margin, P.train_loss_avg)
     testset_tuple = (test_set, test_train_set)
     score = test_print_descriptor(train_type, P, net, testset_tuple, get_embeddings)

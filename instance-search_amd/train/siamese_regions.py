@@ -75,14 +75,13 @@ def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, cr
 
 def main(train_set, test_train_set, test_set):
     """Training entry (reference :171-213) on already loaded (tensor, label, path) datasets."""
-    import torch.optim as optim
+    from utils.train_general import make_sgd
     del labels[:]
     labels.extend(sorted(set(l for _, l, _ in train_set)))
     P.num_classes = len(labels)
     P.train_micro_batch = 1                                               # has to be 1 (reference siamese_regions_p.py:64)
     net = get_siamese_net()
-    optimizer = optim.SGD((p for p in net.parameters() if p.requires_grad), lr=P.train_lr, momentum=P.train_momentum,
-                          weight_decay=P.train_weight_decay)
+    optimizer = make_sgd((p for p in net.parameters() if p.requires_grad), P.train_lr, P.train_momentum, P.train_weight_decay)
     criterion = TripletLoss(P.triplet_margin, P.train_loss_avg)
     criterion2 = nn.CrossEntropyLoss(reduction='mean' if P.train_loss2_avg else 'sum')
     testset_tuple = (test_set, test_train_set)

@@ -202,3 +202,21 @@ def test_backward_kernels_vs_torch():
     check(L.isx_bn_fold_backward(parts.data_ptr(), dparts.data_ptr(), 1, 3, w.detach().data_ptr(), s.detach().contiguous().data_ptr(), mean.data_ptr(),
                                  istd.data_ptr(), Co, Ci, taps, 1, 0, gw.data_ptr(), gg.data_ptr(), gb.data_ptr(), st), "x")
     assert _rel(gw - 1, w.grad) <= 1e-5 and _rel(gg - 1, gam.grad) <= 1e-4 and _rel(gb - 1, bet.grad) <= 1e-6
+
+
+@pytest.mark.parametrize("B,D", [(24, 100352), (24, 2048), (3, 17), (1, 5000), (70, 1025)])
+def test_l2norm_rows_bwd_vs_float64_autograd(B, D):
+    """isx_l2norm_rows_bwd (reference model/custom_modules.py:59-67) against torch autograd of the same formula in float64; and the
+    NormalizeL2 module routes its backward through it on the GPU."""
+    from isx import ops
+    from model.custom_modules import NormalizeL2
+    g = torch.Generator(device="cuda").manual_seed(B * 7 + D)
+    x = torch.randn(B, D, device="cuda", generator=g)
+    dy = torch.randn(B, D, device="cuda", generator=g)
+    x64 = x.double().requires_grad_()
+    (x64 / (x64.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()).backward(dy.double())
+    got = ops.l2norm_rows_bwd(x, dy, 1e-10)
+    assert _rel(got.double(), x64.grad) <= 2e-6
+    xm = x.clone().requires_grad_()
+    NormalizeL2()(xm).backward(dy)
+    assert torch.equal(xm.grad, got)

@@ -48,6 +48,8 @@ def run_config(name, args, world, rank, local):
 
     sd.mine_epoch_negatives = spy
     dp.STATS.clear()
+    import utils.train_general as tg
+    tg.PHASES = {} if args.phases else None
     t0 = time.perf_counter()
     try:
         net, _ = sd.main(tr, tr, te)
@@ -65,6 +67,10 @@ def run_config(name, args, world, rank, local):
            "triplets_per_epoch": n_couples, "optimizer_steps_per_epoch": n_steps, "epoch_seconds": per_epoch, "total_seconds": t1 - t0,
            "triplets_per_s": n_couples / steady, "images_fwd_bwd_per_s": 3 * n_couples / steady,
            "exchange": dict(dp.STATS)}
+    if tg.PHASES:
+        steps = n_steps * args.epochs
+        out["phase_ms_per_step"] = dict((k, 1e3 * v / steps) for k, v in tg.PHASES.items())
+        tg.PHASES = None
     del net
     torch.cuda.empty_cache()
     return out
@@ -77,6 +83,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=2)
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--configs", default="reference,frozen")
+    ap.add_argument("--phases", action="store_true", help="synchronise and time the phases of the training step (diagnostic: the totals are slower)")
     args = ap.parse_args()
     import torch.distributed as dist
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
