@@ -349,6 +349,12 @@ int isx_conv1x1_dgrad_nhwc(const float* dz, int64_t M, int Cout, const float* wt
 int isx_conv3x3_dgrad_nhwc(const float* dz, int64_t B, int H, int W, int Cout, const float* wt, int Cin, const float* mask,
                            float* dx, isx_stream_t stream);
 
+/* Gradient of a STRIDE-2 3x3 convolution (padding 1) wrt its input, second half: dcol[p][tap][ci] = sum_co dz[p][co] w'[co][tap][ci] is
+ * one GEMM over the OUTPUT pixels (isx_conv1x1_dgrad_nhwc with wt = w' as (9*Cin, Cout)); this entry gathers, for every input pixel, the
+ * taps that reach it (1, 2 or 4 of the 9, in (kh, kw) order) and applies the ReLU mask: a quarter of the matrix work of the
+ * zero-upsampled form.  dcol: (B*Ho*Wo, 9, Cin); mask (or NULL) / dx: (B,H,W,Cin); Cin % 4 == 0. */
+int isx_conv3x3_s2_col2im_nhwc(const float* dcol, int64_t B, int H, int W, int Cin, const float* mask, float* dx, isx_stream_t stream);
+
 /* Weight gradient of `leaves` micro-batches in one launch, each split over its pixels: the B images are `leaves` consecutive groups;
  * dw[l][s][co][tap][ci] = sum over the output pixels p of split s of leaf l of dz[p][co] * x[src(p, tap)][ci] and db[l][s][co] = sum over
  * the same pixels of dz[p][co] (the bias gradient, a by-product of the staged dz tiles), s < S = isx_conv_wgrad_splits(pixels of ONE

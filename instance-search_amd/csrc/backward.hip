@@ -160,6 +160,40 @@ __global__ __launch_bounds__(256) void relu_grad_kernel(const float4* __restrict
     dz[i] = make_float4(v.x > 0.0f ? g.x : 0.0f, v.y > 0.0f ? g.y : 0.0f, v.z > 0.0f ? g.z : 0.0f, v.w > 0.0f ? g.w : 0.0f);
 }
 
+// ---- input gradient of a STRIDE-2 3x3 convolution from its per-tap columns --------------------------------------------------------
+// dcol[p][tap][ci] = sum_co dz[p][co] * w'[co][tap][ci] (one NT GEMM over the OUTPUT pixels: a quarter of the pixels of the zero-upsampled
+// form, 9 x Cin columns); input pixel (h, w) collects the taps that reach it: (h + 1 - kh) and (w + 1 - kw) even and inside the output grid
+// -- one tap for (even, even), two for mixed parity, four for (odd, odd) -- in (kh, kw) order; then the ReLU mask.  One thread = 4 channels.
+__global__ __launch_bounds__(256) void col2im_s2_kernel(const float4* __restrict__ dcol, int64_t B, int H, int W, int Ho, int Wo, int C4,
+                                                        const float4* __restrict__ mask, float4* __restrict__ dx) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = B * H * W * C4;
+    if (i >= total) return;
+    const int c = (int)(i % C4);
+    const int64_t pix = i / C4;
+    const int w = (int)(pix % W), h = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hn = h + 1 - kh;
+        if (hn < 0 || (hn & 1) || (hn >> 1) >= Ho) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wn = w + 1 - kw;
+            if (wn < 0 || (wn & 1) || (wn >> 1) >= Wo) continue;
+            const int64_t p = (b * Ho + (hn >> 1)) * Wo + (wn >> 1);
+            const float4 v = dcol[(p * 9 + kh * 3 + kw) * C4 + c];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    if (mask) {
+        const float4 m = mask[i];
+        acc.x = m.x > 0.0f ? acc.x : 0.0f; acc.y = m.y > 0.0f ? acc.y : 0.0f; acc.z = m.z > 0.0f ? acc.z : 0.0f; acc.w = m.w > 0.0f ? acc.w : 0.0f;
+    }
+    dx[i] = acc;
+}
+
 // ---- chain rule of the BatchNorm fold -----------------------------------------------------------------------------------------
 // one block per (output channel, leaf).  dwp: leaves x splits partials of (Cout, taps, Cin) [the wgrad layout], a leaf's partials added in
 // split order; db: leaves x splits partials of (Cout); w: (Cout, Cin, taps) [the nn.Conv2d parameter layout]; gw / ggamma / gbeta: leaf l
@@ -259,6 +293,22 @@ ISX_API int isx_conv_wgrad_nhwc(const float* dz, const float* x, int64_t B, int 
                            Cout, x, Cin, g, taps, dw, ldc, Cin / 64, kt_per, S, db);
     }
     ISX_CHECK_LAUNCH("isx_conv_wgrad_nhwc");
+    return ISX_OK;
+}
+
+// Gradient of a STRIDE-2 3x3 convolution (padding 1) wrt its input from the per-tap columns dcol = dz . w' -- (B*Ho*Wo, 9, Cin), the output of
+// isx_conv1x1_dgrad_nhwc(dz, ..., wt = w' as (9 * Cin, Cout), ...) -- with the ReLU of the layer below fused: dx = gather(dcol) . [mask > 0].
+// mask / dx: (B,H,W,Cin); Ho = (H - 1) / 2 + 1, Wo likewise; Cin % 4 == 0; mask may be NULL.
+ISX_API int isx_conv3x3_s2_col2im_nhwc(const float* dcol, int64_t B, int H, int W, int Cin, const float* mask, float* dx, isx_stream_t stream) {
+    ISX_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cin % 4 == 0, "isx_conv3x3_s2_col2im_nhwc: bad shape B=%lld H=%d W=%d Cin=%d (Cin %% 4 == 0)", (long long)B, H, W, Cin);
+    if (B == 0) return ISX_OK;
+    ISX_REQUIRE(dcol && dx, "isx_conv3x3_s2_col2im_nhwc: null pointer");
+    ISX_REQUIRE((((uintptr_t)dcol | (uintptr_t)dx | (uintptr_t)mask) % 16) == 0, "isx_conv3x3_s2_col2im_nhwc: pointers must be 16-B aligned");
+    const int64_t total = B * H * W * (Cin / 4);
+    ISX_REQUIRE((total + 255) / 256 < (1ll << 31), "isx_conv3x3_s2_col2im_nhwc: too many elements for one grid");
+    hipLaunchKernelGGL(col2im_s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)dcol, B, H, W, (H - 1) / 2 + 1,
+                       (W - 1) / 2 + 1, Cin / 4, (const float4*)mask, (float4*)dx);
+    ISX_CHECK_LAUNCH("isx_conv3x3_s2_col2im_nhwc");
     return ISX_OK;
 }
 

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "isx_triplet_loss_bwd_dev": (C.c_int, [VP, VP, VP, VP, I64, I32, F32, VP, I32, VP, VP, VP, VP]),
     "isx_conv1x1_dgrad_nhwc": (C.c_int, [VP, I64, I32, VP, I32, VP, VP, VP, VP]),
     "isx_conv3x3_dgrad_nhwc": (C.c_int, [VP, I64, I32, I32, I32, VP, I32, VP, VP, VP]),
+    "isx_conv3x3_s2_col2im_nhwc": (C.c_int, [VP, I64, I32, I32, I32, VP, VP, VP]),
     "isx_conv_wgrad_splits": (C.c_int, [I64, I32, I32, I32]),
     "isx_conv_wgrad_nhwc": (C.c_int, [VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP]),
     "isx_relu_grad": (C.c_int, [VP, VP, I64, VP, VP]),

@@ -32,7 +32,7 @@ def _stream():
 
 class _Folded(object):
     """Per-step derived tensors of one convolution + eval-mode BatchNorm."""
-    __slots__ = ("conv", "bn", "key", "taps", "cin", "cout", "stride", "scale", "istd", "mean", "bias", "w_fwd", "w_dgrad", "cat_key", "w_cat", "bias_cat")
+    __slots__ = ("conv", "bn", "key", "taps", "cin", "cout", "stride", "scale", "istd", "mean", "bias", "w_fwd", "w_dgrad", "w_col", "cat_key", "w_cat", "bias_cat")
 
     def __init__(self, conv, bn):
         self.conv, self.bn, self.key, self.cat_key = conv, bn, None, None
@@ -56,6 +56,9 @@ class _Folded(object):
             self.w_fwd = wf.permute(0, 2, 3, 1).contiguous()                            # OHWI: (Cout, kh, kw, Cin)
             if self.taps == 1:
                 self.w_dgrad = wf.view(self.cout, self.cin).t().contiguous()            # W'^T: (Cin, Cout)
+            elif self.stride == 2:
+                self.w_dgrad = None
+                self.w_col = self.w_fwd.view(self.cout, self.taps * self.cin).t().contiguous()   # (9 Cin, Cout): per-tap columns of the input gradient
             else:
                 self.w_dgrad = wf.flip(2, 3).permute(1, 2, 3, 0).contiguous()           # (Cin, kh, kw, Cout), taps flipped
         self.key = key
@@ -244,13 +247,14 @@ class SuffixEngine(object):
                   "isx_conv1x1_dgrad_nhwc")
             # conv2 (3x3)
             self._fold_backward(f2, *self._wgrad(dT2, t1, f2, leaves), g2, leaf_grads)
-            if f2.stride == 2:                                # zero-upsample to the input grid: the gradient becomes a stride-1 convolution
-                up = torch.zeros((B, H, W, f2.cout), device=x.device, dtype=torch.float32)
-                up[:, ::2, ::2] = dT2
-                dT2 = up
             dT1 = torch.empty_like(t1)
-            check(L.isx_conv3x3_dgrad_nhwc(dT2.data_ptr(), B, H, W, f2.cout, f2.w_dgrad.data_ptr(), f2.cin, t1.data_ptr(), dT1.data_ptr(), st),
-                  "isx_conv3x3_dgrad_nhwc")
+            if f2.stride == 2:                                # per-tap columns over the OUTPUT pixels (one GEMM), then each input pixel gathers its 1 / 2 / 4 taps
+                dcol = torch.empty((M2, 9 * f2.cin), device=x.device, dtype=torch.float32)
+                check(L.isx_conv1x1_dgrad_nhwc(dT2.data_ptr(), M2, f2.cout, f2.w_col.data_ptr(), 9 * f2.cin, None, None, dcol.data_ptr(), st), "isx_conv1x1_dgrad_nhwc")
+                check(L.isx_conv3x3_s2_col2im_nhwc(dcol.data_ptr(), B, H, W, f2.cin, t1.data_ptr(), dT1.data_ptr(), st), "isx_conv3x3_s2_col2im_nhwc")
+            else:
+                check(L.isx_conv3x3_dgrad_nhwc(dT2.data_ptr(), B, H, W, f2.cout, f2.w_dgrad.data_ptr(), f2.cin, t1.data_ptr(), dT1.data_ptr(), st),
+                      "isx_conv3x3_dgrad_nhwc")
             # conv1
             self._fold_backward(f1, *self._wgrad(dT1, x, f1, leaves), g1, leaf_grads)
             grads_rev.append(g1 + g2 + g3 + gd)

@@ -86,7 +86,25 @@ def main():
             if isinstance(m, nn.BatchNorm2d):
                 m.eval()
         ref(x).sum().backward()
-        res["ref_flat"] = torch.cat([p.grad.reshape(-1) for p in ref.parameters()]).cpu()
+        res["ref_flat"] = torch.cat([p.grad.reshape(-1) for p in reversed(list(ref.parameters()))]).cpu()     # the flat buffer is in backward (reverse parameter) order
+    # ---- canonical gradient tree across the ranks (isx/dp.TreeExchange: RCCL all-to-all + all-gather) and the row exchange of the head ----
+    from isx import dp
+    if dp.is_power_of_two(world):
+        g2 = torch.Generator().manual_seed(77)
+        leaves = [torch.randn(100003, generator=g2) * (10.0 ** (i % 5 - 2)) for i in range(2 * world)]      # 2 leaves per rank, a length that needs padding
+        lo, hi = dp.rank_leaves(len(leaves), world, rank)
+        mine = dp.tree_sum(lo, hi, lambda i: leaves[i].clone().to(dev))
+        dp.TreeExchange().allreduce_(mine)
+        res["tree"] = mine.cpu()
+        res["tree_ref"] = dp.tree_sum(0, len(leaves), lambda i: leaves[i].clone())
+        w = torch.nn.Parameter(torch.zeros(16, 40, device=dev))
+        sink = dp.RowSink([w])
+        xr = torch.randn(3 * world, 40, generator=g2).to(dev)
+        dyr = torch.randn(3 * world, 16, generator=g2).to(dev)
+        sink.add(w, xr[3 * rank:3 * rank + 3], dyr[3 * rank:3 * rank + 3])
+        sink.finish()
+        res["rows_dw"] = w.grad.cpu()
+        res["rows_ref"] = dp.weight_gradient_from_rows(dyr, xr).cpu()
     torch.save(res, "%s.%d" % (out, rank))
     dist.barrier()
     torch.cuda.synchronize()

@@ -146,7 +146,7 @@ def test_backward_kernels_vs_torch():
     np.testing.assert_allclose(dx.cpu().numpy(), (dzz.double() @ w.double()).float().cpu().numpy(), rtol=1e-4, atol=1e-3)
     # wgrad (+ bias gradient): 1x1, strided 1x1, 3x3 stride 1 and 2 against torch's convolution_backward; pixel counts that give 1 and several splits
     for taps, stride, B, H, W, Ci, Co in ((1, 1, 3, 5, 7, 64, 128), (1, 2, 2, 7, 6, 128, 64), (9, 1, 2, 6, 5, 64, 64), (9, 2, 3, 7, 7, 128, 64),
-                                          (1, 1, 24, 7, 7, 128, 64), (9, 1, 8, 14, 14, 64, 64)):
+                                          (1, 1, 24, 7, 7, 128, 64), (9, 1, 8, 14, 14, 64, 64), (9, 2, 2, 14, 14, 64, 128)):
         k = 3 if taps == 9 else 1
         x = rn(B, Ci, H, W).contiguous(memory_format=torch.channels_last)
         wt = rn(Co, Ci, k, k)
@@ -186,6 +186,16 @@ def test_backward_kernels_vs_torch():
             check(L.isx_conv3x3_dgrad_nhwc(d.data_ptr(), B, H, W, Co, wd.data_ptr(), Ci, m.data_ptr(), dxx.data_ptr(), st), "x")
             want = gx.permute(0, 2, 3, 1) * (m > 0)
             assert _rel(dxx, want) <= 2e-5, (stride, _rel(dxx, want))
+            if stride == 2:                                     # the product path of a stride-2 layer: per-tap columns (one GEMM over the output pixels) + tap gather
+                Mo = out.shape[0] * out.shape[2] * out.shape[3]
+                wcol = wt.permute(0, 2, 3, 1).reshape(Co, 9 * Ci).t().contiguous()          # (9 Ci, Co)
+                dcol = torch.empty(Mo, 9 * Ci, device="cuda")
+                check(L.isx_conv1x1_dgrad_nhwc(dz_.permute(0, 2, 3, 1).contiguous().data_ptr(), Mo, Co, wcol.data_ptr(), 9 * Ci, None, None, dcol.data_ptr(), st), "x")
+                dx2 = torch.empty(B, H, W, Ci, device="cuda")
+                check(L.isx_conv3x3_s2_col2im_nhwc(dcol.data_ptr(), B, H, W, Ci, m.data_ptr(), dx2.data_ptr(), st), "x")
+                assert _rel(dx2, want) <= 2e-5, _rel(dx2, want)
+                check(L.isx_conv3x3_s2_col2im_nhwc(dcol.data_ptr(), B, H, W, Ci, None, dx2.data_ptr(), st), "x")
+                assert _rel(dx2, gx.permute(0, 2, 3, 1)) <= 2e-5
     # chain rule of the fold against autograd through the fold itself
     Co, Ci, taps = 64, 128, 9
     w = rn(Co, Ci, 3, 3).requires_grad_()
