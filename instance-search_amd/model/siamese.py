@@ -236,7 +236,26 @@ def _many(forward_single, xs):
     out = forward_single(torch.cat(xs, 0))
     if isinstance(out, tuple):
         return tuple(tuple(o[i * n:(i + 1) * n] for o in out) for i in range(len(xs)))
+    if out.requires_grad:
+        return _SplitRows.apply(out, len(xs))
     return tuple(out[i * n:(i + 1) * n] for i in range(len(xs)))
+
+
+class _SplitRows(torch.autograd.Function):
+    """(k * n, D) -> k tensors of n consecutive rows; backward = ONE torch.cat of the k gradients (autograd's own slicing costs a zero-filled
+    full-size tensor, a copy and an add per slice: 8 launches where the host-bound head of the training step can afford 1)."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        n = x.size(0) // k
+        ctx.shape = (n, tuple(x.shape[1:]))
+        return tuple(x[i * n:(i + 1) * n] for i in range(k))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n, rest = ctx.shape
+        ref = next(g for g in grads if g is not None)
+        return torch.cat([g if g is not None else ref.new_zeros((n,) + rest) for g in grads], 0), None
 
 
 def _descriptor_head(in_features, out_features):
@@ -317,6 +336,8 @@ class DescriptorNet(nn.Module):
     def head_rows(self, f, n_branches):
         """head_features on the branches ALREADY concatenated along the batch dimension ((n_branches * n) rows): the descriptors, split per branch"""
         out = self._head_only(f)
+        if out.requires_grad:
+            return _SplitRows.apply(out, n_branches)          # one concatenation in the backward pass instead of three zero-fill + copy + add chains
         n = out.size(0) // n_branches
         return tuple(out[i * n:(i + 1) * n] for i in range(n_branches))
 
