@@ -536,7 +536,7 @@ def test_reference_config_one_step_matches_plain_torch_training():
     """The reference's training configuration (stem + layers 1-3 frozen, layer4 + head trained): frozen prefix on the BN-folded HIP trunk
     without a graph, layer4 forward AND backward on the libisx suffix engine, head weight gradient from the step's rows -- against the PLAIN
     torch run (whole trunk = features(x) under autograd, MIOpen).  After ONE optimizer step (5 micro-batches accumulated, SGD with momentum
-    and weight decay) every convolution / linear weight agrees to <= 2e-5 of its tensor's scale (measured 6e-6); the 1-d parameters (biases, BatchNorm affine,
+    and weight decay) every convolution / linear weight agrees to <= 1e-4 of its tensor's scale (measured 5e-6 ... 1.6e-5); the 1-d parameters (biases, BatchNorm affine,
     Shift offsets: they start at or near zero) are judged against the size of the update, see below."""
     mined = []
     init, a = _train_reference_config(True, True, 1, 16, 40, 8, mined, None)     # 16 images, 4 labels: 40 positive couples = ONE mini-batch of 5 micro-batches
@@ -545,8 +545,9 @@ def test_reference_config_one_step_matches_plain_torch_training():
     print("reference config, one step, HIP prefix + suffix engine vs plain torch: max |dw| / max|w| = %.3g (%s); relative to the update %.3g (%s); "
           "layer4 moved %.3g, head moved %.3g" % (worst_w, name_w, worst_u, name_u, moved4, moved_head))
     assert moved4 > 0 and moved_head > 0
-    # 1e-6 of the weight scale would need identical ReLU patterns in both runs; measured 6e-6 (= 2 % of this step's update of that tensor), see below
-    assert worst_w <= 2e-5
+    # 1e-6 of the weight scale would need identical ReLU patterns in both runs -- and a reproducible plain run: MIOpen's split-K weight-gradient
+    # kernels (igemm_wrw ... gkgs: atomic adds) move this number between 5e-6 and 1.6e-5 from one run of the SAME plain configuration to the next
+    assert worst_w <= 1e-4
     # relative to the UPDATE itself the runs differ by per cents in the worst tensor -- always a BatchNorm bias or a Shift offset: a column sum
     # over the rows whose ReLU is open, and a pre-activation of size 1e-7 lands on either side of 0 depending on the rounding of the forward pass
     # (folded vs unfolded BatchNorm, k-ordered chain vs MIOpen's blocked sums); tests/test_gpu_suffix.py pins the masks and finds 2e-6
