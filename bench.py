@@ -78,6 +78,7 @@ def parse():
                          "(default: on a second stream behind the next step's trunk)")
     ap.add_argument("--ingest-images", type=int, default=65536,
                     help="images of the non-resident streaming-ingest side measurement (0 = skip); host memory: 4096 distinct uint8 images, the rest views")
+    ap.add_argument("--no-train-bench", action="store_true", help="skip the siamese-training side measurement (BASELINE configs[3] on one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
 
@@ -290,6 +291,9 @@ def compact_line(full, detail_file=None):
     if isinstance(ig, dict):
         line["ingest_streaming"] = _pick(ig, ("error", "images", "resident_images_per_s", "extract_pcie_inclusive_images_per_s", "streamed_over_resident",
                                               "descriptors_identical"))
+    tr = full.get("training")
+    if isinstance(tr, dict):
+        line["training"] = _pick(tr, ("error", "reference_config_triplets_per_s", "frozen_trunk_triplets_per_s", "reference_over_frozen", "reference_config"))
     if "exchange_ms" in full:
         line["exchange_ms"] = full["exchange_ms"]
         line["exchange"] = _pick(full.get("exchange") or {}, ("query_allgather_ms", "result_allgather_merge_ms", "exposed_when_serialised_frac_of_step",
@@ -307,7 +311,7 @@ def compact_line(full, detail_file=None):
     for key in ("value", "ms_per_step", "dist_per_s"):          # the contract's scalars keep their digits
         if key in full:
             line[key] = full[key]
-    for victim in ("families", "ingest_streaming", "exchange", "extraction_regions", "retrieval_shard", "roofline_step"):      # never expected: a safety net
+    for victim in ("families", "training", "ingest_streaming", "exchange", "extraction_regions", "retrieval_shard", "roofline_step"):      # never expected: a safety net
         if len(json.dumps(line)) <= MAX_LINE_BYTES:
             break
         line.pop(victim, None)
@@ -720,6 +724,38 @@ def main():
             ingest_result = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
 
+    # side measurement: next-scope row f1 (BASELINE configs[3] on ONE GPU) -- siamese triplet training of DescriptorNet(ResNet-50) on the
+    # reference's configuration (layer4 + head trained) and with the whole trunk frozen: tools/bench_train.py, 2 epochs each (N = 1 only)
+    training_result = None
+    if not args.no_train_bench and world == 1 and args.backbone_dtype == "f32":
+        try:
+            import argparse as _ap
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_train
+            import io
+            import contextlib
+            targs = _ap.Namespace(images=512, labels=64, epochs=2, backbone="resnet50", configs="reference,frozen", phases=False)
+            res_t = {}
+            from train import siamese_descriptor as _sd
+            saved_p = dict(_sd.P.__dict__)
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):          # the training script logs its evaluation lines to stdout
+                    for name in ("reference", "frozen"):
+                        res_t[name] = bench_train.run_config(name, targs, 1, 0, local)
+            finally:
+                _sd.P.__dict__.clear(); _sd.P.__dict__.update(saved_p)
+            training_result = {"workload": "BASELINE configs[3] on one GPU: DescriptorNet(ResNet-50, 2048) triplet training with per-epoch hard-negative mining, "
+                                           "batch 64 = 8 micro-batches of 8, SGD 1e-3 / 0.9 / 5e-4, BN frozen, 512 synthetic images / 64 labels, 36 steps per epoch",
+                               "reference_config_triplets_per_s": res_t["reference"]["triplets_per_s"],
+                               "reference_config": "untrained_blocks = 15 (reference train/siamese_descriptor_p.py:14-17,48): layer4 + descriptor head trained",
+                               "frozen_trunk_triplets_per_s": res_t["frozen"]["triplets_per_s"],
+                               "reference_over_frozen": res_t["reference"]["triplets_per_s"] / res_t["frozen"]["triplets_per_s"],
+                               "trainable_parameters": res_t["reference"]["trainable_parameters"],
+                               "epoch_seconds": res_t["reference"]["epoch_seconds"], "exchange": res_t["reference"]["exchange"]}
+        except Exception as e:
+            training_result = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+
     regions_result = None
     if not args.no_regions_bench:
         try:
@@ -838,6 +874,8 @@ def main():
             line["extraction_regions"] = regions_result
         if ingest_result is not None:
             line["ingest_streaming"] = ingest_result
+        if training_result is not None:
+            line["training"] = training_result
         if world > 1:
             ex = exchange_legs or {}
             tot = sum(ex.values()) if ex else None

@@ -10,19 +10,19 @@ cd /tmp && export TMPDIR=/tmp && cd $REPO
 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 cp gpurun_out/bench_detail.json $OUT/bench_detail_full.json
 echo "bench line done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-regions-bench --ingest-images 0 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-regions-bench --ingest-images 0 --no-train-bench > $OUT/stats.log 2>&1
 echo "stats done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/regions -- python3 bench.py --only-regions > $OUT/regions.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/regions -- python3 bench.py --only-regions --no-train-bench > $OUT/regions.log 2>&1
 echo "regions trace done"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-bench --no-kernel-pass --no-regions-bench --ingest-images 0 > $OUT/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-bench --no-kernel-pass --no-regions-bench --ingest-images 0 --no-train-bench > $OUT/fetch.log 2>&1
 echo "fetch done"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-bench --no-kernel-pass --no-regions-bench --ingest-images 0 > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-bench --no-kernel-pass --no-regions-bench --ingest-images 0 --no-train-bench > $OUT/write.log 2>&1
 echo "write done"
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-bench --no-kernel-pass --no-regions-bench --ingest-images 0 > $OUT/mfma.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/mfma -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-shard-bench --no-kernel-pass --no-regions-bench --ingest-images 0 --no-train-bench > $OUT/mfma.log 2>&1
 echo "mfma done"
 python3 profiles/summarize_prof.py $TAG $OUT/stats $OUT/fetch $OUT/write $OUT/mfma > $OUT/summarize.log 2>&1 || tail -5 $OUT/summarize.log
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/rfetch -- python3 bench.py --only-regions > $OUT/rfetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/rwrite -- python3 bench.py --only-regions > $OUT/rwrite.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/rfetch -- python3 bench.py --only-regions --no-train-bench > $OUT/rfetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/rwrite -- python3 bench.py --only-regions --no-train-bench > $OUT/rwrite.log 2>&1
 python3 profiles/summarize_regions_pmc.py $TAG $OUT/rfetch $OUT/rwrite 128 >> $OUT/summarize.log 2>&1 || tail -5 $OUT/summarize.log
 echo "regions pmc done"
 mkdir -p $OUT/summaries && cp profiles/${TAG}_* profiles/roofline_traffic.json $OUT/summaries/ 2>/dev/null || true
