@@ -140,6 +140,27 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
         }
         return;
     }
+    if (EPI == 0 && (int64_t)BM * ldc * 4 < (1ll << 32)) {
+        // plain score store through BUFFER instructions (round 4; the convolution epilogue has used them since round 2): a wave-uniform
+        // descriptor of the tile's rows clipped at row M, one 32-bit lane offset per MFMA tile (a column >= N is sent outside the
+        // descriptor and its store dropped), the row offset as an SGPR -- no per-element 64-bit address, no edge branch.  Short-K
+        // problems (D = 464: 29 k-tiles per 128 x 128 tile) spent a tenth of their time in the old epilogue.
+        const auto rc = conv_tile_rsrc(C, m0, M, ldc, BM);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int ncol = (int)(n0 + wn_u * (32 * TN) + j * 32) + l31;
+                const unsigned lo = conv_lane_off(ncol, N, wm_u * (32 * TM) + i * 32 + 4 * half, ldc);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[i][j][e];             // (a scalar copy first: bit_cast applied to the vector element itself stored element 0 sixteen times, hipcc 7.2)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
