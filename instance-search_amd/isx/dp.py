@@ -204,6 +204,17 @@ class TreeExchange(object):
             self._pad = torch.zeros(per * P, dtype=flat.dtype, device=flat.device)
         pad = self._pad
         pad[:n].copy_(flat)
+        if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo has no all-to-all on device tensors: stage through the host (two ranks on ONE GPU in tests/test_training.py; RCCL never gets here)
+            host = pad.cpu()
+            recv = torch.empty_like(host)
+            dist.all_to_all_single(recv, host, group=self.group)
+            pieces = recv.view(P, per)
+            red = tree_sum(0, P, lambda j: pieces[j])                     # same order, same fp32 adds as on the device
+            dist.all_gather_into_tensor(host, red.contiguous(), group=self.group)
+            pad.copy_(host)
+            flat.copy_(pad[:n])
+            return flat
         recv = torch.empty_like(pad)
         dist.all_to_all_single(recv, pad, group=self.group)               # recv.view(P, per)[j] = rank j's slice number self.rank
         pieces = recv.view(P, per)

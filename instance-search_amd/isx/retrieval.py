@@ -129,7 +129,13 @@ def exchange_topk(s, i, group=None, native_comm=None):
     if native_comm is None and (not dist.is_initialized() or dist.get_world_size(group) == 1):
         return s[None], i[None]
     if native_comm is None and s.is_cuda and exchange_backend(group).startswith("isx_"):
-        native_comm = native_comm_for(group)
+        try:
+            native_comm = native_comm_for(group)
+        except Exception as e:                               # librccl not loadable / communicator refused: every rank fails alike (same library, same node)
+            import os
+            import sys
+            print("isx.retrieval: libisx RCCL communicator unavailable (%s: %s); exchanging over torch.distributed" % (type(e).__name__, e), file=sys.stderr)
+            os.environ["ISX_NATIVE_COMM"] = "0"              # exchange_backend() reports the path actually taken from here on
     if native_comm is not None and s.is_cuda:
         if native_comm.nranks == 1:
             return s[None], i[None]

@@ -590,3 +590,35 @@ def test_batched_suffix_is_bit_identical_to_leaf_by_leaf():
         if a[k].dtype.is_floating_point:
             moved = max(moved, float((a[k] - init[k].to(a[k].device)).abs().max()))
     assert moved > 0
+
+
+def _train_reference_two_ranks_one_gpu(rank, world, port, out):
+    """worker of test_two_ranks_on_one_gpu_match_single_process: rank `rank` of `world`, every rank on cuda:0, gloo process group"""
+    sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _, state = _train_reference_config(True, True, 2, 32, 16, 4, [], None)
+    if rank == 0:
+        torch.save({k: v.cpu() for k, v in state.items()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
+    """Data-parallel training of the REAL net with the REAL kernels: DescriptorNet(ResNet-50) on the reference configuration, two ranks (both
+    on cuda:0, gloo -- the box has one GPU; RCCL replaces only the transport) x 2 of the 4 micro-batches of every step, HIP prefix + batched
+    suffix engine + row-deferred head + TreeExchange, against ONE process with all 4 micro-batches: the whole state dict BIT-IDENTICAL after
+    two epochs (mining included: no replay).  The rank-count independence the gloo CPU tests show on a toy net, here on layer4 + the head."""
+    out = str(tmp_path / "dp.pt")
+    mp.spawn(_train_reference_two_ranks_one_gpu, args=(2, _free_port(), out), nprocs=2, join=True)
+    b = torch.load(out)
+    init, a = _train_reference_config(True, True, 2, 32, 16, 4, [], None)
+    moved = 0.0
+    for k in a:
+        assert torch.equal(a[k].cpu(), b[k]), (k, float((a[k].cpu().float() - b[k].float()).abs().max()))
+        if a[k].dtype.is_floating_point:
+            moved = max(moved, float((a[k] - init[k].to(a[k].device)).abs().max()))
+    assert moved > 0
