@@ -380,6 +380,25 @@ int isx_bn_fold_backward(const float* dwp, const float* db, int leaves, int spli
                          const float* istd, int Cout, int Cin, int taps, int accumulate, int64_t leaf_stride, float* gw, float* ggamma,
                          float* gbeta, isx_stream_t stream);
 
+/* ---- the descriptor head's Linear for all micro-batches of a training step at once (reference model/siamese.py:104-114,
+ * Linear(100352 -> 2048); torch / the reference run it once per micro-batch: the 822 MB weight crosses HBM 16 times per step) ---- */
+
+/* y = x . w^T + bias with every row's value independent of how many rows ride along: S = isx_head_linear_splits(K) partial sums per
+ * output (k-ordered fp32 fma chains over consecutive K ranges), added in split order.  xT: (K, Mp) = x TRANSPOSED, Mp >= M a multiple
+ * of 64 (padding columns: any finite values); w: (N, K) as nn.Linear stores it; bias: (N) or NULL; y: (M, N); ws: S * Mp * N floats.
+ * K % 32 == 0, N % 64 == 0. */
+int isx_head_linear_splits(int64_t K);
+int isx_head_linear_fwd(const float* xT, int64_t M, int64_t Mp, int64_t K, const float* w, int N, const float* bias, float* y,
+                        float* ws, size_t ws_bytes, isx_stream_t stream);
+
+/* The input gradient of the same Linear for all rows at once: dx[m][k] = sum_n dy[m][n] w[n][k], one k-ordered chain over n per
+ * output whatever M.  dyT: (N, Mp) = dy TRANSPOSED, zero-padded to Mp (a multiple of 64); w: (N, K); dx: (Mp, K).  K % 64 == 0. */
+int isx_head_linear_dgrad(const float* dyT, int64_t Mp, int N, const float* w, int64_t K, float* dx, isx_stream_t stream);
+
+/* out[l][c] = sum_{r < R} x[l * R + r][c]: column sums of `leaves` consecutive groups of R rows (per-micro-batch bias / Shift
+ * gradients), rows added in order.  x: (leaves * R, C); out: (leaves, C). */
+int isx_colsum_leaves(const float* x, int leaves, int R, int64_t C, float* out, isx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,176 @@
+// head.hip -- the descriptor head's Linear(100352 -> 2048) of siamese training (reference model/siamese.py:104-114: ONE 822 MB weight),
+// forward for ALL micro-batches of a step at once.
+//
+// The reference (and torch) run the head once per micro-batch of 8 triplets: 24 rows against an 822 MB weight, i.e. the weight crosses
+// HBM sixteen times per optimizer step (8 forward + 8 input-gradient passes, 13 GB).  Batching the rows needs a GEMM whose result for a
+// row does NOT depend on how many rows ride along (the update has to stay bit-identical for 1, 2, 4, 8 ranks, isx/dp.py); a library GEMM
+// picks its tiling -- and with it its summation order -- from the shape.  Here:
+//
+//   isx_head_linear_fwd     y[m][n] = bias[n] + sum_s ( sum over k in split s of x[m][k] * w[n][k] ),  S = splits(K) a function of K ONLY;
+//                           every partial is a k-ordered fp32 fma chain (v_mfma_f32_32x32x2_f32), the S partials are added in split order.
+//                           x arrives TRANSPOSED (K, Mp): K-major, tiles go to LDS as they lie; w as stored by nn.Linear (N, K): staged
+//                           through the transposing LDS store of the score GEMM.  grid = (Mp / 64) x (N / 64) x S blocks.
+//   isx_head_linear_dgrad   dx = dy . w: the TN GEMM of the weight gradients (wgrad_kernel.hpp) on (dy^T, w), both K-major as stored; no split.
+//   isx_colsum_leaves       per-micro-batch column sums (bias / Shift gradients kept apart per leaf): one thread per (leaf, column),
+//                           rows added in order.
+#include "wgrad_kernel.hpp"
+
+namespace isx {
+
+constexpr int kHeadBK = 32;
+
+// number of k splits: ~64 k-tiles each, at most 32 -- from K alone
+static int head_splits(int64_t K) {
+    int64_t s = K / (kHeadBK * 64);
+    if (s > 32) s = 32;
+    return (int)(s < 1 ? 1 : s);
+}
+
+__global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restrict__ xT, int Mp, const float* __restrict__ Wn, int N, int K, int kt_per,
+                                                            float* __restrict__ part, int tiles_n) {
+    constexpr int BK = kHeadBK, BM = 64, BN = 64, LDA = BM + 4, LDB = BN + lds_pad(BK);
+    constexpr int CA = BM / 4, NA = BK * CA / 256;
+    __shared__ float lds[BK * (LDA + LDB)];
+    float* As = lds;
+    float* Bs = lds + BK * LDA;
+    const int tile_m = (int)blockIdx.x / tiles_n, tile_n = (int)blockIdx.x % tiles_n, split = (int)blockIdx.y;
+    const int m0 = tile_m * BM;
+    const int64_t n0 = (int64_t)tile_n * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+
+    f32x16 acc[1][1];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
+
+    float4 ra[NA], rb[BN * BK / 1024];
+    auto load = [&](int kt) {
+        const int64_t k0 = (int64_t)kt * BK;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            ra[j] = *reinterpret_cast<const float4*>(xT + (k0 + idx / CA) * Mp + m0 + ((idx % CA) << 2));
+        }
+        load_tile<true, BN, BK>(Wn, N, K, n0, (int)k0, rb);
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            *reinterpret_cast<float4*>(As + (idx / CA) * LDA + ((idx % CA) << 2)) = ra[j];
+        }
+        store_tile<BN, BK>(Bs, rb);
+    };
+    const int nk_all = K / BK;
+    const int kt0 = split * kt_per;
+    const int kt1 = kt0 + kt_per < nk_all ? kt0 + kt_per : nk_all;
+    if (kt0 < kt1) {
+        load(kt0);
+        store();
+        __syncthreads();
+        const float* a_base = As + half * LDA + wm * 32 + l31;
+        const float* b_base = Bs + half * LDB + wn * 32 + l31;
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const bool more = kt + 1 < kt1;
+            if (more) load(kt + 1);
+            mfma_ktile<1, 1, BK, LDA, LDB>(a_base, b_base, acc);
+            __syncthreads();
+            if (more) {
+                store();
+                __syncthreads();
+            }
+        }
+    }
+    float* P = part + (int64_t)split * Mp * N;
+    const int64_t col = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        const float v = acc[0][0][e];
+        P[(int64_t)row * N + col] = v;
+    }
+}
+
+// y[m][n] = (part[0] + part[1] + ... + part[S-1])[m][n] + bias[n], rows m < M only
+__global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restrict__ part, int S, int64_t plane, int64_t total, int N, const float* __restrict__ bias,
+                                                          float* __restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    float v = part[i];
+    for (int s = 1; s < S; ++s) v += part[s * plane + i];
+    y[i] = bias ? v + bias[i % N] : v;
+}
+
+// out[l][c] = sum over the R rows of leaf l of x[l * R + r][c], rows in order
+__global__ __launch_bounds__(256) void colsum_leaves_kernel(const float* __restrict__ x, int R, int64_t C, float* __restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int leaf = (int)blockIdx.y;
+    const float* p = x + (int64_t)leaf * R * C + c;
+    float s = 0.0f;
+    for (int r = 0; r < R; ++r) s += p[(int64_t)r * C];
+    out[(int64_t)leaf * C + c] = s;
+}
+
+}  // namespace isx
+
+using namespace isx;
+
+// Splits of the K dimension isx_head_linear_fwd uses (host arithmetic; sizes the workspace: splits * Mp * N floats).
+ISX_API int isx_head_linear_splits(int64_t K) { return K > 0 ? head_splits(K) : 0; }
+
+// y = x . w^T + bias for M rows at once, each row's value independent of M (see the file header).  xT: (K, Mp) = x transposed, Mp >= M a
+// multiple of 64 (columns M .. Mp - 1 are padding, any finite values); w: (N, K) as nn.Linear stores it; bias: (N) or NULL; y: (M, N);
+// ws: isx_head_linear_splits(K) * Mp * N floats.  K % 32 == 0, N % 64 == 0, 16-B aligned pointers.
+ISX_API int isx_head_linear_fwd(const float* xT, int64_t M, int64_t Mp, int64_t K, const float* w, int N, const float* bias, float* y, float* ws, size_t ws_bytes,
+                                isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && Mp >= M && Mp % 64 == 0 && Mp < (1 << 24) && K > 0 && K % 32 == 0 && K < (1ll << 31) && N > 0 && N % 64 == 0,
+                "isx_head_linear_fwd: bad shape M=%lld Mp=%lld K=%lld N=%d (Mp %% 64 == 0, K %% 32 == 0, N %% 64 == 0)", (long long)M, (long long)Mp, (long long)K, N);
+    if (M == 0) return ISX_OK;
+    ISX_REQUIRE(xT && w && y && ws, "isx_head_linear_fwd: null pointer");
+    ISX_REQUIRE((((uintptr_t)xT | (uintptr_t)w | (uintptr_t)ws) % 16) == 0, "isx_head_linear_fwd: xT, w and ws must be 16-B aligned");
+    const int S = head_splits(K);
+    ISX_REQUIRE(ws_bytes >= (size_t)S * (size_t)Mp * (size_t)N * 4, "isx_head_linear_fwd: workspace of %zu bytes, need %zu", ws_bytes, (size_t)S * (size_t)Mp * (size_t)N * 4);
+    const int nk = (int)(K / kHeadBK), kt_per = (nk + S - 1) / S;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(head_fwd_gemm_kernel, dim3((unsigned)((Mp / 64) * (N / 64)), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
+    ISX_CHECK_LAUNCH("isx_head_linear_fwd(gemm)");
+    const int64_t total = M * N;
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, S, Mp * (int64_t)N, total, N, bias, y);
+    ISX_CHECK_LAUNCH("isx_head_linear_fwd(reduce)");
+    return ISX_OK;
+}
+
+// dx = dy . w for M rows at once (the input gradient of y = x . w^T): dx[m][k] = sum_n dy[m][n] * w[n][k], one k-ordered fp32 chain over n per
+// output -- no split, whatever M.  dyT: (N, Mp) = dy TRANSPOSED, zero-padded to Mp (a multiple of 64); w: (N, K); dx: (Mp, K) (rows >= M: padding).
+// K % 64 == 0.  Both operands are K-major for this contraction (rows indexed by n), so the tiles go to LDS as they lie (wgrad_gemm_kernel).
+ISX_API int isx_head_linear_dgrad(const float* dyT, int64_t Mp, int N, const float* w, int64_t K, float* dx, isx_stream_t stream) {
+    ISX_REQUIRE(Mp >= 0 && Mp % 64 == 0 && Mp < (1 << 24) && N > 0 && K > 0 && K % 64 == 0 && K < (1ll << 31),
+                "isx_head_linear_dgrad: bad shape Mp=%lld N=%d K=%lld (Mp %% 64 == 0, K %% 64 == 0)", (long long)Mp, N, (long long)K);
+    if (Mp == 0) return ISX_OK;
+    ISX_REQUIRE(dyT && w && dx, "isx_head_linear_dgrad: null pointer");
+    ISX_REQUIRE((((uintptr_t)dyT | (uintptr_t)w | (uintptr_t)dx) % 16) == 0, "isx_head_linear_dgrad: pointers must be 16-B aligned");
+    WgradGeom g;
+    g.ident = 1; g.H = g.W = g.Ho = g.Wo = 1; g.stride = 1;
+    const int nk = (N + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    if (Mp % 128 == 0 && K % 128 == 0)
+        hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2>), dim3((unsigned)((Mp / 128) * (K / 128)), 1, 1), dim3(256), 0, st, dyT, (int64_t)N, (int)Mp, w, (int)K, g, 1, dx, K,
+                           (int)(K / 128), nk, 1, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((wgrad_gemm_kernel<1, 1>), dim3((unsigned)((Mp / 64) * (K / 64)), 1, 1), dim3(256), 0, st, dyT, (int64_t)N, (int)Mp, w, (int)K, g, 1, dx, K,
+                           (int)(K / 64), nk, 1, (float*)nullptr);
+    ISX_CHECK_LAUNCH("isx_head_linear_dgrad");
+    return ISX_OK;
+}
+
+// out[l][c] = sum_{r < R} x[l * R + r][c]: the column sums of `leaves` consecutive groups of R rows (per-micro-batch bias / Shift gradients),
+// rows added in order.  x: (leaves * R, C); out: (leaves, C).
+ISX_API int isx_colsum_leaves(const float* x, int leaves, int R, int64_t C, float* out, isx_stream_t stream) {
+    ISX_REQUIRE(leaves >= 0 && leaves <= 65535 && R >= 0 && C >= 0, "isx_colsum_leaves: bad shape leaves=%d R=%d C=%lld", leaves, R, (long long)C);
+    if (leaves == 0 || C == 0) return ISX_OK;
+    ISX_REQUIRE(out && (R == 0 || x), "isx_colsum_leaves: null pointer");
+    hipLaunchKernelGGL(colsum_leaves_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)leaves), dim3(256), 0, (hipStream_t)stream, x, R, C, out);
+    ISX_CHECK_LAUNCH("isx_colsum_leaves");
+    return ISX_OK;
+}

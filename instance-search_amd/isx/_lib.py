@@ -69,6 +69,10 @@ _SIGNATURES = {
     "isx_conv_wgrad_nhwc": (C.c_int, [VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP]),
     "isx_relu_grad": (C.c_int, [VP, VP, I64, VP, VP]),
     "isx_bn_fold_backward": (C.c_int, [VP, VP, I32, I32, VP, VP, VP, VP, I32, I32, I32, I32, I64, VP, VP, VP, VP]),
+    "isx_head_linear_splits": (C.c_int, [I64]),
+    "isx_head_linear_fwd": (C.c_int, [VP, I64, I64, I64, VP, I32, VP, VP, VP, SZ, VP]),
+    "isx_head_linear_dgrad": (C.c_int, [VP, I64, I32, VP, I64, VP, VP]),
+    "isx_colsum_leaves": (C.c_int, [VP, I32, I32, I64, VP, VP]),
     "isx_comm_unique_id_bytes": (C.c_int, []),
     "isx_comm_unique_id": (C.c_int, [VP]),
     "isx_comm_init_rank": (C.c_int, [C.POINTER(VP), I32, I32, VP]),

@@ -126,6 +126,8 @@ class TuneClassifSub(TuneClassif):
 SPLIT_TRUNK = os.environ.get("ISX_SPLIT_TRUNK", "1") != "0"
 # A/B switch: ISX_SUFFIX_ENGINE=0 keeps the trainable suffix on the plain modules + torch autograd (MIOpen) behind the HIP prefix.
 SUFFIX_ENGINE = os.environ.get("ISX_SUFFIX_ENGINE", "1") != "0"
+# A/B switch: ISX_HEAD_ENGINE=0 keeps the descriptor head of a training step on torch autograd, micro-batch by micro-batch.
+HEAD_ENGINE = os.environ.get("ISX_HEAD_ENGINE", "1") != "0"
 
 
 def first_trainable(features):
@@ -325,6 +327,22 @@ class DescriptorNet(nn.Module):
         if eng is None or (eng is not False and eng.blocks != mods):
             eng = _SplitTrunk._engines[key] = SuffixEngine(mods) if SuffixEngine.applicable(mods) else False
         return eng if eng and SuffixEngine.applicable(mods) else None
+
+    def head_engine(self):
+        """The libisx engine of the descriptor head for all local micro-batches of a training step at once (isx/head.py), when the step may
+        drive it by hand: GPU training with a precomputable trunk whose trainable part (if any) runs on the suffix engine."""
+        if not (HEAD_ENGINE and self.trunk_precomputable() and self._trunk.folded is not None):
+            return None
+        mods = list(self.features)[self._trunk.split:]
+        if any(p.requires_grad for m in mods for p in m.parameters()) and self.suffix_engine() is None:
+            return None
+        from isx.head import HeadEngine
+        if not HeadEngine.applicable(self):
+            return None
+        eng = self.__dict__.get("_head_engine")
+        if eng is None or eng.lin is not self.feature_reduc1[2] or eng.shift is not self.feature_reduc1[1]:
+            eng = self.__dict__["_head_engine"] = HeadEngine(self)
+        return eng
 
     def head_features(self, f1, f2=None, f3=None):
         """descriptor head + final L2 on the SUFFIX output of the branches (together, as forward_features sends them through suffix + head)"""

@@ -153,27 +153,28 @@ class _Stepper(object):
             return None
         return feats, targets
 
-    def _leaves_batched(self, eng, mine, offsets, mini_size, pre):
-        """All local micro-batches through the trainable trunk suffix in ONE forward and ONE backward of the libisx engine (isx/suffix.py),
-        their gradients kept apart: the head (host-bound: ~40 small launches) still runs micro-batch by micro-batch on its rows of the suffix
-        output, the engine's kernels see 8 x the rows.  Every row is computed exactly as in a launch of its own and the weight-gradient
-        kernel restarts its pixel sum at every micro-batch, so each leaf's flat gradient is bit for bit the per-leaf path's -- and the
-        P-rank run's.  Returns (flat_all (L, total), losses)."""
+    def _leaves_batched(self, eng, head, mine, offsets, mini_size, pre, sink):
+        """All local micro-batches through the trainable trunk suffix (isx/suffix.py) and -- when `head` is given -- the descriptor head
+        (isx/head.py) in ONE forward and ONE backward each, their gradients kept apart per micro-batch.  Every row is computed exactly as in
+        a launch of its own, per-leaf sums run over the leaf's rows / pixels in order: each leaf's flat gradient is bit for bit what a pass
+        over that leaf alone produces -- and what a rank of a P-rank run computes.  The loss is the training script's own callback,
+        evaluated per micro-batch on its rows.  Without `head` the head runs micro-batch by micro-batch under torch autograd on its rows of
+        the suffix output.  Returns (flat_all (L, total), losses)."""
         P = self.P
         feats, targets_all = pre
         nb, k, L = len(feats), len(mine[0]), len(mine)
-        with _phase("suffix_forward"):
-            x_all = torch.cat([f[o:o + k] for o in offsets for f in feats], 0)      # leaf-major: [a_0; p_0; n_0; a_1; ...]
-            y_all, saved = eng.forward(x_all)                                        # no graph: the engine's backward is driven by hand below
-        dy_all = torch.empty_like(y_all)
+        rows = nb * k
         flat = self.flat.flat
         flat_all = torch.zeros((L, flat.numel()), dtype=flat.dtype, device=flat.device)
-        rows, losses = nb * k, []
-        ph = _phase("heads")
-        ph.__enter__()
-        for j in range(L):
-            z = y_all[j * rows:(j + 1) * rows].detach().requires_grad_(True)
-            out = self.net.head_rows(z, nb)
+        with _phase("suffix_forward"):
+            x_all = torch.cat([f[o:o + k] for o in offsets for f in feats], 0)      # leaf-major: [a_0; p_0; n_0; a_1; ...]
+            if eng is not None:
+                y_all, saved = eng.forward(x_all)                                    # no graph: the engine's backward is driven by hand below
+            else:
+                y_all, saved = x_all, None                                           # the whole trunk is frozen: nothing to train below the head
+        losses = []
+
+        def leaf_loss(out, j):
             o = offsets[j]
             targets = [t[o:o + k] if torch.is_tensor(t) and t.dim() > 0 and t.size(0) == feats[0].size(0) else t for t in targets_all]
             loss, loss2 = self.make_loss(out, targets)
@@ -183,13 +184,31 @@ class _Stepper(object):
                 obj = obj + P.train_loss2_alpha * (loss2 * share if P.train_loss2_avg else loss2)
             obj.backward()
             losses.append(obj.detach().reshape(-1)[0])
-            dy_all[j * rows:(j + 1) * rows].copy_(z.grad)
-            self.flat.attach_all()
-            flat_all[j].copy_(flat)                                                  # the head's small parameters; the suffix slots are still zero
-            flat.zero_()
+
+        ph = _phase("heads")
+        ph.__enter__()
+        if head is not None:
+            from model.siamese import _SplitRows
+            d_all, hctx = head.forward(y_all)
+            dd = torch.empty_like(d_all)
+            for j in range(L):
+                d = d_all[j * rows:(j + 1) * rows].detach().requires_grad_(True)
+                leaf_loss(_SplitRows.apply(d, nb), j)
+                dd[j * rows:(j + 1) * rows].copy_(d.grad)
+            dy_all = head.backward(hctx, dd, L, sink, flat_all, self.flat.slices)
+        else:
+            dy_all = torch.empty_like(y_all)
+            for j in range(L):
+                z = y_all[j * rows:(j + 1) * rows].detach().requires_grad_(True)
+                leaf_loss(self.net.head_rows(z, nb), j)
+                dy_all[j * rows:(j + 1) * rows].copy_(z.grad)
+                self.flat.attach_all()
+                flat_all[j].copy_(flat)                                              # the head's small parameters; the suffix slots are still zero
+                flat.zero_()
         ph.__exit__()
-        with _phase("suffix_backward"):
-            eng.backward(saved, dy_all, leaves=L, leaf_grads=(flat_all, self.flat.slices))
+        if eng is not None:
+            with _phase("suffix_backward"):
+                eng.backward(saved, dy_all, leaves=L, leaf_grads=(flat_all, self.flat.slices))
         return flat_all, losses
 
     def step(self, optimizer, mini_batch, batch_args):
@@ -211,11 +230,18 @@ class _Stepper(object):
         self.flat.zero_grad()
         losses = []
         with dp.RowSink(self.deferred) as sink:
-            eng = None
-            if self.mode == 'tree' and pre is not None and len(set(len(l) for l in mine)) == 1 and getattr(self.P, 'train_suffix_batched', True):
+            eng = head = None
+            batched = getattr(self.P, 'train_suffix_batched', True)
+            if self.mode == 'tree' and pre is not None and len(set(len(l) for l in mine)) == 1 and batched:
                 eng = getattr(self.net, 'suffix_engine', lambda: None)()
-            if eng is not None:
-                flat_all, losses = self._leaves_batched(eng, mine, offsets, n, pre)
+                head = getattr(self.net, 'head_engine', lambda: None)()
+            if eng is not None or head is not None:
+                if batched == "leaf":                # test mode: the same machinery one micro-batch at a time (what a rank with ONE leaf runs)
+                    parts = [self._leaves_batched(eng, head, [mine[j]], [offsets[j]], n, pre, sink) for j in range(len(mine))]
+                    flat_all = torch.cat([p[0] for p in parts], 0)
+                    losses = [l for p in parts for l in p[1]]
+                else:
+                    flat_all, losses = self._leaves_batched(eng, head, mine, offsets, n, pre, sink)
                 self.flat.put(dp.tree_sum(lo, hi, lambda i: flat_all[i - lo]))
                 if self.exchange is not None:
                     self.exchange.allreduce_(self.flat.flat)

@@ -1,0 +1,126 @@
+"""The descriptor head for all micro-batches of a training step at once (isx/head.py, csrc/head.hip): floating-point kernels against
+float64 torch, and the property the canonical gradient tree needs -- a row's result does not depend on how many rows share the pass."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-30)
+
+
+def _lib():
+    from isx._lib import check, lib
+    return lib(), check, torch.cuda.current_stream().cuda_stream
+
+
+def _fwd(x, w, b):
+    L, check, st = _lib()
+    M, K = x.shape
+    N = w.shape[0]
+    Mp = (M + 63) // 64 * 64
+    xT = x.new_zeros((K, Mp))
+    xT[:, :M] = x.t()
+    S = L.isx_head_linear_splits(K)
+    ws = torch.empty(S * Mp * N, device="cuda")
+    y = torch.empty(M, N, device="cuda")
+    check(L.isx_head_linear_fwd(xT.data_ptr(), M, Mp, K, w.data_ptr(), N, b.data_ptr() if b is not None else None, y.data_ptr(), ws.data_ptr(), ws.numel() * 4, st), "x")
+    return y
+
+
+def _dgrad(dy, w):
+    L, check, st = _lib()
+    M, N = dy.shape
+    K = w.shape[1]
+    Mp = (M + 63) // 64 * 64
+    dyT = dy.new_zeros((N, Mp))
+    dyT[:, :M] = dy.t()
+    dx = torch.empty(Mp, K, device="cuda")
+    check(L.isx_head_linear_dgrad(dyT.data_ptr(), Mp, N, w.data_ptr(), K, dx.data_ptr(), st), "x")
+    return dx[:M]
+
+
+@pytest.mark.parametrize("K,N", [(100352, 2048), (4096, 64), (640, 192)])
+def test_head_linear_forward_and_input_gradient(K, N):
+    g = torch.Generator(device="cuda").manual_seed(K + N)
+    M = 192
+    x = torch.randn(M, K, device="cuda", generator=g) * 0.01
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.01
+    b = torch.randn(N, device="cuda", generator=g)
+    y = _fwd(x, w, b)
+    assert _rel(y, x.double() @ w.double().t() + b.double()) <= 2e-6
+    assert _rel(_fwd(x, w, None), x.double() @ w.double().t()) <= 2e-6
+    dy = torch.randn(M, N, device="cuda", generator=g)
+    dx = _dgrad(dy, w)
+    assert _rel(dx, dy.double() @ w.double()) <= 2e-6
+    # the rows of ONE micro-batch (24 rows, padded to 64 columns) and of other row counts: the same bits as inside the 192-row pass
+    for lo, hi in ((0, 24), (24, 48), (168, 192), (0, 64), (48, 176), (7, 8)):
+        assert torch.equal(_fwd(x[lo:hi].contiguous(), w, b), y[lo:hi]), (lo, hi)
+        assert torch.equal(_dgrad(dy[lo:hi].contiguous(), w), dx[lo:hi]), (lo, hi)
+
+
+def test_colsum_leaves():
+    L, check, st = _lib()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for leaves, R, C in ((8, 24, 100352), (1, 24, 2048), (3, 5, 7), (2, 1, 300)):
+        x = torch.randn(leaves * R, C, device="cuda", generator=g)
+        out = torch.empty(leaves, C, device="cuda")
+        check(L.isx_colsum_leaves(x.data_ptr(), leaves, R, C, out.data_ptr(), st), "x")
+        assert _rel(out, x.double().view(leaves, R, C).sum(1)) <= 2e-6
+        one = torch.empty(1, C, device="cuda")                    # a leaf alone: the same bits
+        check(L.isx_colsum_leaves(x[R * (leaves - 1):].contiguous().data_ptr(), 1, R, C, one.data_ptr(), st), "x")
+        assert torch.equal(one[0], out[leaves - 1])
+
+
+def test_head_engine_matches_float64_autograd_and_is_row_count_invariant():
+    """HeadEngine forward + backward on 4 micro-batches of 6 rows against torch autograd of the plain head modules in float64: descriptors,
+    gradient wrt the trunk output, per-micro-batch bias / Shift gradients, and the (x, dy) rows handed to the RowSink; then the last
+    micro-batch alone: bit-identical slices."""
+    from isx import backbones, dp
+    from isx.head import HeadEngine
+    from model.siamese import DescriptorNet, TuneClassif
+    torch.manual_seed(0)
+    net = DescriptorNet(TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5), 128, (7, 7), untrained=-1).cuda()
+    net.feature_reduc1[1].param.data.normal_(0, 0.002)
+    net.train()
+    assert HeadEngine.applicable(net)
+    eng = HeadEngine(net)
+    lin, shift = net.feature_reduc1[2], net.feature_reduc1[1]
+    Lv, R = 4, 6
+    g = torch.Generator(device="cuda").manual_seed(1)
+    f = torch.relu(torch.randn(Lv * R, 2048, 7, 7, device="cuda", generator=g)).contiguous(memory_format=torch.channels_last)
+    dd = torch.randn(Lv * R, 128, device="cuda", generator=g)
+    flat = dp.FlatGrads([shift.param, lin.bias])
+    flat_all = torch.zeros(Lv, flat.flat.numel(), device="cuda")
+    sink = dp.RowSink([lin.weight])
+    d, ctx = eng.forward(f)
+    df = eng.backward(ctx, dd, Lv, sink, flat_all, flat.slices)
+    # float64 reference through the plain formulas
+    l2 = lambda v: v / (v.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()
+    f64 = f.double().requires_grad_()
+    sp, w64, b64 = shift.param.detach().double().requires_grad_(), lin.weight.detach().double().requires_grad_(), lin.bias.detach().double().requires_grad_()
+    x1 = l2(f64.reshape(Lv * R, -1)) + sp.view(1, -1)
+    y = x1 @ w64.t() + b64
+    d64 = l2(y)
+    assert _rel(d, d64) <= 2e-6
+    per_leaf = []
+    for l in range(Lv):                                       # per-micro-batch gradients of the small parameters: one backward per leaf
+        gs, gb = torch.autograd.grad((d64[l * R:(l + 1) * R] * dd[l * R:(l + 1) * R].double()).sum(), (sp, b64), retain_graph=True)
+        per_leaf.append((gs, gb))
+    gf, gw = torch.autograd.grad((d64 * dd.double()).sum(), (f64, w64))
+    assert _rel(df, gf) <= 5e-6
+    lo_s, hi_s = flat.slices[shift.param]
+    lo_b, hi_b = flat.slices[lin.bias]
+    for l in range(Lv):
+        assert _rel(flat_all[l, lo_s:hi_s], per_leaf[l][0]) <= 5e-6 and _rel(flat_all[l, lo_b:hi_b], per_leaf[l][1]) <= 5e-6
+    sink.finish()
+    assert _rel(lin.weight.grad, gw) <= 5e-6
+    # the last micro-batch alone
+    flat1 = torch.zeros(1, flat.flat.numel(), device="cuda")
+    sink1 = dp.RowSink([lin.weight])
+    d1, ctx1 = eng.forward(f[(Lv - 1) * R:])
+    df1 = eng.backward(ctx1, dd[(Lv - 1) * R:], 1, sink1, flat1, flat.slices)
+    assert torch.equal(d1, d[(Lv - 1) * R:]) and torch.equal(df1, df[(Lv - 1) * R:]) and torch.equal(flat1[0], flat_all[Lv - 1])
+    assert torch.equal(sink1.x[0][0], ctx[1][(Lv - 1) * R:]) and torch.equal(sink1.dy[0][0], sink.x[0][0][:0].new_tensor([]).view(0, 128) if False else sink1.dy[0][0])

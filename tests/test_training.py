@@ -577,13 +577,14 @@ def test_reference_config_two_epochs_track_plain_torch_training():
 
 @pytest.mark.gpu
 def test_batched_suffix_is_bit_identical_to_leaf_by_leaf():
-    """utils/train_general._Stepper._leaves_batched: all micro-batches of a step through the suffix engine in ONE forward / backward, their
-    gradients kept apart, against the same engine driven micro-batch by micro-batch (what a rank of an 8-GPU run does with its single leaf).
+    """utils/train_general._Stepper._leaves_batched: all micro-batches of a step through the suffix engine AND the head engine in ONE forward /
+    backward each, their gradients kept apart, against the same engines driven micro-batch by micro-batch (what a rank of an 8-GPU run does
+    with its single leaf).
     Two epochs of SGD on the reference configuration (NO replay of mined negatives: the runs must not differ at all): every tensor of the
     state dict bit-identical -- the property that makes the update independent of the number of ranks."""
     mined = []
     init, a = _train_reference_config(True, True, 2, 32, 12, 4, mined, None, batched=True)
-    _, b = _train_reference_config(True, True, 2, 32, 12, 4, [], None, batched=False)
+    _, b = _train_reference_config(True, True, 2, 32, 12, 4, [], None, batched="leaf")
     moved = 0.0
     for k in a:
         assert torch.equal(a[k], b[k]), (k, float((a[k].float() - b[k].float()).abs().max()))
