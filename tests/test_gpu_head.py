@@ -54,7 +54,7 @@ def test_head_linear_forward_and_input_gradient(K, N):
     assert _rel(_fwd(x, w, None), x.double() @ w.double().t()) <= 2e-6
     dy = torch.randn(M, N, device="cuda", generator=g)
     dx = _dgrad(dy, w)
-    assert _rel(dx, dy.double() @ w.double()) <= 2e-6
+    assert _rel(dx, dy.double() @ w.double()) <= 5e-6                 # one k-ordered fp32 chain over N = 2048 terms per output
     # the rows of ONE micro-batch (24 rows, padded to 64 columns) and of other row counts: the same bits as inside the 192-row pass
     for lo, hi in ((0, 24), (24, 48), (168, 192), (0, 64), (48, 176), (7, 8)):
         assert torch.equal(_fwd(x[lo:hi].contiguous(), w, b), y[lo:hi]), (lo, hi)
@@ -123,4 +123,4 @@ def test_head_engine_matches_float64_autograd_and_is_row_count_invariant():
     d1, ctx1 = eng.forward(f[(Lv - 1) * R:])
     df1 = eng.backward(ctx1, dd[(Lv - 1) * R:], 1, sink1, flat1, flat.slices)
     assert torch.equal(d1, d[(Lv - 1) * R:]) and torch.equal(df1, df[(Lv - 1) * R:]) and torch.equal(flat1[0], flat_all[Lv - 1])
-    assert torch.equal(sink1.x[0][0], ctx[1][(Lv - 1) * R:]) and torch.equal(sink1.dy[0][0], sink.x[0][0][:0].new_tensor([]).view(0, 128) if False else sink1.dy[0][0])
+    assert torch.equal(sink1.x[0][0], ctx[1][(Lv - 1) * R:])          # the rows handed to the sink are the rows of the big pass
