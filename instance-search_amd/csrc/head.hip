@@ -26,9 +26,12 @@ static int head_splits(int64_t K) {
     return (int)(s < 1 ? 1 : s);
 }
 
+// TM: 32-row MFMA tiles per wave along M (block tile 64 TM x 64).  TM = 2 / 3 cover Mp = 128 / 192 rows with ONE m-tile, so the weight is
+// read once instead of once per 64 rows; the tile shape only groups outputs, every output is the same chain in any of them.
+template <int TM>
 __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restrict__ xT, int Mp, const float* __restrict__ Wn, int N, int K, int kt_per,
                                                             float* __restrict__ part, int tiles_n) {
-    constexpr int BK = kHeadBK, BM = 64, BN = 64, LDA = BM + 4, LDB = BN + lds_pad(BK);
+    constexpr int BK = kHeadBK, BM = 64 * TM, BN = 64, LDA = BM + 4, LDB = BN + lds_pad(BK);
     constexpr int CA = BM / 4, NA = BK * CA / 256;
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
@@ -39,9 +42,11 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
 
-    f32x16 acc[1][1];
+    f32x16 acc[TM][1];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[0][0][e] = 0.0f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.0f;
 
     float4 ra[NA], rb[BN * BK / 1024];
     auto load = [&](int kt) {
@@ -68,12 +73,12 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restr
         load(kt0);
         store();
         __syncthreads();
-        const float* a_base = As + half * LDA + wm * 32 + l31;
+        const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
         const float* b_base = Bs + half * LDB + wn * 32 + l31;
         for (int kt = kt0; kt < kt1; ++kt) {
             const bool more = kt + 1 < kt1;
             if (more) load(kt + 1);
-            mfma_ktile<1, 1, BK, LDA, LDB>(a_base, b_base, acc);
+            mfma_ktile<TM, 1, BK, LDA, LDB>(a_base, b_base, acc);
             __syncthreads();
             if (more) {
                 store();
@@ -84,11 +89,13 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restr
     float* P = part + (int64_t)split * Mp * N;
     const int64_t col = n0 + wn * 32 + l31;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        const float v = acc[0][0][e];
-        P[(int64_t)row * N + col] = v;
-    }
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+            const float v = acc[i][0][e];
+            P[(int64_t)row * N + col] = v;
+        }
 }
 
 // y[m][n] = (part[0] + part[1] + ... + part[S-1])[m][n] + bias[n], rows m < M only
@@ -133,7 +140,12 @@ ISX_API int isx_head_linear_fwd(const float* xT, int64_t M, int64_t Mp, int64_t 
     ISX_REQUIRE(ws_bytes >= (size_t)S * (size_t)Mp * (size_t)N * 4, "isx_head_linear_fwd: workspace of %zu bytes, need %zu", ws_bytes, (size_t)S * (size_t)Mp * (size_t)N * 4);
     const int nk = (int)(K / kHeadBK), kt_per = (nk + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(head_fwd_gemm_kernel, dim3((unsigned)((Mp / 64) * (N / 64)), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
+    if (Mp == 192)
+        hipLaunchKernelGGL(head_fwd_gemm_kernel<3>, dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
+    else if (Mp == 128)
+        hipLaunchKernelGGL(head_fwd_gemm_kernel<2>, dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
+    else
+        hipLaunchKernelGGL(head_fwd_gemm_kernel<1>, dim3((unsigned)((Mp / 64) * (N / 64)), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
     ISX_CHECK_LAUNCH("isx_head_linear_fwd(gemm)");
     const int64_t total = M * N;
     hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, S, Mp * (int64_t)N, total, N, bias, y);
@@ -154,7 +166,10 @@ ISX_API int isx_head_linear_dgrad(const float* dyT, int64_t Mp, int N, const flo
     g.ident = 1; g.H = g.W = g.Ho = g.Wo = 1; g.stride = 1;
     const int nk = (N + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
-    if (Mp % 128 == 0 && K % 128 == 0)
+    if (Mp == 192)            // all rows in ONE 192 x 64 tile: the weight is read once
+        hipLaunchKernelGGL((wgrad_gemm_kernel<3, 1>), dim3((unsigned)(K / 64), 1, 1), dim3(256), 0, st, dyT, (int64_t)N, (int)Mp, w, (int)K, g, 1, dx, K,
+                           (int)(K / 64), nk, 1, (float*)nullptr);
+    else if (Mp % 128 == 0 && K % 128 == 0)
         hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2>), dim3((unsigned)((Mp / 128) * (K / 128)), 1, 1), dim3(256), 0, st, dyT, (int64_t)N, (int)Mp, w, (int)K, g, 1, dx, K,
                            (int)(K / 128), nk, 1, (float*)nullptr);
     else
