@@ -623,3 +623,33 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
         if a[k].dtype.is_floating_point:
             moved = max(moved, float((a[k] - init[k].to(a[k].device)).abs().max()))
     assert moved > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,fs,size", [("alexnet", (6, 6), 288), ("resnet50", (7, 7), 288)])
+def test_region_training_runs_on_gpu(model, fs, size):
+    """siamese_regions training (reference train/siamese_regions.py: triplet + window classification loss, micro-batch 1, the head shared by
+    the k windows of an image) on the GPU: the region kernels on the no-graph side, autograd on the training side, the row-deferred head
+    gradient collecting the rows of every window -- runs, and the trainable parameters receive gradients."""
+    import copy
+    from train import siamese_regions as sr
+    from utils.dataset import synthetic_image_set
+    saved = copy.copy(sr.P.__dict__)
+    try:
+        torch.manual_seed(0); random.seed(0)
+        P = sr.P
+        P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim, P.regions_k = 0, model, fs, 16, 3
+        P.train_epochs, P.train_batch_size, P.test_batch_size, P.train_loss_int = 1, 4, 4, 1000
+        P.untrained_blocks = None                                  # the reference's table
+        # (a seeded random-init ResNet-50 with identity BatchNorm statistics has activations of size 1e3 at layer4: its class-score loss needs a
+        # tiny step to stay finite -- the test is about the plumbing, not about learning on noise)
+        P.train_lr, P.train_epoch_switch = (1e-3 if model == "alexnet" else 1e-9), 1
+        tr = synthetic_image_set(8, 2, size=(3, size, size), seed=1)
+        te = synthetic_image_set(4, 2, size=(3, size, size), seed=2)
+        net, score = sr.main(tr, tr, te)
+        assert next(net.parameters()).is_cuda and score >= 0
+        lin = net.feature_reduc1[2]
+        assert lin.weight.grad is not None and bool(torch.isfinite(lin.weight.grad).all()) and float(lin.weight.grad.abs().sum()) > 0     # from the windows' (x, dy) rows
+        assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for n, p in net.named_parameters() if n.startswith("features.") and p.requires_grad)
+    finally:
+        sr.P.__dict__.clear(); sr.P.__dict__.update(saved)
