@@ -45,6 +45,18 @@ def test_argument_validation_without_gpu():
     assert lib.isx_region_topk_nhwc(None, 1, 4, 100, 100, 3, None, None, None) == -1 and b"4096" in lib.isx_last_error()
     assert lib.isx_region_gather_l2_nhwc(None, 1, 6, 9, 9, 3, 3, None, 2, 7, None, 1e-10, None, None) == -1 and b"multiple of 4" in lib.isx_last_error()
     assert lib.isx_best_location_desc_nhwc(None, 0, 4, 2, 2, 1e-10, None, None, None) == 0
+    # round-4 entries: training kernels (backward.hip, head.hip)
+    assert lib.isx_conv_wgrad_nhwc(None, None, 4, 1, 7, 7, 100, 64, 1, 1, None, None, None) == -1 and b"multiples of 64" in lib.isx_last_error()
+    assert lib.isx_conv_wgrad_nhwc(None, None, 5, 2, 7, 7, 64, 64, 1, 1, None, None, None) == -1 and b"multiple of leaves" in lib.isx_last_error()
+    assert lib.isx_conv_wgrad_splits(1176, 512, 2048, 1) == 4 and lib.isx_conv_wgrad_splits(1176, 512, 512, 9) == 2 and lib.isx_conv_wgrad_splits(10, 100, 64, 1) == 0
+    assert lib.isx_conv3x3_s2_col2im_nhwc(None, 1, 14, 14, 30, None, None, None) == -1 and b"Cin % 4" in lib.isx_last_error()
+    assert lib.isx_conv1x1_dgrad_nhwc(None, 0, 64, None, 64, None, None, None, None) == 0
+    assert lib.isx_bn_fold_backward(None, None, 1, 1, None, None, None, None, 64, 64, 5, 0, 0, None, None, None, None) == -1 and b"taps" in lib.isx_last_error()
+    assert lib.isx_relu_grad(None, None, 6, None, None) == -1 and b"multiple of 4" in lib.isx_last_error()
+    assert lib.isx_head_linear_splits(100352) == 32 and lib.isx_head_linear_splits(640) == 1
+    assert lib.isx_head_linear_fwd(None, 24, 60, 100352, None, 2048, None, None, None, 0, None) == -1 and b"Mp % 64" in lib.isx_last_error()
+    assert lib.isx_head_linear_dgrad(None, 64, 2048, None, 100, None, None) == -1 and b"K % 64" in lib.isx_last_error()
+    assert lib.isx_colsum_leaves(None, 0, 24, 2048, None, None) == 0 and lib.isx_l2norm_rows_bwd(None, None, 0, 16, 1e-10, None, None) == 0
     # empty problems are no-ops
     assert lib.isx_l2norm_rows(None, 0, 16, 1e-10, None, None) == 0
     assert lib.isx_cosine_sim(None, 0, None, 0, 8, None, None) == 0
