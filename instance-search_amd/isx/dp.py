@@ -204,6 +204,10 @@ class TreeExchange(object):
             self._pad = torch.zeros(per * P, dtype=flat.dtype, device=flat.device)
         pad = self._pad
         pad[:n].copy_(flat)
+        moved = 4 * per * (P - 1)
+        STATS["flat_all_to_all_bytes_sent"] = moved
+        STATS["flat_all_gather_bytes_received"] = moved
+        STATS["flat_gradient_bytes"] = 4 * n
         if flat.is_cuda and dist.get_backend(self.group) == "gloo":
             # gloo has no all-to-all on device tensors: stage through the host (two ranks on ONE GPU in tests/test_training.py; RCCL never gets here)
             host = pad.cpu()
@@ -221,10 +225,6 @@ class TreeExchange(object):
         red = tree_sum(0, P, lambda j: pieces[j])                         # in place into the received pieces: rank order = subtree order
         dist.all_gather_into_tensor(pad, red.contiguous(), group=self.group)
         flat.copy_(pad[:n])
-        moved = 4 * per * (P - 1)
-        STATS["flat_all_to_all_bytes_sent"] = moved
-        STATS["flat_all_gather_bytes_received"] = moved
-        STATS["flat_gradient_bytes"] = 4 * n
         return flat
 
 

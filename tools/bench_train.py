@@ -87,9 +87,17 @@ def main():
     args = ap.parse_args()
     import torch.distributed as dist
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    # debugging aid for boxes with ONE GPU (as in bench.py): ISX_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 over gloo, so that the
+    # data-parallel code path (micro-batch subtrees, TreeExchange, row all-gather) runs and its byte counts print; the rates mean nothing
+    one_device = world > 1 and os.environ.get("ISX_BENCH_ONE_DEVICE", "0") == "1"
+    if one_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     res = {}
     for name in args.configs.split(","):
         res[name] = run_config(name, args, world, rank, local)
@@ -99,6 +107,7 @@ def main():
     if rank != 0:
         return
     line = {"model": "DescriptorNet(%s, 2048)" % args.backbone, "images": args.images, "labels": args.labels, "n_gpus": world,
+            "collective_backend": (dist.get_backend() if False else ("gloo (all ranks on cuda:0)" if one_device else ("nccl" if world > 1 else None))),
             "includes": "epoch embedding pass + isx_cosine_sim + isx_mine_negatives + forward/backward of 3 images per triplet + SGD",
             "configs": res}
     if "reference" in res and "frozen" in res:
