@@ -307,9 +307,21 @@ class RowSink(object):
 
 
 def weight_gradient_from_rows(dy, x):
-    """(R, out), (R, in) -> (out, in) = dy^T x, rows summed in row order by one GEMM of a fixed shape (deterministic for a given R)."""
+    """(R, out), (R, in) -> (out, in) = dy^T x.  On the GPU: libisx's TN GEMM over the rows (isx_conv_wgrad_nhwc with the rows as "pixels":
+    both operands are K-major as stored, every output is ONE fp32 fma chain over the rows in row order -- deterministic by construction);
+    otherwise (CPU, widths that are not multiples of 64) one torch GEMM of a fixed shape."""
     if x.size(0) == 0:
         return x.new_zeros((dy.size(1), x.size(1)))
+    R, n_out, n_in = x.size(0), dy.size(1), x.size(1)
+    if x.is_cuda and x.dtype == torch.float32 and dy.dtype == torch.float32 and n_out % 64 == 0 and n_in % 64 == 0:
+        from ._lib import check, lib
+        L = lib()
+        if L.isx_conv_wgrad_splits(R, n_in, n_out, 1) == 1:
+            x, dy = x.contiguous(), dy.contiguous()
+            g = torch.empty((n_out, n_in), dtype=torch.float32, device=x.device)
+            check(L.isx_conv_wgrad_nhwc(dy.data_ptr(), x.data_ptr(), R, 1, 1, 1, n_in, n_out, 1, 1, g.data_ptr(), None,
+                                        torch.cuda.current_stream().cuda_stream), "isx_conv_wgrad_nhwc")
+            return g
     return dy.t().mm(x)
 
 

@@ -124,3 +124,18 @@ def test_head_engine_matches_float64_autograd_and_is_row_count_invariant():
     df1 = eng.backward(ctx1, dd[(Lv - 1) * R:], 1, sink1, flat1, flat.slices)
     assert torch.equal(d1, d[(Lv - 1) * R:]) and torch.equal(df1, df[(Lv - 1) * R:]) and torch.equal(flat1[0], flat_all[Lv - 1])
     assert torch.equal(sink1.x[0][0], ctx[1][(Lv - 1) * R:])          # the rows handed to the sink are the rows of the big pass
+
+
+def test_weight_gradient_from_rows_on_the_tn_kernel():
+    """isx/dp.weight_gradient_from_rows on the GPU = the TN GEMM over the rows: against float64, and one chain per output in row order (a row
+    of zeros appended changes nothing, bit for bit; the hipBLASLt result only agrees to rounding)."""
+    from isx import dp
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for R, n_out, n_in in ((192, 2048, 100352), (24, 128, 100352), (77, 64, 640)):
+        x = torch.randn(R, n_in, device="cuda", generator=g)
+        dy = torch.randn(R, n_out, device="cuda", generator=g)
+        got = dp.weight_gradient_from_rows(dy, x)
+        assert got.shape == (n_out, n_in) and _rel(got, dy.double().t() @ x.double()) <= 2e-6
+        pad = dp.weight_gradient_from_rows(torch.cat([dy, torch.zeros(5, n_out, device="cuda")]), torch.cat([x, torch.zeros(5, n_in, device="cuda")]))
+        assert torch.equal(pad, got)
+        assert _rel(got, dy.t().mm(x)) <= 1e-5
