@@ -194,14 +194,20 @@ class _Stepper(object):
             for j in range(L):
                 d = d_all[j * rows:(j + 1) * rows].detach().requires_grad_(True)
                 leaf_loss(_SplitRows.apply(d, nb), j)
-                dd[j * rows:(j + 1) * rows].copy_(d.grad)
+                if d.grad is None:                       # a loss that does not touch this leaf's descriptors
+                    dd[j * rows:(j + 1) * rows].zero_()
+                else:
+                    dd[j * rows:(j + 1) * rows].copy_(d.grad)
             dy_all = head.backward(hctx, dd, L, sink, flat_all, self.flat.slices)
         else:
             dy_all = torch.empty_like(y_all)
             for j in range(L):
                 z = y_all[j * rows:(j + 1) * rows].detach().requires_grad_(True)
                 leaf_loss(self.net.head_rows(z, nb), j)
-                dy_all[j * rows:(j + 1) * rows].copy_(z.grad)
+                if z.grad is None:
+                    dy_all[j * rows:(j + 1) * rows].zero_()
+                else:
+                    dy_all[j * rows:(j + 1) * rows].copy_(z.grad)
                 self.flat.attach_all()
                 flat_all[j].copy_(flat)                                              # the head's small parameters; the suffix slots are still zero
                 flat.zero_()
