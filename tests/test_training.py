@@ -593,14 +593,14 @@ def test_batched_suffix_is_bit_identical_to_leaf_by_leaf():
     assert moved > 0
 
 
-def _train_reference_two_ranks_one_gpu(rank, world, port, out):
-    """worker of test_two_ranks_on_one_gpu_match_single_process: rank `rank` of `world`, every rank on cuda:0, gloo process group"""
+def _train_reference_two_ranks_one_gpu(rank, world, port, out, batch=16, micro=4):
+    """worker of test_ranks_on_one_gpu_match_single_process: rank `rank` of `world`, every rank on cuda:0, gloo process group"""
     sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    _, state = _train_reference_config(True, True, 2, 32, 16, 4, [], None)
+    _, state = _train_reference_config(True, True, 2, 32, batch, micro, [], None)
     if rank == 0:
         torch.save({k: v.cpu() for k, v in state.items()}, out)
     dist.barrier()
@@ -608,15 +608,17 @@ def _train_reference_two_ranks_one_gpu(rank, world, port, out):
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_gpu_match_single_process(tmp_path):
-    """Data-parallel training of the REAL net with the REAL kernels: DescriptorNet(ResNet-50) on the reference configuration, two ranks (both
-    on cuda:0, gloo -- the box has one GPU; RCCL replaces only the transport) x 2 of the 4 micro-batches of every step, HIP prefix + batched
-    suffix engine + row-deferred head + TreeExchange, against ONE process with all 4 micro-batches: the whole state dict BIT-IDENTICAL after
-    two epochs (mining included: no replay).  The rank-count independence the gloo CPU tests show on a toy net, here on layer4 + the head."""
+@pytest.mark.parametrize("world,batch,micro", [(2, 16, 4), (4, 64, 8)])
+def test_ranks_on_one_gpu_match_single_process(tmp_path, world, batch, micro):
+    """Data-parallel training of the REAL net with the REAL kernels: DescriptorNet(ResNet-50) on the reference configuration, `world` ranks
+    (all on cuda:0, gloo -- the box has one GPU; RCCL replaces only the transport) x their subtree of the micro-batches of every step, HIP
+    prefix + batched suffix engine + head engine + row-deferred head gradient + TreeExchange, against ONE process with all micro-batches: the
+    whole state dict BIT-IDENTICAL after two epochs (mining included: no replay).  (4, 64, 8) is the reference's step -- 64 triplets as 8
+    micro-batches of 8: one process runs 192 rows per pass (192-row tiles in the head GEMMs), each of the 4 ranks 48 (64-row tiles)."""
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_train_reference_two_ranks_one_gpu, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_train_reference_two_ranks_one_gpu, args=(world, _free_port(), out, batch, micro), nprocs=world, join=True)
     b = torch.load(out)
-    init, a = _train_reference_config(True, True, 2, 32, 16, 4, [], None)
+    init, a = _train_reference_config(True, True, 2, 32, batch, micro, [], None)
     moved = 0.0
     for k in a:
         assert torch.equal(a[k].cpu(), b[k]), (k, float((a[k].cpu().float() - b[k].float()).abs().max()))
