@@ -13,6 +13,8 @@
 //   isx_head_linear_dgrad   dx = dy . w: the TN GEMM of the weight gradients (wgrad_kernel.hpp) on (dy^T, w), both K-major as stored; no split.
 //   isx_colsum_leaves       per-micro-batch column sums (bias / Shift gradients kept apart per leaf): one thread per (leaf, column),
 //                           rows added in order.
+#include <stdlib.h>
+
 #include "wgrad_kernel.hpp"
 
 namespace isx {
@@ -28,10 +30,10 @@ static int head_splits(int64_t K) {
 
 // TM: 32-row MFMA tiles per wave along M (block tile 64 TM x 64).  TM = 2 / 3 cover Mp = 128 / 192 rows with ONE m-tile, so the weight is
 // read once instead of once per 64 rows; the tile shape only groups outputs, every output is the same chain in any of them.
-template <int TM>
+template <int TM, int TN = 1>
 __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restrict__ xT, int Mp, const float* __restrict__ Wn, int N, int K, int kt_per,
                                                             float* __restrict__ part, int tiles_n) {
-    constexpr int BK = kHeadBK, BM = 64 * TM, BN = 64, LDA = BM + 4, LDB = BN + lds_pad(BK);
+    constexpr int BK = kHeadBK, BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + lds_pad(BK);
     constexpr int CA = BM / 4, NA = BK * CA / 256;
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
@@ -42,11 +44,13 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
 
-    f32x16 acc[TM][1];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.0f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     float4 ra[NA], rb[BN * BK / 1024];
     auto load = [&](int kt) {
@@ -74,11 +78,11 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restr
         store();
         __syncthreads();
         const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
-        const float* b_base = Bs + half * LDB + wn * 32 + l31;
+        const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
         for (int kt = kt0; kt < kt1; ++kt) {
             const bool more = kt + 1 < kt1;
             if (more) load(kt + 1);
-            mfma_ktile<TM, 1, BK, LDA, LDB>(a_base, b_base, acc);
+            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
             __syncthreads();
             if (more) {
                 store();
@@ -87,14 +91,17 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restr
         }
     }
     float* P = part + (int64_t)split * Mp * N;
-    const int64_t col = n0 + wn * 32 + l31;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-            const float v = acc[i][0][e];
-            P[(int64_t)row * N + col] = v;
+        for (int j = 0; j < TN; ++j) {
+            const int64_t col = n0 + wn * (32 * TN) + j * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (32 * TM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                const float v = acc[i][j][e];
+                P[(int64_t)row * N + col] = v;
+            }
         }
 }
 
@@ -140,7 +147,10 @@ ISX_API int isx_head_linear_fwd(const float* xT, int64_t M, int64_t Mp, int64_t 
     ISX_REQUIRE(ws_bytes >= (size_t)S * (size_t)Mp * (size_t)N * 4, "isx_head_linear_fwd: workspace of %zu bytes, need %zu", ws_bytes, (size_t)S * (size_t)Mp * (size_t)N * 4);
     const int nk = (int)(K / kHeadBK), kt_per = (nk + S - 1) / S;
     hipStream_t st = (hipStream_t)stream;
-    if (Mp == 192)
+    static const bool wide = [] { const char* e = getenv("ISX_HEAD_WIDE"); return !(e && e[0] == '0'); }();      // A/B: 192 x 128 tiles (default) vs 192 x 64
+    if (Mp == 192 && N % 128 == 0 && wide)
+        hipLaunchKernelGGL((head_fwd_gemm_kernel<3, 2>), dim3((unsigned)(N / 128), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 128);
+    else if (Mp == 192)
         hipLaunchKernelGGL(head_fwd_gemm_kernel<3>, dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
     else if (Mp == 128)
         hipLaunchKernelGGL(head_fwd_gemm_kernel<2>, dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
