@@ -31,6 +31,10 @@
  *     -0.0 == +0.0; gallery indices must be < 2^32
  *   - canonical dot product: k-ordered fp32 fma chain from +0.0f, which is what
  *     v_mfma_f32_32x32x2_f32 computes bit for bit
+ *   - canonical convolution sum (trunk kernels, version >= 110): the flattened reduction
+ *     (kh, kw, ci) in chunks of ISX_CONV_CHUNK terms -- that chain inside a chunk, the chunk
+ *     sums added in order into a second fp32 accumulator (tot = tot + chain_c), then the
+ *     epilogue on tot.  The 7x7 stem cuts after filter rows 2 and 5 (63 + 63 + 21 terms).
  */
 #ifndef ISX_H_
 #define ISX_H_
@@ -41,6 +45,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define ISX_CONV_CHUNK 64      /* terms per first-level chain of a trunk convolution (see above) */
 
 #define ISX_OK 0
 #define ISX_ERR_ARG (-1)       /* bad shape / pointer / unsupported size */

@@ -14,4 +14,4 @@ void isx_set_error(const char* fmt, ...) {
 }
 
 extern "C" __attribute__((visibility("default"))) const char* isx_last_error(void) { return g_err; }
-extern "C" __attribute__((visibility("default"))) int isx_version(void) { return 100; }
+extern "C" __attribute__((visibility("default"))) int isx_version(void) { return 110; }

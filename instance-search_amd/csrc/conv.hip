@@ -12,37 +12,40 @@
 //
 // Reference call sites: the torchvision ResNet `features` trunk built by model/ModelDefinition.py, split by
 // model/nn_utils.py:56-71 and run from model/siamese.py:20,107,151.
+#include <stdlib.h>
+
 #include "conv3x3_tile.hpp"
 
 namespace isx {
 
-// one output tile: main loop + bias / residual / ReLU epilogue
-template <int TM, int TN, int BK>
+// one output tile: main loop + bias / residual / ReLU epilogue.  CHUNK: two-level sum of the inference trunk (gemm_tile.hpp), 0 for the gradient kernels
+template <int TM, int TN, int BK, int CHUNK = kConvChunk>
 __device__ __forceinline__ void conv3x3_tile(float* __restrict__ lds, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
                                              const Conv3x3Geom& g, float* __restrict__ C, int64_t m0, int64_t n0,
                                              const float* __restrict__ bias, const float* __restrict__ res, int relu, const float* __restrict__ mask = nullptr) {
     f32x16 acc[TM][TN];
-    conv3x3_mainloop<TM, TN, BK>(lds, x, M, Wt, N, g, m0, n0, acc);
+    conv3x3_mainloop<TM, TN, BK, false, 2, CHUNK>(lds, x, M, Wt, N, g, m0, n0, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm_u = __builtin_amdgcn_readfirstlane(wave >> 1), wn_u = __builtin_amdgcn_readfirstlane(wave & 1);
     conv_epilogue_buffers<TM, TN>(acc, C, res, bias, relu, m0, M, n0, N, N, 64 * TM, wm_u * (32 * TM), wn_u * (32 * TN), lane & 31, lane >> 5, mask);
 }
 
-template <int TM, int TN, int BK>
-__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv3x3_nhwc_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
+// workgroups per CU: 64x64 tiles 6; 128x64 4 (two-level: 126 VGPRs); 128x128 4 with one accumulator set (gradients), 2 with two (64 + 64 accumulator VGPRs)
+template <int TM, int TN, int BK, bool GRAD>
+__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : (TM * TN == 4 && !GRAD) ? ISX_WG_PER_CU_128 : 4) void conv3x3_nhwc_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
                                                            Conv3x3Geom g, float* __restrict__ C, TileMap tm,
                                                            const float* __restrict__ bias, const float* __restrict__ res, int relu, const float* __restrict__ mask) {
     __shared__ float lds[BK * (64 * TM + 64 * TN + 2 * lds_pad(BK))];
     int tile_m, tile_n;
     tile_of_block(tm, tile_m, tile_n);
-    conv3x3_tile<TM, TN, BK>(lds, x, M, Wt, N, g, C, (int64_t)tile_m * (64 * TM), (int64_t)tile_n * (64 * TN), bias, res, relu, mask);
+    conv3x3_tile<TM, TN, BK, GRAD ? 0 : kConvChunk>(lds, x, M, Wt, N, g, C, (int64_t)tile_m * (64 * TM), (int64_t)tile_n * (64 * TN), bias, res, relu, mask);
 }
 
 // 128x128 tiles with a 64x64 TAIL.  A launch whose tile count is a little above a whole number of rounds (1024 resident workgroups) ends
 // with a few 128x128 tiles running alone on their CUs at half the matrix-pipe rate while the other CUs idle -- 256->256 at 14x14, B = 1024:
 // 3136 tiles = 3 rounds + 64 tiles, 256 us of tail in a 1.79 ms launch.  Here the rows past the last whole round are cut into 64x64
 // tiles (a quarter of the work each, four times as many): the same blocks of the grid, same arithmetic per output element.
-__global__ __launch_bounds__(256, 4) void conv3x3_tail_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N, Conv3x3Geom g,
+__global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv3x3_tail_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N, Conv3x3Geom g,
                                                               float* __restrict__ C, TileMap tm_big, TileMap tm_small, int64_t m_split,
                                                               const float* __restrict__ bias, const float* __restrict__ res, int relu) {
     __shared__ float lds[16 * (128 + 128 + 2 * lds_pad(16))];                        // = 32 * (64 + 64 + 2 * lds_pad(32)) floats
@@ -76,8 +79,10 @@ static void launch_conv3x3(const float* x, int64_t M, const float* w, int64_t N,
                            tm, small, split, bias, res, relu);
         return;
     }
-    hipLaunchKernelGGL((conv3x3_nhwc_kernel<TM, TN, BK>), dim3((unsigned)(tm.tiles_m * tm.tiles_n)), dim3(256), 0, st, x, M, w, N, g, y, tm, bias,
-                       res, relu, mask);
+    if (mask) hipLaunchKernelGGL((conv3x3_nhwc_kernel<TM, TN, BK, true>), dim3((unsigned)(tm.tiles_m * tm.tiles_n)), dim3(256), 0, st, x, M, w, N, g, y, tm, bias,
+                                 res, relu, mask);
+    else hipLaunchKernelGGL((conv3x3_nhwc_kernel<TM, TN, BK, false>), dim3((unsigned)(tm.tiles_m * tm.tiles_n)), dim3(256), 0, st, x, M, w, N, g, y, tm, bias,
+                            res, relu, mask);
 }
 
 
@@ -111,6 +116,8 @@ __device__ __forceinline__ void conv1x1_dual_tile(float* __restrict__ lds, const
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    f32x16 tot[TM][TN];                            // second accumulator of the two-level sum (gemm_tile.hpp)
+    zero_tiles(tot);
 
     const int c4 = (threadIdx.x % CH) << 2;
     // A rows through buffer loads (as load_tile / conv3x3): descriptor 1 = the tile's rows of t, descriptor 2 = the block input from the
@@ -161,7 +168,7 @@ __device__ __forceinline__ void conv1x1_dual_tile(float* __restrict__ lds, const
             load_a();
             load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
         }
-        mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+        mfma_ktile_2l<TM, TN, BK, LDA, LDB, kConvChunk>(kt, a_base, b_base, acc, tot);     // chunks of the flattened [t ; x] reduction
         __syncthreads();
         if (more) {
             store_tile<BM, BK>(As, ra);
@@ -169,13 +176,14 @@ __device__ __forceinline__ void conv1x1_dual_tile(float* __restrict__ lds, const
             __syncthreads();
         }
     }
+    two_level_value<TM, TN, kConvChunk>(acc, tot);
 
     const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
     conv_epilogue_buffers<TM, TN>(acc, C, nullptr, bias, relu, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31, half);
 }
 
 template <int TM, int TN, int BK>
-__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t M,
+__global__ __launch_bounds__(256, TM * TN == 1 ? 6 : TM * TN == 4 ? ISX_WG_PER_CU_128 : 4) void conv1x1_dual_nhwc_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t M,
                                                                                       const float* __restrict__ Wt, int64_t N, DualGeom g,
                                                                                       float* __restrict__ C, TileMap tm,
                                                                                       const float* __restrict__ bias, int relu) {
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : 4) void conv1x1_dual_nhwc_k
 }
 
 // 128x128 tiles + 64x64 tail in one grid (see conv3x3_tail_kernel)
-__global__ __launch_bounds__(256, 4) void conv1x1_dual_tail_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt,
+__global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_dual_tail_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt,
                                                                    int64_t N, DualGeom g, float* __restrict__ C, TileMap tm_big, TileMap tm_small,
                                                                    int64_t m_split, const float* __restrict__ bias, int relu) {
     __shared__ float lds[16 * (128 + 128 + 2 * lds_pad(16))];
@@ -223,7 +231,7 @@ static void launch_dual(const float* t, const float* x, int64_t M, const float* 
                        bias, relu);
 }
 
-static std::atomic<int> g_force_conv_cfg{-1};
+static std::atomic<int> g_force_conv_cfg{[] { const char* e = getenv("ISX_DEBUG_CONV_CFG"); return e ? atoi(e) : -1; }()};       // debug / A-B hook
 
 }  // namespace isx
 

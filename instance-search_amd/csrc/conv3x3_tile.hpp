@@ -18,7 +18,8 @@ struct Conv3x3Geom { int H, W, Cin, Ho, Wo, stride; };
 // AHEAD2 (64x64 tiles only): operands requested two k-tiles ahead instead of one (16 more VGPRs: the fused expand kernel has them, the plain
 // 64x64 kernel at six workgroups per CU does not).
 // WM: waves along M (2: the 2x2 arrangement of every other kernel; 4: four waves stacked along the pixels, each TM x TN tiles of the FULL width)
-template <int TM, int TN, int BK, bool AHEAD2 = false, int WM = 2>
+// CHUNK: terms per first-level chain of the two-level sum (gemm_tile.hpp; the inference trunk), 0 = one chain over all 9 Cin terms (gradients)
+template <int TM, int TN, int BK, bool AHEAD2 = false, int WM = 2, int CHUNK = kConvChunk>
 __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N,
                                                  const Conv3x3Geom& g, int64_t m0, int64_t n0, f32x16 (&acc)[TM][TN]) {
     constexpr int WN = 4 / WM, BM = 32 * TM * WM, BN = 32 * TN * WN, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK);
@@ -37,6 +38,8 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    f32x16 tot[CHUNK ? TM : 1][CHUNK ? TN : 1];
+    zero_tiles(tot);
 
     // staged A rows of this thread: top-left input pixel of the 3x3 window (may be -1: padding)
     int pbase[NA], hw0[NA];                       // pixel index of (hi0, wi0); (hi0 + 1) << 16 | (wi0 + 1)
@@ -109,7 +112,7 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
         float4 ra1[NA];
         if (nk & 1) {
             if (nk > 1) stage(ra1, rb, 1);
-            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+            mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(0, a_base, b_base, acc, tot);
             __syncthreads();
             if (nk > 1) {
                 store_tile<BM, BK>(As, ra1);
@@ -124,13 +127,13 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
         // undo the prefetch); those of the last trip point past the last tap / weight column -- range-checked buffer loads, values never used.
         for (; kt < nk; kt += 2) {
             stage(ra2, rb2, kt + 2);
-            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+            mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(kt, a_base, b_base, acc, tot);
             __syncthreads();
             store_tile<BM, BK>(As, ra1);
             store_tile<BN, BK>(Bs, rb);
             __syncthreads();
             stage(ra1, rb, kt + 3);
-            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+            mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(kt + 1, a_base, b_base, acc, tot);
             __syncthreads();
             if (kt + 2 < nk) {
                 store_tile<BM, BK>(As, ra2);
@@ -138,6 +141,7 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
                 __syncthreads();
             }
         }
+        two_level_value<TM, TN, CHUNK>(acc, tot);
         return;
     }
     load_a();
@@ -152,7 +156,7 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
             load_a();
             load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
         }
-        mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+        mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(kt, a_base, b_base, acc, tot);
         __syncthreads();
         if (more) {
             store_tile<BM, BK>(As, ra);
@@ -160,7 +164,7 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
             __syncthreads();
         }
     }
-
+    two_level_value<TM, TN, CHUNK>(acc, tot);
 }
 
 }  // namespace isx

@@ -32,7 +32,8 @@ namespace isx {
 // Block tile (64*TM) x (64*TN): 4 waves as 2x2, each wave TM x TN MFMA tiles of 32x32.
 // EPI: 0 = store scores, 1 = top-k filter (thr, gflag, ngrp), 2 = 1x1-convolution epilogue: thr = bias[n],
 // gflag = residual (float, same layout as C) or null, ngrp = relu flag
-template <bool ALIGNED, int TM, int TN, int EPI, int BK>
+// CHUNK (convolution mode only): terms per first-level chain of the two-level sum (gemm_tile.hpp), 0 = one chain over all of D (scores, gradients)
+template <bool ALIGNED, int TM, int TN, int EPI, int BK, int CHUNK = (EPI == 2 ? kConvChunk : 0)>
 __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const float* __restrict__ Q, int64_t M,
                                                  const float* __restrict__ G, int64_t N, int D,
                                                  float* __restrict__ C, int64_t ldc, int64_t m0, int64_t n0,
@@ -53,6 +54,8 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    f32x16 tot[CHUNK ? TM : 1][CHUNK ? TN : 1];
+    zero_tiles(tot);
 
     // convolution epilogue on 64x64 tiles (short K loops, residual layers): fetch the residual values before
     // the main loop so that their latency overlaps the operand loads and the MFMAs
@@ -91,7 +94,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
             load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
             load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
         }
-        mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+        mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(kt, a_base, b_base, acc, tot);
         __syncthreads();
         if (more) {
             store_tile<BM, BK>(As, ra);
@@ -99,6 +102,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
             __syncthreads();
         }
     }
+    two_level_value<TM, TN, CHUNK>(acc, tot);
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (EPI == 3) {
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restric
 // as 64x64 tiles in the same grid (see conv3x3_tail_kernel in conv.hip: a few 128x128 tiles alone on their CUs at the end of a launch of
 // three to twelve rounds cost 3-10 % of it).  Same arithmetic per output element.
 template <bool ALIGNED>
-__global__ __launch_bounds__(256, 4) void conv1x1_tail_kernel(const float* __restrict__ Q, int64_t M, const float* __restrict__ G, int64_t N, int D,
+__global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_tail_kernel(const float* __restrict__ Q, int64_t M, const float* __restrict__ G, int64_t N, int D,
                                                               float* __restrict__ C, int64_t ldc, TileMap tm_big, TileMap tm_small, int64_t m_split,
                                                               const float* __restrict__ bias, uint8_t* __restrict__ res, int relu) {
     __shared__ float lds[16 * (128 + 128 + 2 * lds_pad(16))];
@@ -275,7 +279,7 @@ int pick_tile_cfg(int64_t M, int64_t N, int64_t split, const float* eff, unsigne
     return best;
 }
 
-static std::atomic<int> g_force_cfg{-1};            // debug / A-B hook
+static std::atomic<int> g_force_cfg{[] { const char* e = getenv("ISX_DEBUG_GEMM_CFG"); return e ? atoi(e) : -1; }()};            // debug / A-B hook
 void set_gemm_cfg(int c) { g_force_cfg = c; }
 
 template <int TM, int TN, int BK>

@@ -14,8 +14,11 @@ namespace isx {
 // DUAL: the first block of the stage, whose shortcut is a 1x1 projection of the block input x2 (64 channels, same pixels: stride 1):
 //   y = act( [W3 | Wd] . [relu(conv3x3(x, W2) + b2) ; x2] + b ),  W3t = the concatenated weight transposed, (128, Cout);
 // the x2 rows of the tile are fetched at kernel start, wait in registers during the 3x3 loop and go to a second LDS tile.
+// Two-level sum (gemm_tile.hpp): the 3x3 loop folds its chain every 64 terms (conv3x3_mainloop); the expansion is ONE chunk (64 mid channels), with
+// DUAL two -- the chain over the mid channels, then the chain over the x2 channels, added: that kernel holds two accumulator sets (2 x 64 VGPRs)
+// and runs two workgroups per CU (one launch per trunk: the first block of stage 1).
 template <int TN2, bool DUAL, bool STAMPS = false>
-__global__ __launch_bounds__(256, 4) void conv3x3_expand_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ W2, Conv3x3Geom g,
+__global__ __launch_bounds__(256, DUAL ? 2 : 4) void conv3x3_expand_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ W2, Conv3x3Geom g,
                                                                 const float* __restrict__ b2, const float* __restrict__ W3t, const float* __restrict__ b3,
                                                                 const float* __restrict__ res, int relu, float* __restrict__ y,
                                                                 unsigned long long* __restrict__ stamps = nullptr) {
@@ -75,6 +78,15 @@ __global__ __launch_bounds__(256, 4) void conv3x3_expand_kernel(const float* __r
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const unsigned wvo = (unsigned)((half * COUT + l31) * 4);
     const unsigned wso = (unsigned)(wave_u * 32 * NJ * 4);
+    f32x16 acc3[DUAL ? 2 : 1][DUAL ? NJ : 1];                                   // DUAL: chain over the x2 channels (second chunk)
+    if (DUAL) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc3[i][j][e] = 0.0f;
+    }
 #pragma unroll
     for (int s = 0; s < (DUAL ? 64 : 32); ++s) {
         const int ao = s < 32 ? 2 * s * LDY : TILE_F + 2 * (s - 32) * LDY;      // mid channels, then the x2 channels
@@ -85,9 +97,20 @@ __global__ __launch_bounds__(256, 4) void conv3x3_expand_kernel(const float* __r
             bq[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wr, wvo, wso + (unsigned)((2 * s * COUT + 32 * j) * 4), 0));
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            acc2[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[j], acc2[0][j], 0, 0, 0);
-            acc2[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[j], acc2[1][j], 0, 0, 0);
+            if (DUAL && s >= 32) {
+                acc3[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[j], acc3[0][j], 0, 0, 0);
+                acc3[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[j], acc3[1][j], 0, 0, 0);
+            } else {
+                acc2[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bq[j], acc2[0][j], 0, 0, 0);
+                acc2[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bq[j], acc2[1][j], 0, 0, 0);
+            }
         }
+    }
+    if (DUAL) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc2[i][j] = acc2[i][j] + acc3[i][j];       // tot = (0 + chain_0) + chain_1
     }
     stamp(3);
     conv_epilogue_buffers<2, NJ>(acc2, y, DUAL ? nullptr : res, b3, relu, m0, M, 0, COUT, COUT, 64, 0, wave_u * (32 * NJ), l31, half);

@@ -173,11 +173,35 @@ __device__ __forceinline__ void conv_epilogue_buffers(const f32x16 (&acc)[TM][TN
     }
 }
 
+// ---- two-level accumulation of the trunk convolutions (round 5) -----------------------------------------------------------------
+// A convolution output is NOT one fp32 chain over the whole reduction any more: the flattened reduction (kh, kw, ci) is cut into chunks of
+// ISX_CONV_CHUNK terms; inside a chunk the k-ordered fma chain of the matrix core starts from +0, and the chunk sums are added, in order, into
+// a second accumulator:   tot = 0;  for each chunk c: tot = tot + chain_c;   y = act(tot + bias (+ residual)).
+// Why: a chain over K terms drifts from the exact sum like eps . K, chunks of c terms like eps . sqrt(K c + K^2 / c); measured end to end
+// (scratch/chunk_study.py, ResNet-50 / ResNet-152 descriptors against a float64 evaluation): one chain is 1.2x further from float64 than torch's
+// CPU fp32 path, chunks of 64 land at 0.7x.  K <= 64 (one chunk): tot = 0 + chain, the bits of rounds 1-4.  Restated by oracle/isx_oracle.c.
+constexpr int kConvChunk = ISX_CONV_CHUNK;
+#ifndef ISX_WG_PER_CU_128
+#define ISX_WG_PER_CU_128 2     // resident workgroups per CU of the 128x128 convolution tiles: two accumulator sets = 128 VGPRs + ~55 -> two waves per SIMD
+#endif
+static_assert(kConvChunk % 32 == 0, "a chunk is a whole number of k-tiles");
+
+// tot += acc (the chain of the chunk that just ended; acc itself is overwritten by the first MFMAs of the next chunk, which take C = 0)
+template <int TM, int TN>
+__device__ __forceinline__ void add_chunk(f32x16 (&tot)[TM][TN], const f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) tot[i][j] = tot[i][j] + acc[i][j];
+}
+
 // MFMAs of one staged k-tile.  Small tiles (TM * TN <= 2) have too few MFMAs per k-step to hide an LDS round trip
 // behind: the operand reads of HALF a k-tile are issued back to back, then the MFMAs (counted lgkmcnt(n) waits instead
 // of a drain per step; +4 % on the trunk's 1x1 convolutions).  a_base / b_base: this lane's first operand element.
-template <int TM, int TN, int BK, int LDA, int LDB>
+// ZERO_C: the first k-step starts new chains (C = 0 as an inline constant; the old contents of acc are dead): chunk start of the two-level sum.
+template <int TM, int TN, int BK, int LDA, int LDB, bool ZERO_C = false>
 __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, const float* __restrict__ b_base, f32x16 (&acc)[TM][TN]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (TM * TN <= 2 && !ISX_SIMPLE_KLOOP) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -194,7 +218,8 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, con
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], (ZERO_C && h == 0 && kk == 0) ? zero : acc[i][j], 0, 0, 0);
         }
     } else if (ISX_KLOOP_PREFETCH) {
         // register prefetch one k-step ahead: the operand reads of step kk + 1 are issued BEFORE the MFMAs of step kk, so a wave
@@ -216,7 +241,8 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, con
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], (ZERO_C && kk == 0) ? zero : acc[i][j], 0, 0, 0);
         }
     } else {
 #pragma unroll
@@ -229,8 +255,45 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, con
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], (ZERO_C && kk == 0) ? zero : acc[i][j], 0, 0, 0);
         }
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void zero_tiles(f32x16 (&t)[TM][TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) t[i][j][e] = 0.0f;
+}
+
+// k-tile kt of a reduction summed in two levels (CHUNK terms per chain; 0 = one chain, acc only): after the last k-tile of a chunk the finished
+// chain is added to tot and acc restarts from 0.  acc and tot must be zero before k-tile 0; the value is tot + acc after the last k-tile
+// (two_level_value; acc then holds the last, partial chunk or 0).
+// (A/B, round 5: adding the chain lazily at the next chunk's start with C = 0 in its first MFMAs -- no zeroing, no wait for the last MFMA -- needs two
+// copies of the k-tile body and came out 3 % SLOWER on the bench step: 74.5 vs 71.9 ms.)
+template <int TM, int TN, int BK, int LDA, int LDB, int CHUNK>
+__device__ __forceinline__ void mfma_ktile_2l(int kt, const float* __restrict__ a_base, const float* __restrict__ b_base, f32x16 (&acc)[TM][TN],
+                                              f32x16 (&tot)[CHUNK ? TM : 1][CHUNK ? TN : 1]) {
+    mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+    if constexpr (CHUNK != 0) {
+        static_assert(CHUNK % BK == 0 && ((CHUNK / BK) & (CHUNK / BK - 1)) == 0, "a chunk is 2^n k-tiles");
+        if (((kt + 1) & (CHUNK / BK - 1)) == 0) {        // uniform
+            add_chunk<TM, TN>(tot, acc);
+            zero_tiles(acc);
+        }
+    }
+}
+template <int TM, int TN, int CHUNK>
+__device__ __forceinline__ void two_level_value(f32x16 (&acc)[TM][TN], const f32x16 (&tot)[CHUNK ? TM : 1][CHUNK ? TN : 1]) {
+    if constexpr (CHUNK != 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j] + acc[i][j];
     }
 }
 

@@ -19,7 +19,8 @@
 //     unit (step t, band cb) stages the 21 rows x 232 columns under its tile (the 4-pixel border now holds the neighbouring band's
 //     pixels, or zeros at the image edge), the carry row of every band stays in registers, and the right-most pooled partial column of
 //     band cb reaches band cb + 1 through an LDS slot of its own -- nothing is recomputed and nothing but the pooled map is stored.
-// Arithmetic: acc = fp32 fma chain over (kh, kw, c) ascending from +0 (padding taps contribute fma(0, w, acc) = acc), y = max(acc + bias, 0),
+// Arithmetic: fp32 fma chains over (kh, kw, c) ascending from +0 (padding taps contribute fma(0, w, acc) = acc), one per group of three filter rows
+// (kh 0-2, 3-5, 6), summed in order: acc = ((0 + c0) + c1) + c2 (two-level sum, gemm_tile.hpp), y = max(acc + bias, 0),
 // out = max over the window: bit-identical to oracle/isx_oracle.c::isxo_stem7x7_pool_nhwc (tests/test_gpu_parity.py).
 // Reference: the torchvision ResNet stem (conv1, bn1, relu, maxpool) inside the `features` trunk built by model/ModelDefinition.py and
 // split by model/nn_utils.py:56-71; run from model/siamese.py:20,107,151.
@@ -158,11 +159,13 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
         }
         const int wc_left = g.Wc - 112 * cb;                                    // convolution columns of the image from this band's first one on
 
-        f32x16 acc[7];
+        // two-level sum (gemm_tile.hpp): the chain restarts after filter rows 2 and 5 (63 + 63 + 21 terms; the zero-weight slot that pads a filter
+        // row to 22 adds fma(x, 0, acc) = acc) and the three chunk sums are added in order: tot = ((0 + c0) + c1) + c2
+        f32x16 acc[7], tot[7];
 #pragma unroll
         for (int b = 0; b < 7; ++b)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[b][e] = 0.0f;
+            for (int e = 0; e < 16; ++e) acc[b][e] = 0.0f, tot[b][e] = 0.0f;
         const float* const ap = in_lds + buf * ST_BUF_F + a_lane;
         float av[2][7], bv[2];
 #pragma unroll
@@ -179,7 +182,17 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < 7; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][b], bv[s & 1], acc[b], 0, 0, 0);
+            if (s == 32 || s == 65) {                                           // filter rows 0-2 / 3-5 done (11 k-steps per row)
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {
+                    tot[b] += acc[b];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[b][e] = 0.0f;
+                }
+            }
         }
+#pragma unroll
+        for (int b = 0; b < 7; ++b) acc[b] = tot[b] + acc[b];
 
         // ---- epilogue: bias + ReLU, 3x3 / stride 2 max.  acc[b][4 gg + 2 r + c] = convolution row 8 t + 2 gg + r, column 112 cb + 28 cg + 4 b + 2 h + c
         float own[7][4], rgt[7][4];

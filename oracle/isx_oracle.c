@@ -19,6 +19,9 @@
  *   - canonical ranking order = (score descending, index ascending); -0.0 == +0.0
  *   - canonical dot product = k-ordered fp32 fmaf chain starting from +0.0f
  *     (this is what v_mfma_f32_32x32x2_f32 computes bit-for-bit)
+ *   - canonical convolution sum (trunk convolutions, round 5): the flattened (kh, kw, ci)
+ *     reduction in chunks of ISXO_CONV_CHUNK terms -- that chain inside a chunk, the chunk
+ *     sums added in order into a second fp32 accumulator (conv_sum_t below)
  *
  * Citations are file:line under /root/reference.
  */
@@ -216,6 +219,23 @@ ISXO_API void isxo_images_u8_to_f32(const uint8_t* img, int64_t B, int H, int W,
             }
 }
 
+/* Two-level sum of the trunk convolutions (include/isx.h ISX_CONV_CHUNK; csrc/gemm_tile.hpp fold_chunk): terms arrive in the flattened
+ * (kh, kw, ci) order; `acc` is the fma chain of the current chunk (from +0), `tot` the in-order sum of the finished chunks.  One chain over
+ * the whole reduction (rounds 1-4) sat 1.2x further from a float64 evaluation of the ResNet-50 / ResNet-152 descriptors than torch's CPU fp32
+ * path (the reference's arithmetic; third-party, unpinned by the reference); chunks of 64 sit at 0.7-0.8x.  K <= 64: tot = 0 + chain. */
+#define ISXO_CONV_CHUNK 64
+typedef struct { float acc, tot; int n, chunk; } conv_sum_t;
+static inline void cs_init(conv_sum_t* s, int chunk) { s->acc = 0.0f; s->tot = 0.0f; s->n = 0; s->chunk = chunk; }
+static inline void cs_fold(conv_sum_t* s) { s->tot = s->tot + s->acc; s->acc = 0.0f; s->n = 0; }
+static inline void cs_term(conv_sum_t* s, float a, float b) {
+    s->acc = fmaf(a, b, s->acc);
+    if (++s->n == s->chunk) cs_fold(s);
+}
+static inline float cs_value(conv_sum_t* s) {
+    if (s->n) cs_fold(s);                       /* the last, partial chunk */
+    return s->tot;
+}
+
 /* relu(y + bias) -> MaxPool2d(3, stride 2, padding 1) on an NHWC map (torchvision ResNet stem after the folded BN). */
 ISXO_API void isxo_bias_relu_maxpool_nhwc(const float* y, const float* bias, int64_t B, int H, int W, int C, float* out) {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -237,18 +257,21 @@ ISXO_API void isxo_bias_relu_maxpool_nhwc(const float* y, const float* bias, int
 
 /* 1x1 stride-1 convolution over NHWC pixels with the folded-BN epilogue of the inference trunk
  * (torchvision Bottleneck conv1 / conv3 / downsample as used through model/nn_utils.py:56-71 extract_layers):
- * y[m][co] = act(sum_ci x[m][ci] * w[co][ci] (fma chain, ci ascending) + bias[co] (+ res[m][co])). */
+ * y[m][co] = act(sum_ci x[m][ci] * w[co][ci] (two-level sum, ci ascending) + bias[co] (+ res[m][co])). */
 ISXO_API void isxo_conv1x1_nhwc(const float* x, int64_t M, int Cin, const float* w, int Cout, const float* bias,
                                 const float* res, int relu, float* y) {
     for (int64_t m = 0; m < M; ++m)
         for (int co = 0; co < Cout; ++co) {
-            float v = dot_fma(x + m * Cin, w + (int64_t)co * Cin, Cin) + bias[co];
+            conv_sum_t cs;
+            cs_init(&cs, ISXO_CONV_CHUNK);
+            for (int ci = 0; ci < Cin; ++ci) cs_term(&cs, x[m * Cin + ci], w[(int64_t)co * Cin + ci]);
+            float v = cs_value(&cs) + bias[co];
             if (res) v += res[m * Cout + co];
             y[m * Cout + co] = relu ? fmaxf(v, 0.0f) : v;
         }
 }
 
-/* conv3 + 1x1 projection shortcut of a bottleneck block as one fma chain per output: t's K1 channels, then the K2 channels
+/* conv3 + 1x1 projection shortcut of a bottleneck block as one two-level sum per output: t's K1 channels, then the K2 channels
  * of the strided block input (torchvision Bottleneck: out = conv3(t) + downsample(x), BN folded, then ReLU). */
 ISXO_API void isxo_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_t B, int H, int W, int K2, int stride,
                                      const float* w, int Cout, const float* bias, int relu, float* y) {
@@ -261,18 +284,19 @@ ISXO_API void isxo_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int
                 const float* xp = x + ((b * H + (int64_t)ho * stride) * W + (int64_t)wo * stride) * K2;
                 for (int co = 0; co < Cout; ++co) {
                     const float* wp = w + (int64_t)co * (K1 + K2);
-                    float acc = 0.0f;
-                    for (int c = 0; c < K1; ++c) acc = fmaf(tp[c], wp[c], acc);
-                    for (int c = 0; c < K2; ++c) acc = fmaf(xp[c], wp[K1 + c], acc);
-                    const float v = acc + bias[co];
+                    conv_sum_t cs;
+                    cs_init(&cs, ISXO_CONV_CHUNK);
+                    for (int c = 0; c < K1; ++c) cs_term(&cs, tp[c], wp[c]);
+                    for (int c = 0; c < K2; ++c) cs_term(&cs, xp[c], wp[K1 + c]);
+                    const float v = cs_value(&cs) + bias[co];
                     y[m * Cout + co] = relu ? fmaxf(v, 0.0f) : v;
                 }
             }
 }
 
 /* 3x3 convolution, padding 1, stride 1|2, NHWC, weights (Cout,3,3,Cin), folded-BN epilogue (conv2 of the torchvision
- * Bottleneck / BasicBlock convolutions inside `features`): fma chain over (kh, kw, ci) in that order; padding taps
- * contribute fma(0, w, acc). */
+ * Bottleneck / BasicBlock convolutions inside `features`): two-level sum over (kh, kw, ci) in that order; padding taps
+ * contribute fma(0, w, acc) and count as terms. */
 ISXO_API void isxo_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, const float* w, int Cout, int stride,
                                 const float* bias, const float* res, int relu, float* y) {
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -281,16 +305,17 @@ ISXO_API void isxo_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin
             for (int wo = 0; wo < Wo; ++wo) {
                 const int64_t m = (b * Ho + ho) * Wo + wo;
                 for (int co = 0; co < Cout; ++co) {
-                    float acc = 0.0f;
+                    conv_sum_t cs;
+                    cs_init(&cs, ISXO_CONV_CHUNK);
                     for (int kh = 0; kh < 3; ++kh)
                         for (int kw = 0; kw < 3; ++kw) {
                             const int hi = ho * stride - 1 + kh, wi = wo * stride - 1 + kw;
                             const int ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
                             const float* xp = x + ((b * H + (ok ? hi : 0)) * W + (ok ? wi : 0)) * (int64_t)Cin;
                             const float* wp = w + (((int64_t)co * 3 + kh) * 3 + kw) * Cin;
-                            for (int ci = 0; ci < Cin; ++ci) acc = fmaf(ok ? xp[ci] : 0.0f, wp[ci], acc);
+                            for (int ci = 0; ci < Cin; ++ci) cs_term(&cs, ok ? xp[ci] : 0.0f, wp[ci]);
                         }
-                    float v = acc + bias[co];
+                    float v = cs_value(&cs) + bias[co];
                     if (res) v += res[m * Cout + co];
                     y[m * Cout + co] = relu ? fmaxf(v, 0.0f) : v;
                 }
@@ -299,7 +324,7 @@ ISXO_API void isxo_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin
 
 /* The torchvision ResNet stem on a channels-last image batch (conv1 7x7 / stride 2 / padding 3 with bn1 folded, relu, maxpool 3/2/1;
  * the first four modules of the `features` trunk of model/ModelDefinition.py as split by model/nn_utils.py:56-71):
- * conv = fma chain over (kh, kw, c) ascending, padding taps contribute fma(0, w, acc); y = relu(conv + bias); out = max over the
+ * conv = two-level sum over (kh, kw, c) ascending in chunks of three filter rows, padding taps contribute fma(0, w, acc); y = relu(conv + bias); out = max over the
  * in-bounds 3x3 window.  x: (B,H,W,3), w: (64,7,7,3), out: (B,Hp,Wp,64). */
 ISXO_API void isxo_stem7x7_pool_nhwc(const float* x, int64_t B, int H, int W, const float* w, const float* bias, float* out) {
     const int Hc = (H - 1) / 2 + 1, Wc = (W - 1) / 2 + 1, Hp = (Hc - 1) / 2 + 1, Wp = (Wc - 1) / 2 + 1;
@@ -308,16 +333,17 @@ ISXO_API void isxo_stem7x7_pool_nhwc(const float* x, int64_t B, int H, int W, co
         for (int ho = 0; ho < Hc; ++ho)
             for (int wo = 0; wo < Wc; ++wo)
                 for (int co = 0; co < 64; ++co) {
-                    float acc = 0.0f;
+                    conv_sum_t cs;
+                    cs_init(&cs, 63);                      /* three filter rows of 21 terms per chunk: 63 + 63 + 21 */
                     for (int kh = 0; kh < 7; ++kh)
                         for (int kw = 0; kw < 7; ++kw) {
                             const int hi = ho * 2 - 3 + kh, wi = wo * 2 - 3 + kw;
                             const int ok = hi >= 0 && hi < H && wi >= 0 && wi < W;
                             const float* xp = x + ((b * H + (ok ? hi : 0)) * W + (ok ? wi : 0)) * 3;
                             const float* wp = w + (((int64_t)co * 7 + kh) * 7 + kw) * 3;
-                            for (int c = 0; c < 3; ++c) acc = fmaf(ok ? xp[c] : 0.0f, wp[c], acc);
+                            for (int c = 0; c < 3; ++c) cs_term(&cs, ok ? xp[c] : 0.0f, wp[c]);
                         }
-                    y[((int64_t)ho * Wc + wo) * 64 + co] = fmaxf(acc + bias[co], 0.0f);
+                    y[((int64_t)ho * Wc + wo) * 64 + co] = fmaxf(cs_value(&cs) + bias[co], 0.0f);
                 }
         for (int po = 0; po < Hp; ++po)
             for (int qo = 0; qo < Wp; ++qo)
