@@ -68,7 +68,7 @@ static void launch_conv3x3(const float* x, int64_t M, const float* w, int64_t N,
     tm.m_active = nullptr;
     tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
     tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
-    const int64_t split = (TM == 2 && TN == 2 && !mask) ? gemm_tail_split_rows(M, N) : 0;
+    const int64_t split = (TM == 2 && TN == 2 && !mask) ? gemm_tail_split_rows(M, N, 256 * ISX_WG_PER_CU_128) : 0;
     if (split > 0) {
         TileMap small;
         small.m_active = nullptr;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void conv1x1_dual_tile(float* __restrict__ lds, const
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-    f32x16 tot[TM][TN];                            // second accumulator of the two-level sum (gemm_tile.hpp)
+    f32x16 tot[kConvChunk ? TM : 1][kConvChunk ? TN : 1];     // second accumulator of the two-level sum (gemm_tile.hpp)
     zero_tiles(tot);
 
     const int c4 = (threadIdx.x % CH) << 2;
@@ -162,21 +162,34 @@ __device__ __forceinline__ void conv1x1_dual_tile(float* __restrict__ lds, const
 
     const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
     const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            load_a();
-            load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
-        }
-        mfma_ktile_2l<TM, TN, BK, LDA, LDB, kConvChunk>(kt, a_base, b_base, acc, tot);     // chunks of the flattened [t ; x] reduction
-        __syncthreads();
-        if (more) {
-            store_tile<BM, BK>(As, ra);
-            store_tile<BN, BK>(Bs, rb);
+    constexpr bool PINNED = kConvChunk != 0 && TM * TN == 4;
+    KtilePtrs<BK> pins;
+    if constexpr (PINNED) pins = pin_ktile_ptrs<BK, LDA, LDB>(a_base, b_base);
+    // outer loop: chunks of the two-level sum over the flattened [t ; x] reduction; inner loop: the staged k-tiles of a chunk (gemm_tile.hpp)
+    for (int kt = 0; kt < nk;) {
+        const int kend = (kConvChunk && kt + kConvChunk / BK < nk) ? kt + kConvChunk / BK : nk;
+        for (; kt < kend; ++kt) {
+            const bool more = (kt + 1 < nk);
+            if (more) {
+                load_a();
+                load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
+            }
+            mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED>(a_base, b_base, pins, acc);
             __syncthreads();
+            if (more) {
+                store_tile<BM, BK>(As, ra);
+                store_tile<BN, BK>(Bs, rb);
+                __syncthreads();
+            }
         }
+        if constexpr (kConvChunk != 0) fold_chunk<TM, TN>(tot, acc);
     }
-    two_level_value<TM, TN, kConvChunk>(acc, tot);
+    if constexpr (kConvChunk != 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];
+    }
 
     const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
     conv_epilogue_buffers<TM, TN>(acc, C, nullptr, bias, relu, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31, half);
@@ -216,7 +229,7 @@ static void launch_dual(const float* t, const float* x, int64_t M, const float* 
     tm.m_active = nullptr;
     tm.tiles_m = (int)((M + 64 * TM - 1) / (64 * TM));
     tm.tiles_n = (int)((N + 64 * TN - 1) / (64 * TN));
-    const int64_t split = (TM == 2 && TN == 2) ? gemm_tail_split_rows(M, N) : 0;
+    const int64_t split = (TM == 2 && TN == 2) ? gemm_tail_split_rows(M, N, 256 * ISX_WG_PER_CU_128) : 0;
     if (split > 0) {
         TileMap small;
         small.m_active = nullptr;
@@ -275,7 +288,7 @@ ISX_API int isx_conv3x3_nhwc(const float* x, int64_t B, int H, int W, int Cin, c
     // 1.71 / 1.78 / 1.76; 64->64 at 56x56 - / 1.89 / 1.85): 128x128 (+ 64x64 tail) wherever the grid fills the chip, the shape with the
     // fewest idle CUs below that (512->512 at 14x14 with 64 images: 1568 tiles of 64x64 are 1.02 rounds, 784 of 128x64 are 0.77)
     static const float eff3x3[4] = {0.90f, 0.0f, 0.865f, 0.87f};
-    int best = pick_tile_cfg(M, N, gemm_tail_split_rows(M, N), eff3x3, 0xD);
+    int best = pick_tile_cfg(M, N, gemm_tail_split_rows(M, N, 256 * ISX_WG_PER_CU_128), eff3x3, 0xD, ISX_WG_PER_CU_128);
     { const int fc_ = g_force_conv_cfg; if (fc_ == 0 || fc_ == 2 || fc_ == 3) best = fc_; }
     hipStream_t st = (hipStream_t)stream;
     switch (best) {
@@ -335,7 +348,7 @@ ISX_API int isx_conv1x1_dual_nhwc(const float* t, int K1, const float* x, int64_
     // measured at B = 1024 (ms, 128x128 / 128x64 / 64x64): layer 1 2.10 / 2.22 / 2.21, layer 2 2.64 / 2.68 / 2.84,
     // layer 3 2.54 / 2.54 / 2.75, layer 4 (50 k pixels) 2.55 / 2.48 / 2.72
     static const float eff_dual[4] = {0.92f, 0.0f, 0.885f, 0.85f};                         // layer 1-4 at B = 1024: 128x128 best, then 128x64, then 64x64
-    int best = pick_tile_cfg(M, N, gemm_tail_split_rows(M, N), eff_dual, 0xD);
+    int best = pick_tile_cfg(M, N, gemm_tail_split_rows(M, N, 256 * ISX_WG_PER_CU_128), eff_dual, 0xD, ISX_WG_PER_CU_128);
     { const int fc_ = g_force_conv_cfg; if (fc_ == 0 || fc_ == 2 || fc_ == 3) best = fc_; }
     hipStream_t st = (hipStream_t)stream;
     if (best == 0) launch_dual<2, 2, 16>(t, x, M, w_cat, N, g, y, bias, relu ? 1 : 0, st);

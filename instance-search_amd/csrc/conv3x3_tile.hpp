@@ -91,57 +91,58 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
     const int nk = D / BK;
     const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
     const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
-    if (AHEAD2 && TM * TN == 1) {
+    constexpr bool PINNED = CHUNK != 0 && TM * TN == 4;
+    KtilePtrs<BK> pins;
+    if constexpr (PINNED) pins = pin_ktile_ptrs<BK, LDA, LDB>(a_base, b_base);
+    auto take_tot = [&]() {                       // the tile's value: the sum of the chunk sums
+        if constexpr (CHUNK != 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];
+        }
+    };
+    if (AHEAD2 && TM * TN == 1 && !(nk & 1)) {
         // 64x64 tiles: a k-tile is 16 MFMAs per wave -- 1024 matrix-pipe cycles, ~4000 when four waves share the SIMD -- while a loaded HBM / L2
         // round trip can take longer (scratch/lab/expand_lab.hip: 6200 -> 5800 cycles per k-tile, fused kernel 2.98 -> 2.95 ms): the operands are
-        // requested TWO k-tiles ahead, in two staging register sets (+16 VGPRs; the LDS stays single-staged)
-        float4 ra2[NA], rb2[BN * BK / 1024];
+        // requested TWO k-tiles ahead, in two staging register sets (+16 VGPRs; the LDS stays single-staged).  An even k-tile count only (Cin a
+        // multiple of 64); one trip of the loop = two k-tiles = ONE chunk of the two-level sum.
+        static_assert(!AHEAD2 || CHUNK % (2 * BK) == 0, "a chunk is a whole number of trips of the two-ahead loop");
+        float4 ra1[NA], ra2[NA], rb2[BN * BK / 1024];
         auto stage = [&](float4 (&qa)[NA], float4 (&qb)[BN * BK / 1024], int kt) {
             load_a();
 #pragma unroll
             for (int j = 0; j < NA; ++j) qa[j] = ra[j];
             load_tile<true, BN, BK>(Wt, N, D, n0, kt * BK, qb);
         };
-        // tile 0 -> LDS; an odd k-tile count runs one k-tile in the plain one-ahead scheme first, so that an even number is left
         load_a();
         load_tile<true, BN, BK>(Wt, N, D, n0, 0, rb);
         store_tile<BM, BK>(As, ra);
         store_tile<BN, BK>(Bs, rb);
         __syncthreads();
-        int kt = 0;
-        float4 ra1[NA];
-        if (nk & 1) {
-            if (nk > 1) stage(ra1, rb, 1);
-            mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(0, a_base, b_base, acc, tot);
-            __syncthreads();
-            if (nk > 1) {
-                store_tile<BM, BK>(As, ra1);
-                store_tile<BN, BK>(Bs, rb);
-                __syncthreads();
-            }
-            kt = 1;
-        }
-        if (kt < nk) stage(ra1, rb, kt + 1);
+        stage(ra1, rb, 1);
         // steady state, two k-tiles per trip: tile kt is in the LDS, tile kt + 1 on its way to (ra1, rb), tile kt + 2 is requested into (ra2, rb2).
         // The requests inside the loop are UNCONDITIONAL (hipcc's wait-count pass falls back to vmcnt(0) behind a conditional load, which would
         // undo the prefetch); those of the last trip point past the last tap / weight column -- range-checked buffer loads, values never used.
-        for (; kt < nk; kt += 2) {
+        for (int kt = 0; kt < nk; kt += 2) {
             stage(ra2, rb2, kt + 2);
-            mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(kt, a_base, b_base, acc, tot);
+            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
             __syncthreads();
             store_tile<BM, BK>(As, ra1);
             store_tile<BN, BK>(Bs, rb);
             __syncthreads();
             stage(ra1, rb, kt + 3);
-            mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(kt + 1, a_base, b_base, acc, tot);
+            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
             __syncthreads();
             if (kt + 2 < nk) {
                 store_tile<BM, BK>(As, ra2);
                 store_tile<BN, BK>(Bs, rb2);
                 __syncthreads();
             }
+            if constexpr (CHUNK == 2 * BK) fold_chunk<TM, TN>(tot, acc);
+            else if constexpr (CHUNK != 0) { if (((kt + 2) * BK) % CHUNK == 0 || kt + 2 >= nk) fold_chunk<TM, TN>(tot, acc); }
         }
-        two_level_value<TM, TN, CHUNK>(acc, tot);
+        take_tot();
         return;
     }
     load_a();
@@ -150,21 +151,26 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
     store_tile<BN, BK>(Bs, rb);
     __syncthreads();
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            load_a();
-            load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
-        }
-        mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(kt, a_base, b_base, acc, tot);
-        __syncthreads();
-        if (more) {
-            store_tile<BM, BK>(As, ra);
-            store_tile<BN, BK>(Bs, rb);
+    // outer loop: chunks of the two-level sum (one pass when CHUNK == 0); inner loop: the staged k-tiles of a chunk (gemm_tile.hpp)
+    for (int kt = 0; kt < nk;) {
+        const int kend = (CHUNK && kt + CHUNK / BK < nk) ? kt + CHUNK / BK : nk;
+        for (; kt < kend; ++kt) {
+            const bool more = (kt + 1 < nk);
+            if (more) {
+                load_a();
+                load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
+            }
+            mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED>(a_base, b_base, pins, acc);
             __syncthreads();
+            if (more) {
+                store_tile<BM, BK>(As, ra);
+                store_tile<BN, BK>(Bs, rb);
+                __syncthreads();
+            }
         }
+        if constexpr (CHUNK != 0) fold_chunk<TM, TN>(tot, acc);
     }
-    two_level_value<TM, TN, CHUNK>(acc, tot);
+    take_tot();
 }
 
 }  // namespace isx

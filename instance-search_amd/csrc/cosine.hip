@@ -87,22 +87,35 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
 
     const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
     const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+    constexpr bool PINNED = CHUNK != 0 && TM * TN == 4;
+    KtilePtrs<BK> pins;
+    if constexpr (PINNED) pins = pin_ktile_ptrs<BK, LDA, LDB>(a_base, b_base);
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
-            load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
-        }
-        mfma_ktile_2l<TM, TN, BK, LDA, LDB, CHUNK>(kt, a_base, b_base, acc, tot);
-        __syncthreads();
-        if (more) {
-            store_tile<BM, BK>(As, ra);
-            store_tile<BN, BK>(Bs, rb);
+    // outer loop: chunks of the two-level sum (one pass when CHUNK == 0); inner loop: the staged k-tiles of a chunk
+    for (int kt = 0; kt < nk;) {
+        const int kend = (CHUNK && kt + CHUNK / BK < nk) ? kt + CHUNK / BK : nk;
+        for (; kt < kend; ++kt) {
+            const bool more = (kt + 1 < nk);
+            if (more) {
+                load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
+                load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
+            }
+            mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED>(a_base, b_base, pins, acc);
             __syncthreads();
+            if (more) {
+                store_tile<BM, BK>(As, ra);
+                store_tile<BN, BK>(Bs, rb);
+                __syncthreads();
+            }
         }
+        if constexpr (CHUNK != 0) fold_chunk<TM, TN>(tot, acc);
     }
-    two_level_value<TM, TN, CHUNK>(acc, tot);
+    if constexpr (CHUNK != 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];       // the epilogues below read acc
+    }
 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (EPI == 3) {
@@ -199,8 +212,9 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
     }
 }
 
+// (convolution mode in 128x128 tiles: two accumulator sets, two workgroups per CU -- without the bound hipcc takes 296 registers and one fits)
 template <bool ALIGNED, int TM, int TN, int EPI, int BK>
-__global__ __launch_bounds__(256) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
+__global__ __launch_bounds__(256, (EPI == 2 && TM * TN == 4) ? ISX_WG_PER_CU_128 : 1) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
                                                           const float* __restrict__ G, int64_t N, int D,
                                                           float* __restrict__ C, int64_t ldc, TileMap tm,
                                                           const float* __restrict__ thr, uint8_t* __restrict__ gflag,
@@ -235,10 +249,10 @@ __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_tail_kernel(co
 
 // rows covered by whole rounds of 128x128 tiles when the rest of the grid is a partial round (0: no split)
 std::atomic<int> g_tail_split{1};
-int64_t gemm_tail_split_rows(int64_t M, int64_t N) {
+int64_t gemm_tail_split_rows(int64_t M, int64_t N, int64_t slots) {
     static const bool env_off = [] { const char* e = getenv("ISX_TAIL_SPLIT"); return e && e[0] == '0'; }();      // A/B from the environment
     if (env_off) return 0;
-    const int64_t tn = (N + 127) / 128, tiles = ((M + 127) / 128) * tn, slots = 1024;
+    const int64_t tn = (N + 127) / 128, tiles = ((M + 127) / 128) * tn;
     if (!g_tail_split || tn > slots || slots % tn != 0) return 0;
     const int64_t rounds = tiles / slots, rem = tiles - rounds * slots;
     if (rounds < 1 || rem == 0 || rem > slots * 4 / 5) return 0;
@@ -254,12 +268,13 @@ struct TileCfg { int tm, tn, wg_per_cu; float eff; };
 static const TileCfg kCfgs[] = { {2, 2, 4, 0.92f}, {1, 2, 4, 0.87f}, {2, 1, 4, 0.89f}, {1, 1, 6, 0.84f} };     // 10 000 x 32 768 x 2048: 145 / 137 / 140 / 132 TFLOP/s
 // The tile shape (index into kCfgs: 0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64) with the smallest estimated time among those in
 // `mask`; eff[c]: steady-state efficiency of shape c for the calling kernel family; split > 0: shape 0 runs with a 64x64 tail.
-int pick_tile_cfg(int64_t M, int64_t N, int64_t split, const float* eff, unsigned mask) {
+int pick_tile_cfg(int64_t M, int64_t N, int64_t split, const float* eff, unsigned mask, int wg_per_cu_128) {
     int best = -1;
     double best_t = 1e300;
     for (int c = 0; c < 4; ++c) {
         if (!((mask >> c) & 1u)) continue;
-        const TileCfg& k = kCfgs[c];
+        TileCfg k = kCfgs[c];
+        if (c == 0) k.wg_per_cu = wg_per_cu_128;
         const double tiles = (double)((M + 64 * k.tm - 1) / (64 * k.tm)) * (double)((N + 64 * k.tn - 1) / (64 * k.tn));
         const double slots = 256.0 * k.wg_per_cu;
         // time in units of "one full round" (= wg_per_cu tiles on every CU).  Workgroups finish unevenly,
@@ -313,9 +328,10 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     if (((M + 63) / 64) * ((N + 63) / 64) >= (1ll << 31)) { isx_set_error("cosine gemm: too many tiles for one grid"); return ISX_ERR_ARG; }
     const bool aligned = (D % 32 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0);     // no k tail for BK = 16 or 32
     const bool aligned16 = aligned || ((D % 16 == 0) && (((uintptr_t)Q | (uintptr_t)G) % 16 == 0));   // enough for the BK = 16 (128x128) tiles: D = 464
-    const int64_t split = (epi == 2) ? gemm_tail_split_rows(M, N) : 0;      // convolutions: 128x128 tiles + 64x64 tail in one grid
+    // convolutions: 128x128 tiles (two workgroups per CU: the two-level sum) + 64x64 tail in one grid
+    const int64_t split = (epi == 2) ? gemm_tail_split_rows(M, N, 256 * ISX_WG_PER_CU_128) : 0;
     static const float eff_gemm[4] = {kCfgs[0].eff, kCfgs[1].eff, kCfgs[2].eff, kCfgs[3].eff};
-    int best = pick_tile_cfg(M, N, split, eff_gemm, 0xF);
+    int best = pick_tile_cfg(M, N, split, eff_gemm, 0xF, epi == 2 ? ISX_WG_PER_CU_128 : 4);
     // (Round 1 forced 64x64 tiles on residual layers and 128x64 on the others: the per-element epilogue was a visible share of a tile.
     // With the buffer-instruction epilogue the same round / tail model as for the score GEMM picks the convolution tiles: 128x128
     // wherever the grid fills the chip -- 256->1024 + residual 0.90 -> 0.87 ms, 512->2048 + residual 0.85 -> 0.81, 512->256 1.64 -> 1.58 --

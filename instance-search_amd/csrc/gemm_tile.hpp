@@ -180,7 +180,11 @@ __device__ __forceinline__ void conv_epilogue_buffers(const f32x16 (&acc)[TM][TN
 // Why: a chain over K terms drifts from the exact sum like eps . K, chunks of c terms like eps . sqrt(K c + K^2 / c); measured end to end
 // (scratch/chunk_study.py, ResNet-50 / ResNet-152 descriptors against a float64 evaluation): one chain is 1.2x further from float64 than torch's
 // CPU fp32 path, chunks of 64 land at 0.7x.  K <= 64 (one chunk): tot = 0 + chain, the bits of rounds 1-4.  Restated by oracle/isx_oracle.c.
+#ifdef ISX_CONV_CHUNK_AB
+constexpr int kConvChunk = ISX_CONV_CHUNK_AB;      // A/B builds only (tools/build_variant.sh): the oracle follows ISX_CONV_CHUNK
+#else
 constexpr int kConvChunk = ISX_CONV_CHUNK;
+#endif
 #ifndef ISX_WG_PER_CU_128
 #define ISX_WG_PER_CU_128 2     // resident workgroups per CU of the 128x128 convolution tiles: two accumulator sets = 128 VGPRs + ~55 -> two waves per SIMD
 #endif
@@ -260,6 +264,50 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, con
     }
 }
 
+// Operand addresses of the k-steps of a staged k-tile, PINNED in registers.  The K-major images put k-step kk at 2 kk LDA floats = more than the
+// 1020 B a ds_read2_b32 offset reaches, so every k-step needs a base register of its own.  In the plain loops hipcc computes these 2 x BK / 2
+// addresses once; with the chunk fold in the loop it re-derived them with a v_add_u32 in front of every ds_read2 instead (15 VALU instructions
+// among the 32 MFMAs of a k-tile; the two-level kernels ran 10 % below the one-chain ones at ANY chunk length).  The empty asm makes each
+// address an opaque 32-bit LDS pointer that cannot be rematerialised.
+using lds_cfp = const __attribute__((address_space(3))) float*;
+template <int BK>
+struct KtilePtrs { lds_cfp a[BK / 2], b[BK / 2]; };
+template <int BK, int LDA, int LDB>
+__device__ __forceinline__ KtilePtrs<BK> pin_ktile_ptrs(const float* a_base, const float* b_base) {
+    KtilePtrs<BK> p;
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+        p.a[kk] = (lds_cfp)(a_base + 2 * kk * LDA);
+        p.b[kk] = (lds_cfp)(b_base + 2 * kk * LDB);
+        asm volatile("" : "+v"(p.a[kk]));
+        asm volatile("" : "+v"(p.b[kk]));
+    }
+    return p;
+}
+// the k loop of mfma_ktile's prefetch variant on pinned addresses
+template <int TM, int TN, int BK>
+__device__ __forceinline__ void mfma_ktile_pinned(const KtilePtrs<BK>& p, f32x16 (&acc)[TM][TN]) {
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[0][i] = p.a[0][32 * i];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[0][j] = p.b[0][32 * j];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+        if (kk + 1 < BK / 2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[(kk + 1) & 1][i] = p.a[kk + 1][32 * i];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[(kk + 1) & 1][j] = p.b[kk + 1][32 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);             // keep the reads above the MFMAs
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+    }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void zero_tiles(f32x16 (&t)[TM][TN]) {
 #pragma unroll
@@ -270,31 +318,22 @@ __device__ __forceinline__ void zero_tiles(f32x16 (&t)[TM][TN]) {
             for (int e = 0; e < 16; ++e) t[i][j][e] = 0.0f;
 }
 
-// k-tile kt of a reduction summed in two levels (CHUNK terms per chain; 0 = one chain, acc only): after the last k-tile of a chunk the finished
-// chain is added to tot and acc restarts from 0.  acc and tot must be zero before k-tile 0; the value is tot + acc after the last k-tile
-// (two_level_value; acc then holds the last, partial chunk or 0).
-// (A/B, round 5: adding the chain lazily at the next chunk's start with C = 0 in its first MFMAs -- no zeroing, no wait for the last MFMA -- needs two
-// copies of the k-tile body and came out 3 % SLOWER on the bench step: 74.5 vs 71.9 ms.)
-template <int TM, int TN, int BK, int LDA, int LDB, int CHUNK>
-__device__ __forceinline__ void mfma_ktile_2l(int kt, const float* __restrict__ a_base, const float* __restrict__ b_base, f32x16 (&acc)[TM][TN],
-                                              f32x16 (&tot)[CHUNK ? TM : 1][CHUNK ? TN : 1]) {
-    mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
-    if constexpr (CHUNK != 0) {
-        static_assert(CHUNK % BK == 0 && ((CHUNK / BK) & (CHUNK / BK - 1)) == 0, "a chunk is 2^n k-tiles");
-        if (((kt + 1) & (CHUNK / BK - 1)) == 0) {        // uniform
-            add_chunk<TM, TN>(tot, acc);
-            zero_tiles(acc);
-        }
-    }
+// Loop shape of the two-level sum (CHUNK terms per chain; 0 = one chain): the k loop is NESTED -- an outer loop over the chunks, the inner loop
+// over the CHUNK / BK k-tiles of a chunk is the plain staged loop of rounds 1-4 (loads of the next k-tile, MFMAs, barrier, LDS stores, barrier),
+// and fold_chunk runs between two inner loops:  tot = tot + acc;  acc = 0  (after the last chunk too: the value is tot).
+// Why nested (round 5 A/B on the 3x3 / dual families, ms per lab pass; one chain: 9.89 / 6.61): a conditional fold INSIDE the k loop cost 10-15 %
+// at any chunk length -- behind the MFMAs it needs 16 wait states and keeps hipcc from hoisting the loop's first barrier in between the last
+// MFMAs, the operand addresses were re-derived with a v_add_u32 per ds_read2 (11.13 / 7.56; addresses pinned: 10.85 / 7.29); in front of the
+// MFMAs hipcc duplicates the loop body and serialises the staging loads (11.37 / 7.61); C = 0 in the chunk's first MFMAs instead of zeroing
+// (two copies of the k-tile body) was slower still.
+template <int TM, int TN>
+__device__ __forceinline__ void fold_chunk(f32x16 (&tot)[TM][TN], f32x16 (&acc)[TM][TN]) {
+    add_chunk<TM, TN>(tot, acc);
+    zero_tiles(acc);
 }
-template <int TM, int TN, int CHUNK>
-__device__ __forceinline__ void two_level_value(f32x16 (&acc)[TM][TN], const f32x16 (&tot)[CHUNK ? TM : 1][CHUNK ? TN : 1]) {
-    if constexpr (CHUNK != 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j] + acc[i][j];
-    }
+template <int TM, int TN, int BK, int LDA, int LDB, bool PINNED>
+__device__ __forceinline__ void mfma_ktile_sel(const float* __restrict__ a_base, const float* __restrict__ b_base, const KtilePtrs<BK>& pins, f32x16 (&acc)[TM][TN]) {
+    if constexpr (PINNED) mfma_ktile_pinned<TM, TN, BK>(pins, acc);
+    else mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
 }
-
 }  // namespace isx

@@ -24,10 +24,10 @@ int launch_conv1x1_gemm(const float* x, int64_t M, const float* w, int64_t N, in
 // Tail of a convolution launch in 128x128 tiles: rows covered by whole rounds of 1024 resident workgroups when the rest of the grid is a
 // partial round -- the caller runs the remaining rows as 64x64 tiles in the same grid; 0 = no split.  g_tail_split: debug / A-B switch.
 extern std::atomic<int> g_tail_split;      // (the debug / A-B knobs are relaxed atomics: a test thread may flip them while another thread launches)
-int64_t gemm_tail_split_rows(int64_t M, int64_t N);
+int64_t gemm_tail_split_rows(int64_t M, int64_t N, int64_t slots = 1024);       // slots: resident 128x128 workgroups of the calling kernel (256 CUs x workgroups per CU)
 // Tile shape (0 = 128x128, 1 = 64x128, 2 = 128x64, 3 = 64x64) with the smallest estimated launch time among those in `mask` (rounds of resident
 // workgroups + tail + per-CU quantisation, cosine.hip); eff[4]: steady-state efficiency per shape of the calling kernel family.
-int pick_tile_cfg(int64_t M, int64_t N, int64_t split, const float* eff, unsigned mask);
+int pick_tile_cfg(int64_t M, int64_t N, int64_t split, const float* eff, unsigned mask, int wg_per_cu_128 = 4);
 
 // Streaming variant for the HBM-bound Cin = 64 layers (stream1x1.hip): persistent workgroups, weights in registers, pixel tiles by LDS-DMA.
 bool conv1x1_stream_applicable(int64_t M, int Cin, int Cout, const float* x, const float* res);
