@@ -162,27 +162,34 @@ __device__ __forceinline__ void conv1x1_dual_tile(float* __restrict__ lds, const
 
     const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
     const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
-    constexpr bool PINNED = kConvChunk != 0 && TM * TN == 4;
+    constexpr bool PINNED = kConvChunk != 0 && TM * TN == 4 && ISX_PIN_KTILE;
     KtilePtrs<BK> pins;
     if constexpr (PINNED) pins = pin_ktile_ptrs<BK, LDA, LDB>(a_base, b_base);
-    // outer loop: chunks of the two-level sum over the flattened [t ; x] reduction; inner loop: the staged k-tiles of a chunk (gemm_tile.hpp)
-    for (int kt = 0; kt < nk;) {
-        const int kend = (kConvChunk && kt + kConvChunk / BK < nk) ? kt + kConvChunk / BK : nk;
-        for (; kt < kend; ++kt) {
-            const bool more = (kt + 1 < nk);
-            if (more) {
-                load_a();
-                load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
-            }
-            mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED>(a_base, b_base, pins, acc);
-            __syncthreads();
-            if (more) {
-                store_tile<BM, BK>(As, ra);
-                store_tile<BN, BK>(Bs, rb);
-                __syncthreads();
-            }
+    // outer loop: chunks of the two-level sum over the flattened [t ; x] reduction; inner loop: the staged k-tiles of a chunk (gemm_tile.hpp); the
+    // first k-tile of a chunk starts its chains with C = 0
+    auto body = [&](int kt, auto zero_c) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_a();
+            load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
         }
-        if constexpr (kConvChunk != 0) fold_chunk<TM, TN>(tot, acc);
+        mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc);
+        __syncthreads();
+        if (more) {
+            store_tile<BM, BK>(As, ra);
+            store_tile<BN, BK>(Bs, rb);
+            __syncthreads();
+        }
+    };
+    if constexpr (kConvChunk == 0) {
+        for (int kt = 0; kt < nk; ++kt) body(kt, std::false_type());
+    } else {
+        for (int kt = 0; kt < nk;) {
+            const int kend = kt + kConvChunk / BK < nk ? kt + kConvChunk / BK : nk;
+            body(kt++, std::true_type());
+            for (; kt < kend; ++kt) body(kt, std::false_type());
+            add_chunk<TM, TN>(tot, acc);
+        }
     }
     if constexpr (kConvChunk != 0) {
 #pragma unroll

@@ -91,7 +91,7 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
     const int nk = D / BK;
     const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
     const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
-    constexpr bool PINNED = CHUNK != 0 && TM * TN == 4;
+    constexpr bool PINNED = CHUNK != 0 && TM * TN == 4 && ISX_PIN_KTILE;
     KtilePtrs<BK> pins;
     if constexpr (PINNED) pins = pin_ktile_ptrs<BK, LDA, LDB>(a_base, b_base);
     auto take_tot = [&]() {                       // the tile's value: the sum of the chunk sums
@@ -126,7 +126,8 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
         // undo the prefetch); those of the last trip point past the last tap / weight column -- range-checked buffer loads, values never used.
         for (int kt = 0; kt < nk; kt += 2) {
             stage(ra2, rb2, kt + 2);
-            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+            if (CHUNK != 0 && (kt * BK) % (CHUNK ? CHUNK : 1) == 0) mfma_ktile<TM, TN, BK, LDA, LDB, CHUNK != 0>(a_base, b_base, acc);      // chunk start: C = 0
+            else mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
             __syncthreads();
             store_tile<BM, BK>(As, ra1);
             store_tile<BN, BK>(Bs, rb);
@@ -139,8 +140,8 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
                 store_tile<BN, BK>(Bs, rb2);
                 __syncthreads();
             }
-            if constexpr (CHUNK == 2 * BK) fold_chunk<TM, TN>(tot, acc);
-            else if constexpr (CHUNK != 0) { if (((kt + 2) * BK) % CHUNK == 0 || kt + 2 >= nk) fold_chunk<TM, TN>(tot, acc); }
+            if constexpr (CHUNK == 2 * BK) add_chunk<TM, TN>(tot, acc);
+            else if constexpr (CHUNK != 0) { if (((kt + 2) * BK) % CHUNK == 0 || kt + 2 >= nk) add_chunk<TM, TN>(tot, acc); }
         }
         take_tot();
         return;
@@ -151,24 +152,31 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
     store_tile<BN, BK>(Bs, rb);
     __syncthreads();
 
-    // outer loop: chunks of the two-level sum (one pass when CHUNK == 0); inner loop: the staged k-tiles of a chunk (gemm_tile.hpp)
-    for (int kt = 0; kt < nk;) {
-        const int kend = (CHUNK && kt + CHUNK / BK < nk) ? kt + CHUNK / BK : nk;
-        for (; kt < kend; ++kt) {
-            const bool more = (kt + 1 < nk);
-            if (more) {
-                load_a();
-                load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
-            }
-            mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED>(a_base, b_base, pins, acc);
-            __syncthreads();
-            if (more) {
-                store_tile<BM, BK>(As, ra);
-                store_tile<BN, BK>(Bs, rb);
-                __syncthreads();
-            }
+    // outer loop: chunks of the two-level sum (one pass when CHUNK == 0); inner loop: the staged k-tiles of a chunk (gemm_tile.hpp); the first
+    // k-tile of a chunk starts its chains with C = 0
+    auto body = [&](int kt, auto zero_c) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_a();
+            load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
         }
-        if constexpr (CHUNK != 0) fold_chunk<TM, TN>(tot, acc);
+        mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc);
+        __syncthreads();
+        if (more) {
+            store_tile<BM, BK>(As, ra);
+            store_tile<BN, BK>(Bs, rb);
+            __syncthreads();
+        }
+    };
+    if constexpr (CHUNK == 0) {
+        for (int kt = 0; kt < nk; ++kt) body(kt, std::false_type());
+    } else {
+        for (int kt = 0; kt < nk;) {
+            const int kend = kt + CHUNK / BK < nk ? kt + CHUNK / BK : nk;
+            body(kt++, std::true_type());
+            for (; kt < kend; ++kt) body(kt, std::false_type());
+            add_chunk<TM, TN>(tot, acc);
+        }
     }
     take_tot();
 }

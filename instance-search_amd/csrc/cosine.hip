@@ -87,28 +87,35 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
 
     const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
     const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
-    constexpr bool PINNED = CHUNK != 0 && TM * TN == 4;
+    constexpr bool PINNED = CHUNK != 0 && TM * TN == 4 && ISX_PIN_KTILE;
     KtilePtrs<BK> pins;
     if constexpr (PINNED) pins = pin_ktile_ptrs<BK, LDA, LDB>(a_base, b_base);
 
-    // outer loop: chunks of the two-level sum (one pass when CHUNK == 0); inner loop: the staged k-tiles of a chunk
-    for (int kt = 0; kt < nk;) {
-        const int kend = (CHUNK && kt + CHUNK / BK < nk) ? kt + CHUNK / BK : nk;
-        for (; kt < kend; ++kt) {
-            const bool more = (kt + 1 < nk);
-            if (more) {
-                load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
-                load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
-            }
-            mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED>(a_base, b_base, pins, acc);
-            __syncthreads();
-            if (more) {
-                store_tile<BM, BK>(As, ra);
-                store_tile<BN, BK>(Bs, rb);
-                __syncthreads();
-            }
+    // outer loop: chunks of the two-level sum (one pass when CHUNK == 0); inner loop: the staged k-tiles of a chunk.  The FIRST k-tile of a chunk is
+    // a second copy of the body whose first MFMAs take C = 0 (no zeroing pass), the chain is added to tot behind the chunk's last barrier.
+    auto body = [&](int kt, auto zero_c) {
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
+            load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
         }
-        if constexpr (CHUNK != 0) fold_chunk<TM, TN>(tot, acc);
+        mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc);
+        __syncthreads();
+        if (more) {
+            store_tile<BM, BK>(As, ra);
+            store_tile<BN, BK>(Bs, rb);
+            __syncthreads();
+        }
+    };
+    if constexpr (CHUNK == 0) {
+        for (int kt = 0; kt < nk; ++kt) body(kt, std::false_type());
+    } else {
+        for (int kt = 0; kt < nk;) {
+            const int kend = kt + CHUNK / BK < nk ? kt + CHUNK / BK : nk;
+            body(kt++, std::true_type());
+            for (; kt < kend; ++kt) body(kt, std::false_type());
+            add_chunk<TM, TN>(tot, acc);
+        }
     }
     if constexpr (CHUNK != 0) {
 #pragma unroll
@@ -212,9 +219,10 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
     }
 }
 
-// (convolution mode in 128x128 tiles: two accumulator sets, two workgroups per CU -- without the bound hipcc takes 296 registers and one fits)
+// (convolution mode: two accumulator sets.  128x128 tiles: two workgroups per CU -- without the bound hipcc takes 296 registers and one fits;
+// the smaller tiles serve the HBM-bound layers and keep four -- unbounded, the 128x64 shape took 164 registers and lost a fifth on 256 -> 64 at 56x56)
 template <bool ALIGNED, int TM, int TN, int EPI, int BK>
-__global__ __launch_bounds__(256, (EPI == 2 && TM * TN == 4) ? ISX_WG_PER_CU_128 : 1) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
+__global__ __launch_bounds__(256, EPI != 2 ? 1 : TM * TN == 4 ? ISX_WG_PER_CU_128 : 4) void cosine_gemm_kernel(const float* __restrict__ Q, int64_t M,
                                                           const float* __restrict__ G, int64_t N, int D,
                                                           float* __restrict__ C, int64_t ldc, TileMap tm,
                                                           const float* __restrict__ thr, uint8_t* __restrict__ gflag,

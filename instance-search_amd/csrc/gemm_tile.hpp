@@ -7,6 +7,8 @@
 #ifndef ISX_KLOOP_PREFETCH
 #define ISX_KLOOP_PREFETCH 1    // A/B: 1 = operand fragments of k-step kk + 1 fetched before the MFMAs of step kk (large tiles; +0.7-1.5 % on the big GEMMs)
 #endif
+#include <type_traits>
+
 #include "isx_internal.hpp"
 
 namespace isx {
@@ -269,6 +271,9 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, con
 // addresses once; with the chunk fold in the loop it re-derived them with a v_add_u32 in front of every ds_read2 instead (15 VALU instructions
 // among the 32 MFMAs of a k-tile; the two-level kernels ran 10 % below the one-chain ones at ANY chunk length).  The empty asm makes each
 // address an opaque 32-bit LDS pointer that cannot be rematerialised.
+#ifndef ISX_PIN_KTILE
+#define ISX_PIN_KTILE 1
+#endif
 using lds_cfp = const __attribute__((address_space(3))) float*;
 template <int BK>
 struct KtilePtrs { lds_cfp a[BK / 2], b[BK / 2]; };
@@ -285,8 +290,9 @@ __device__ __forceinline__ KtilePtrs<BK> pin_ktile_ptrs(const float* a_base, con
     return p;
 }
 // the k loop of mfma_ktile's prefetch variant on pinned addresses
-template <int TM, int TN, int BK>
+template <int TM, int TN, int BK, bool ZERO_C = false>
 __device__ __forceinline__ void mfma_ktile_pinned(const KtilePtrs<BK>& p, f32x16 (&acc)[TM][TN]) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float a[2][TM], b[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) a[0][i] = p.a[0][32 * i];
@@ -304,7 +310,7 @@ __device__ __forceinline__ void mfma_ktile_pinned(const KtilePtrs<BK>& p, f32x16
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], (ZERO_C && kk == 0) ? zero : acc[i][j], 0, 0, 0);
     }
 }
 
@@ -331,9 +337,9 @@ __device__ __forceinline__ void fold_chunk(f32x16 (&tot)[TM][TN], f32x16 (&acc)[
     add_chunk<TM, TN>(tot, acc);
     zero_tiles(acc);
 }
-template <int TM, int TN, int BK, int LDA, int LDB, bool PINNED>
+template <int TM, int TN, int BK, int LDA, int LDB, bool PINNED, bool ZERO_C = false>
 __device__ __forceinline__ void mfma_ktile_sel(const float* __restrict__ a_base, const float* __restrict__ b_base, const KtilePtrs<BK>& pins, f32x16 (&acc)[TM][TN]) {
-    if constexpr (PINNED) mfma_ktile_pinned<TM, TN, BK>(pins, acc);
-    else mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+    if constexpr (PINNED) mfma_ktile_pinned<TM, TN, BK, ZERO_C>(pins, acc);
+    else mfma_ktile<TM, TN, BK, LDA, LDB, ZERO_C>(a_base, b_base, acc);
 }
 }  // namespace isx

@@ -34,17 +34,38 @@ with torch.no_grad():
         b = torch.randn(Cout, device=dev); r = cl(torch.randn(B, Cout, H, H, device=dev)) if res else None
         t = timeit(lambda: ops.conv1x1_nhwc(x, w, b, r, True)); f = 2.0 * B * H * H * Cin * Cout
         tot["1x1"] += t; fl["1x1"] += f
-        print("1x1 H=%3d %5d->%5d res=%d %7.3f ms %6.1f TF" % (H, Cin, Cout, res, t, f / t / 1e9), flush=True)
+        per = ""
+        if os.environ.get("LAB_CFGS"):
+            from isx._lib import lib
+            for cfg in (0, 2, 3):
+                lib().isx_debug_set_gemm_cfg(cfg)
+                per += "  cfg%d %.3f" % (cfg, timeit(lambda: ops.conv1x1_nhwc(x, w, b, r, True)))
+            lib().isx_debug_set_gemm_cfg(-1)
+        print("1x1 H=%3d %5d->%5d res=%d %7.3f ms %6.1f TF%s" % (H, Cin, Cout, res, t, f / t / 1e9, per), flush=True)
     for H, C, s in three:
         x = cl(torch.relu(torch.randn(B, C, H, H, device=dev))); w = cl(torch.randn(C, C, 3, 3, device=dev) * (9 * C) ** -0.5).permute(0, 2, 3, 1).contiguous()
         b = torch.randn(C, device=dev)
         t = timeit(lambda: ops.conv3x3_nhwc(x, w, b, s, None, True)); Ho = (H - 1) // s + 1; f = 18.0 * B * Ho * Ho * C * C
         tot["3x3"] += t; fl["3x3"] += f
-        print("3x3 H=%3d %5d s=%d        %7.3f ms %6.1f TF" % (H, C, s, t, f / t / 1e9), flush=True)
+        per = ""
+        if os.environ.get("LAB_CFGS"):
+            from isx._lib import lib
+            for cfg in (0, 2, 3):
+                lib().isx_debug_set_conv_cfg(cfg)
+                per += "  cfg%d %.3f" % (cfg, timeit(lambda: ops.conv3x3_nhwc(x, w, b, s, None, True)))
+            lib().isx_debug_set_conv_cfg(-1)
+        print("3x3 H=%3d %5d s=%d        %7.3f ms %6.1f TF%s" % (H, C, s, t, f / t / 1e9, per), flush=True)
     for Ho, K1, K2, Cout, s in dual:
         tt = cl(torch.relu(torch.randn(B, K1, Ho, Ho, device=dev))); x = cl(torch.relu(torch.randn(B, K2, Ho * s, Ho * s, device=dev)))
         w = torch.randn(Cout, K1 + K2, device=dev) * (K1 + K2) ** -0.5; b = torch.randn(Cout, device=dev)
         t = timeit(lambda: ops.conv1x1_dual_nhwc(tt, x, w, b, s, True)); f = 2.0 * B * Ho * Ho * (K1 + K2) * Cout
         tot["dual"] += t; fl["dual"] += f
-        print("dual Ho=%3d %4d+%4d->%5d   %7.3f ms %6.1f TF" % (Ho, K1, K2, Cout, t, f / t / 1e9), flush=True)
+        per = ""
+        if os.environ.get("LAB_CFGS"):
+            from isx._lib import lib
+            for cfg in (0, 2, 3):
+                lib().isx_debug_set_conv_cfg(cfg)
+                per += "  cfg%d %.3f" % (cfg, timeit(lambda: ops.conv1x1_dual_nhwc(tt, x, w, b, s, True)))
+            lib().isx_debug_set_conv_cfg(-1)
+        print("dual Ho=%3d %4d+%4d->%5d   %7.3f ms %6.1f TF%s" % (Ho, K1, K2, Cout, t, f / t / 1e9, per), flush=True)
 print("TOTAL %s: " % os.environ.get("ISX_LIB", "in-tree") + "  ".join("%s %.2f ms (%.1f TF)" % (k, tot[k], fl[k] / tot[k] / 1e9) for k in tot), flush=True)
