@@ -128,11 +128,37 @@ def _check(res_gpu, res_cpu, emb_gpu, emb_cpu, labs, what, cos_tol=COS_TOL):
         assert res_gpu[0] == res_cpu[0], "%s: P@1 %r vs %r" % (what, res_gpu[0], res_cpu[0])
     else:
         assert abs(res_gpu[0] - res_cpu[0]) <= label_flips / float(len(ql)) + 1e-12, "%s: P@1 %r vs %r with %d label flips" % (what, res_gpu[0], res_cpu[0], label_flips)
-    assert abs(res_gpu[1] - res_cpu[1]) <= MAP_TOL, "%s: mAP %r vs %r" % (what, res_gpu[1], res_cpu[1])
+    # mAP: within 1e-4 -- except for queries whose ranked LABEL sequence differs between the two paths, and those differences must all be ties
+    # inside the arithmetic's resolution (the CPU path's own scores of the two items at a differing rank lie closer than 2 x max|dcos|): the two
+    # APs of such a query are both the reference's answer under a different summation order.  The rest of the mean must agree to 1e-4.
+    from utils.metrics import _average_precisions
+    qlab = torch.tensor([sorted(set(ql + gl)).index(l) for l in ql], dtype=torch.int32)
+    glab = torch.tensor([sorted(set(ql + gl)).index(l) for l in gl], dtype=torch.int32)
+    full_g = sim_gpu.sort(dim=1, descending=True, stable=True).indices
+    full_c = sim_cpu.sort(dim=1, descending=True, stable=True).indices
+    seq_differs = (glab[full_g] != glab[full_c]).any(1)
+    unexplained_ap = 0
+    for q in seq_differs.nonzero().flatten().tolist():
+        for j in (glab[full_g[q]] != glab[full_c[q]]).nonzero().flatten().tolist():
+            if abs(float(sim_cpu[q, full_c[q, j]] - sim_cpu[q, full_g[q, j]])) > 2 * dcos:
+                unexplained_ap += 1
+    assert unexplained_ap == 0, "%s: %d rank positions change a label sequence beyond the arithmetic's resolution" % (what, unexplained_ap)
+    ap_g = _average_precisions(sim_gpu, qlab, glab, 1)
+    ap_c = _average_precisions(sim_cpu, qlab, glab, 1)
+    valid = (ap_c == ap_c)
+    same = valid & ~seq_differs
+    assert float((ap_g[same] - ap_c[same]).abs().max() if same.any() else 0.0) <= 1e-12, "%s: AP differs on identical label sequences" % what
+    tie_shift = float((ap_g[valid & seq_differs] - ap_c[valid & seq_differs]).sum()) / max(int(valid.sum()), 1)
+    print("%s: %d of %d queries have a tie-swapped label sequence; they move mAP by %.3g" % (what, int(seq_differs.sum()), len(ql), tie_shift))
+    assert abs((res_gpu[1] - res_cpu[1]) - tie_shift) <= MAP_TOL, "%s: mAP %r vs %r (ties explain %.3g)" % (what, res_gpu[1], res_cpu[1], tie_shift)
     assert 0.0 < res_cpu[1] <= 1.0
 
 
-ARBITER_RATIO = 1.6     # the HIP path may sit at most this much further from a float64 evaluation than the reference's fp32 CPU path does (measured: 1.5)
+# The HIP path may sit at most this much further from a float64 evaluation than the reference's fp32 CPU path does.  Rounds 1-4 (one fp32 chain per
+# convolution output): measured 1.36-1.5, bound 1.6.  Round 5 (two-level sums, chunks of 64 terms): measured 0.84 (ResNet-50, 200 x 1000 pairs),
+# 0.73 (siamese descriptor), 1.01 (ResNet-152, 20 x 60 pairs; rms over many more pairs in scratch/chunk_study.py: 0.79).  The statistic is a MAX over
+# the pairs of one set, so the bound keeps a margin over the measured values.
+ARBITER_RATIO = 1.1
 
 
 def _arbiter(arch, w, n_labels, spec, r, kind="classif", feature_dim=0):
@@ -146,8 +172,8 @@ def _arbiter(arch, w, n_labels, spec, r, kind="classif", feature_dim=0):
 
 
 def test_classif_finetune_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
-    """BASELINE configs[1] end to end: ResNet-50 global descriptors, 200 queries x 1000 gallery images, with the float64 arbiter: the k-ordered
-    fp32 fma chains of the HIP trunk (K up to 4608) may not drift further from float64 than ARBITER_RATIO x the reference's own fp32 CPU path."""
+    """BASELINE configs[1] end to end: ResNet-50 global descriptors, 200 queries x 1000 gallery images, with the float64 arbiter: the HIP trunk
+    (two-level fp32 sums, chunks of 64 terms) may not sit further from float64 than ARBITER_RATIO x the reference's own fp32 CPU path."""
     from test import classif_finetune_test as T
     w = _calibrated_weights("classif", 50, str(tmp_path / "w.pth"))
     spec = "synthetic:CLICIDE_video_224sq:n=1000:q=200:labels=50:struct=70"
@@ -190,7 +216,7 @@ def test_siamese_descriptor_main_gpu_vs_cpu(monkeypatch, capsys, tmp_path):
     e_gpu, e_cpu = _arbiter("resnet50", w, 25, spec, r, "descriptor", 256)
     with capsys.disabled():
         print("siamese descriptor: max|cos - cos_f64|: HIP path %.3g, torch-CPU fp32 path %.3g (ratio %.2f)" % (e_gpu, e_cpu, e_gpu / e_cpu))
-        _check(*r, what="siamese_descriptor_test resnet50 100 x 500", cos_tol=max(COS_TOL, e_gpu + e_cpu))
+        _check(*r, what="siamese_descriptor_test resnet50 100 x 500", cos_tol=max(COS_TOL, 2 * e_cpu))
     assert e_gpu <= max(COS_TOL, ARBITER_RATIO * e_cpu), "HIP path is %.3g from the float64 result, the CPU fp32 path %.3g" % (e_gpu, e_cpu)
 
 
@@ -246,7 +272,7 @@ def test_classif_finetune_main_resnet152_gpu_vs_cpu(monkeypatch, capsys, tmp_pat
     P@1, ranked lists and mAP (1e-4) are held to the same asserts as ResNet-50.  Cosine scores: on this seeded random-init network
     (50 residual blocks amplify every rounding) the reference's OWN fp32 CPU path is ~1.3e-5 away from a float64 evaluation of the same
     weights, so no fp32 implementation can be held to 1e-5 against it; the assert is instead that the HIP path stays within ARBITER_RATIO x the
-    CPU path's own distance from the float64 result (measured: 1.9e-5 vs 1.3e-5; ResNet-50: 7.5e-7 vs 5.0e-7, under 1e-5 and held to the same
+    CPU path's own distance from the float64 result (measured, round 5: 1.32e-5 vs 1.30e-5; ResNet-50: 7.7e-7 vs 9.2e-7, under 1e-5 and held to the same
     ratio in test_classif_finetune_main_gpu_vs_cpu)."""
     from test import classif_finetune_test as T
     w = _calibrated_weights("classif", 10, str(tmp_path / "w.pth"), arch="resnet152")
@@ -255,7 +281,7 @@ def test_classif_finetune_main_resnet152_gpu_vs_cpu(monkeypatch, capsys, tmp_pat
     e_gpu, e_cpu = _arbiter("resnet152", w, 10, spec, r)
     with capsys.disabled():
         print("resnet152: max|cos - cos_f64|: HIP path %.3g, torch-CPU fp32 path %.3g (ratio %.2f)" % (e_gpu, e_cpu, e_gpu / e_cpu))
-        _check(*r, what="classif_finetune_test resnet152", cos_tol=max(COS_TOL, e_gpu + e_cpu))
+        _check(*r, what="classif_finetune_test resnet152", cos_tol=max(COS_TOL, 2 * e_cpu))
     assert e_gpu <= max(COS_TOL, ARBITER_RATIO * e_cpu), "HIP path is %.3g from the float64 result, the CPU fp32 path %.3g" % (e_gpu, e_cpu)
 
 
