@@ -293,7 +293,9 @@ def compact_line(full, detail_file=None):
                                               "descriptors_identical"))
     tr = full.get("training")
     if isinstance(tr, dict):
-        line["training"] = _pick(tr, ("error", "reference_config_triplets_per_s", "frozen_trunk_triplets_per_s", "reference_over_frozen", "reference_config"))
+        line["training"] = _pick(tr, ("error", "reference_config_triplets_per_s", "frozen_trunk_triplets_per_s", "reference_over_frozen", "reference_config", "statistic"))
+        if isinstance(tr.get("roofline"), dict):
+            line["training"]["roofline"] = _pick(tr["roofline"], ("bound", "achieved", "peak", "unit", "frac", "ms_per_step", "algorithmic_flop_per_step"))
     if "exchange_ms" in full:
         line["exchange_ms"] = full["exchange_ms"]
         line["exchange"] = _pick(full.get("exchange") or {}, ("query_allgather_ms", "result_allgather_merge_ms", "exposed_when_serialised_frac_of_step",
@@ -734,7 +736,7 @@ def main():
             import bench_train
             import io
             import contextlib
-            targs = _ap.Namespace(images=512, labels=64, epochs=2, backbone="resnet50", configs="reference,frozen", phases=False)
+            targs = _ap.Namespace(images=512, labels=64, epochs=5, backbone="resnet50", configs="reference,frozen", phases=False)
             res_t = {}
             from train import siamese_descriptor as _sd
             saved_p = dict(_sd.P.__dict__)
@@ -745,11 +747,16 @@ def main():
             finally:
                 _sd.P.__dict__.clear(); _sd.P.__dict__.update(saved_p)
             training_result = {"workload": "BASELINE configs[3] on one GPU: DescriptorNet(ResNet-50, 2048) triplet training with per-epoch hard-negative mining, "
-                                           "batch 64 = 8 micro-batches of 8, SGD 1e-3 / 0.9 / 5e-4, BN frozen, 512 synthetic images / 64 labels, 36 steps per epoch",
+                                           "batch 64 = 8 micro-batches of 8, SGD 1e-3 / 0.9 / 5e-4, BN frozen, 512 synthetic images / 64 labels, 36 steps per epoch, 5 epochs",
                                "reference_config_triplets_per_s": res_t["reference"]["triplets_per_s"],
                                "reference_config": "untrained_blocks = 15 (reference train/siamese_descriptor_p.py:14-17,48): layer4 + descriptor head trained",
                                "frozen_trunk_triplets_per_s": res_t["frozen"]["triplets_per_s"],
                                "reference_over_frozen": res_t["reference"]["triplets_per_s"] / res_t["frozen"]["triplets_per_s"],
+                               "statistic": res_t["reference"]["statistic"],
+                               "reference_config_triplets_per_s_min_max": res_t["reference"]["triplets_per_s_min_max"],
+                               "frozen_trunk_triplets_per_s_min_max": res_t["frozen"]["triplets_per_s_min_max"],
+                               "roofline": dict((k, res_t["reference"]["roofline"][k]) for k in ("bound", "achieved", "peak", "unit", "frac", "ms_per_step",
+                                                                                                  "algorithmic_flop_per_step", "phases_flop", "counts")),
                                "trainable_parameters": res_t["reference"]["trainable_parameters"],
                                "epoch_seconds": res_t["reference"]["epoch_seconds"], "exchange": res_t["reference"]["exchange"]}
         except Exception as e:

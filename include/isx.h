@@ -397,9 +397,25 @@ int isx_head_linear_splits(int64_t K);
 int isx_head_linear_fwd(const float* xT, int64_t M, int64_t Mp, int64_t K, const float* w, int N, const float* bias, float* y,
                         float* ws, size_t ws_bytes, isx_stream_t stream);
 
+/* The same with x as stored, (M, K) row-major (no transposed copy of the activation), any M; ws: isx_head_linear_rows_workspace(M, K, N)
+ * bytes.  Bit-identical to isx_head_linear_fwd.  Also the inference path of DescriptorNet / RegionDescriptorNet
+ * (model/siamese.py:117-122, 215-220): ONE implementation of the layer, a row's descriptor independent of the batch it rides in. */
+size_t isx_head_linear_rows_workspace(int64_t M, int64_t K, int N);
+int isx_head_linear_fwd_rows(const float* x, int64_t M, int64_t K, const float* w, int N, const float* bias, float* y, float* ws,
+                             size_t ws_bytes, isx_stream_t stream);
+
 /* The input gradient of the same Linear for all rows at once: dx[m][k] = sum_n dy[m][n] w[n][k], one k-ordered chain over n per
  * output whatever M.  dyT: (N, Mp) = dy TRANSPOSED, zero-padded to Mp (a multiple of 64); w: (N, K); dx: (Mp, K).  K % 64 == 0. */
 int isx_head_linear_dgrad(const float* dyT, int64_t Mp, int N, const float* w, int64_t K, float* dx, isx_stream_t stream);
+
+/* The weight gradient of the same Linear over the R rows of a whole mini-batch AND torch.optim.SGD's update of the weight, as ONE
+ * kernel (reference: the optimizer of train/siamese_descriptor.py:136-139 stepped from utils/train_general.py:53 on the 822 MB weight of
+ * model/siamese.py:104-114): g[n][k] = sum_r dy[r][n] x[r][k] (one fp32 fma chain over the rows in row order), then per element
+ *   g += weight_decay * w;  buf = first ? g : momentum * buf + (1 - dampening) * g;  w -= lr * (nesterov ? g + momentum * buf : buf)
+ * dy: (R, N), x: (R, K), w / mom: (N, K) updated in place (mom NULL when momentum == 0).  N % 128 == 0, K % 128 == 0.  No dW tensor:
+ * 4 passes over the weight's size per step instead of 7. */
+int isx_head_sgd_step(const float* dy, const float* x, int64_t R, int N, int64_t K, float* w, float* mom, int first, float lr,
+                      float momentum, float dampening, float weight_decay, int nesterov, isx_stream_t stream);
 
 /* out[l][c] = sum_{r < R} x[l * R + r][c]: column sums of `leaves` consecutive groups of R rows (per-micro-batch bias / Shift
  * gradients), rows added in order.  x: (leaves * R, C); out: (leaves, C). */

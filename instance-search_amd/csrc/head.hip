@@ -11,6 +11,10 @@
 //                           x arrives TRANSPOSED (K, Mp): K-major, tiles go to LDS as they lie; w as stored by nn.Linear (N, K): staged
 //                           through the transposing LDS store of the score GEMM.  grid = (Mp / 64) x (N / 64) x S blocks.
 //   isx_head_linear_dgrad   dx = dy . w: the TN GEMM of the weight gradients (wgrad_kernel.hpp) on (dy^T, w), both K-major as stored; no split.
+//   isx_head_sgd_step       the weight gradient dW = dY^T X over the rows of the whole mini-batch AND the SGD update of the 822 MB weight as ONE kernel:
+//                           the TN GEMM's epilogue reads the weight / momentum tile, applies weight decay, momentum and the step and writes both back.
+//                           No dW tensor (822 MB written, then re-read by the optimizer), no separate optimizer pass over W, dW and the momentum:
+//                           3.3 GB of HBM traffic per step instead of 5.8 GB.
 //   isx_colsum_leaves       per-micro-batch column sums (bias / Shift gradients kept apart per leaf): one thread per (leaf, column),
 //                           rows added in order.
 #include <stdlib.h>
@@ -30,15 +34,22 @@ static int head_splits(int64_t K) {
 
 // TM: 32-row MFMA tiles per wave along M (block tile 64 TM x 64).  TM = 2 / 3 cover Mp = 128 / 192 rows with ONE m-tile, so the weight is
 // read once instead of once per 64 rows; the tile shape only groups outputs, every output is the same chain in any of them.
-template <int TM, int TN = 1>
+// ROWS: x is given as stored, (M, K) row-major (xT = x, Mrows = M): its tiles take the transposing LDS store of the weight tiles; rows past M read
+// zeros through the buffer descriptor.  Otherwise xT is (K, Mp), K-major, and goes to the LDS as it lies.  Same chain per output either way.
+template <int TM, int TN = 1, bool ROWS = false>
 __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restrict__ xT, int Mp, const float* __restrict__ Wn, int N, int K, int kt_per,
-                                                            float* __restrict__ part, int tiles_n) {
-    constexpr int BK = kHeadBK, BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + lds_pad(BK);
-    constexpr int CA = BM / 4, NA = BK * CA / 256;
+                                                            float* __restrict__ part, int tiles_m, int Mrows = 0) {
+    constexpr int BK = kHeadBK, BM = 64 * TM, BN = 64 * TN, LDA = ROWS ? BM + lds_pad(BK) : BM + 4, LDB = BN + lds_pad(BK);
+    constexpr int CA = BM / 4, NA = ROWS ? BM * BK / 1024 : BK * CA / 256;
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
     float* Bs = lds + BK * LDA;
-    const int tile_m = (int)blockIdx.x / tiles_n, tile_n = (int)blockIdx.x % tiles_n, split = (int)blockIdx.y;
+    // row tiles fastest, and XCD x gets a contiguous range of tile ids (blocks b and b + 8 share an XCD): the row tiles that read the same slice of
+    // the weight run next to each other on ONE XCD and share it in that L2
+    const int nwg = (int)gridDim.x, bx = (int)blockIdx.x;
+    const int xcd = bx & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bx >> 3);
+    const int tile_m = wg % tiles_m, tile_n = wg / tiles_m, split = (int)blockIdx.y;
     const int m0 = tile_m * BM;
     const int64_t n0 = (int64_t)tile_n * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -55,18 +66,26 @@ __global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restr
     float4 ra[NA], rb[BN * BK / 1024];
     auto load = [&](int kt) {
         const int64_t k0 = (int64_t)kt * BK;
+        if constexpr (ROWS) {
+            load_tile<true, BM, BK>(xT, Mrows, K, m0, (int)k0, ra);
+        } else {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int idx = j * 256 + threadIdx.x;
-            ra[j] = *reinterpret_cast<const float4*>(xT + (k0 + idx / CA) * Mp + m0 + ((idx % CA) << 2));
+            for (int j = 0; j < NA; ++j) {
+                const int idx = j * 256 + threadIdx.x;
+                ra[j] = *reinterpret_cast<const float4*>(xT + (k0 + idx / CA) * Mp + m0 + ((idx % CA) << 2));
+            }
         }
         load_tile<true, BN, BK>(Wn, N, K, n0, (int)k0, rb);
     };
     auto store = [&]() {
+        if constexpr (ROWS) {
+            store_tile<BM, BK>(As, ra);
+        } else {
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int idx = j * 256 + threadIdx.x;
-            *reinterpret_cast<float4*>(As + (idx / CA) * LDA + ((idx % CA) << 2)) = ra[j];
+            for (int j = 0; j < NA; ++j) {
+                const int idx = j * 256 + threadIdx.x;
+                *reinterpret_cast<float4*>(As + (idx / CA) * LDA + ((idx % CA) << 2)) = ra[j];
+            }
         }
         store_tile<BN, BK>(Bs, rb);
     };
@@ -115,6 +134,110 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
     y[i] = bias ? v + bias[i % N] : v;
 }
 
+// ---- weight gradient + SGD update of the head's Linear in one kernel ---------------------------------------------------------------------
+// g[n][k] = sum_r dy[r][n] * x[r][k]  (ONE fp32 fma chain over the rows in row order: the bits of isx_conv_wgrad_nhwc on the same rows, and the
+// same at any number of ranks -- every rank holds all rows of the mini-batch), then torch.optim.SGD's update of element (n, k)
+// (torch/optim/sgd.py _single_tensor_sgd; reference: optim.SGD in train/siamese_descriptor.py:136-139 stepped from utils/train_general.py:53):
+//   g += weight_decay * w;   buf = first ? g : momentum * buf + (1 - dampening) * g;   w -= lr * (nesterov ? g + momentum * buf : buf)
+// Tile 128 x 128 of the (N, K) weight per workgroup, R reduced in k-tiles of 32 rows (a tail of rows is zero-filled: fma(0, 0, acc) = acc).
+struct SgdParams { float lr, momentum, dampening, weight_decay; int nesterov, first, use_momentum; };
+
+__global__ __launch_bounds__(256) void head_sgd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t R, int N, int64_t K,
+                                                       float* __restrict__ w, float* __restrict__ mom, SgdParams sp, int tiles_k) {
+    constexpr int TM = 2, TN = 2, BK = 32, BM = 128, BN = 128, LDA = BM + 4, LDB = BN + 4;
+    constexpr int CA = BM / 4, CB = BN / 4, NA = BK * CA / 256, NB = BK * CB / 256;
+    __shared__ float lds[BK * (LDA + LDB)];
+    float* As = lds;
+    float* Bs = lds + BK * LDA;
+    const int tile_n = (int)(blockIdx.x / tiles_k);
+    const int64_t n0 = (int64_t)tile_n * BM, k0 = (int64_t)(blockIdx.x % tiles_k) * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
+
+    const auto rw = conv_tile_rsrc(w, n0, N, K, BM);
+    const auto rmom = conv_tile_rsrc(mom ? mom : w, n0, N, K, BM);
+    f32x16 acc[TM][TN];
+    zero_tiles(acc);
+
+    float4 ra[NA], rb[NB];
+    auto load = [&](int64_t r0) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            const int64_t r = r0 + idx / CA;
+            ra[j] = r < R ? *reinterpret_cast<const float4*>(dy + r * N + n0 + ((idx % CA) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            const int64_t r = r0 + idx / CB;
+            rb[j] = r < R ? *reinterpret_cast<const float4*>(x + r * K + k0 + ((idx % CB) << 2)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            *reinterpret_cast<float4*>(As + (idx / CA) * LDA + ((idx % CA) << 2)) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int idx = j * 256 + threadIdx.x;
+            *reinterpret_cast<float4*>(Bs + (idx / CB) * LDB + ((idx % CB) << 2)) = rb[j];
+        }
+    };
+    const int64_t nk = (R + BK - 1) / BK;
+    if (nk > 0) {
+        load(0);
+        store();
+        __syncthreads();
+        const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
+        const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+        for (int64_t kt = 0; kt < nk; ++kt) {
+            const bool more = kt + 1 < nk;
+            if (more) load((kt + 1) * BK);
+            mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+            __syncthreads();
+            if (more) {
+                store();
+                __syncthreads();
+            }
+        }
+    }
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); one 32-bit lane offset per MFMA tile
+    // into the tile's rows of w / mom (buffer instructions: rows past N and columns past K fall outside the descriptor)
+    const float one_minus_damp = 1.0f - sp.dampening;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int64_t col = k0 + wn_u * (32 * TN) + j * 32 + l31;
+            const unsigned lo = conv_lane_off(col, K, wm_u * (32 * TM) + i * 32 + 4 * half, K);
+            float wv[16], mv[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0));
+            if (sp.use_momentum && !sp.first) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmom, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float g = acc[i][j][e];
+                if (sp.weight_decay != 0.0f) g = g + sp.weight_decay * wv[e];
+                float upd = g;
+                if (sp.use_momentum) {
+                    const float buf = sp.first ? g : sp.momentum * mv[e] + one_minus_damp * g;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, buf), rmom, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0);
+                    upd = sp.nesterov ? g + sp.momentum * buf : buf;
+                }
+                const float nw = wv[e] - sp.lr * upd;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nw), rw, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0);
+            }
+        }
+    }
+}
+
 // out[l][c] = sum over the R rows of leaf l of x[l * R + r][c], rows in order
 __global__ __launch_bounds__(256) void colsum_leaves_kernel(const float* __restrict__ x, int R, int64_t C, float* __restrict__ out) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -149,17 +272,57 @@ ISX_API int isx_head_linear_fwd(const float* xT, int64_t M, int64_t Mp, int64_t 
     hipStream_t st = (hipStream_t)stream;
     static const bool wide = [] { const char* e = getenv("ISX_HEAD_WIDE"); return !(e && e[0] == '0'); }();      // A/B: 192 x 128 tiles (default) vs 192 x 64
     if (Mp == 192 && N % 128 == 0 && wide)
-        hipLaunchKernelGGL((head_fwd_gemm_kernel<3, 2>), dim3((unsigned)(N / 128), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 128);
+        hipLaunchKernelGGL((head_fwd_gemm_kernel<3, 2>), dim3((unsigned)(N / 128), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, 1);
     else if (Mp == 192)
-        hipLaunchKernelGGL(head_fwd_gemm_kernel<3>, dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
+        hipLaunchKernelGGL(head_fwd_gemm_kernel<3>, dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, 1);
     else if (Mp == 128)
-        hipLaunchKernelGGL(head_fwd_gemm_kernel<2>, dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
+        hipLaunchKernelGGL(head_fwd_gemm_kernel<2>, dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, 1);
     else
-        hipLaunchKernelGGL(head_fwd_gemm_kernel<1>, dim3((unsigned)((Mp / 64) * (N / 64)), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, N / 64);
+        hipLaunchKernelGGL(head_fwd_gemm_kernel<1>, dim3((unsigned)((Mp / 64) * (N / 64)), (unsigned)S), dim3(256), 0, st, xT, (int)Mp, w, N, (int)K, kt_per, ws, (int)(Mp / 64));
     ISX_CHECK_LAUNCH("isx_head_linear_fwd(gemm)");
     const int64_t total = M * N;
     hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, S, Mp * (int64_t)N, total, N, bias, y);
     ISX_CHECK_LAUNCH("isx_head_linear_fwd(reduce)");
+    return ISX_OK;
+}
+
+// The same with x as stored, (M, K) row-major: no transposed copy of the activation (77 MB per training step).  Tiles: up to 64 rows 64 x 64,
+// up to 128 rows 128 x 64, above that 192 x 128 (192 x 64 when N is not a multiple of 128) over ceil(M / 192) row tiles -- the weight crosses HBM
+// once per 192 rows (a 1024-row inference batch: 6 times, 4.9 GB for 421 GFLOP).  The tile shape only groups outputs: every output is the same S
+// chains added in split order, so a row's result does not depend on M.  Bit-identical to isx_head_linear_fwd on the transposed rows.
+static int64_t head_rows_padded(int64_t M) { return M <= 64 ? 64 : M <= 128 ? 128 : (M + 191) / 192 * 192; }
+
+ISX_API size_t isx_head_linear_rows_workspace(int64_t M, int64_t K, int N) {
+    if (M <= 0 || K <= 0 || N <= 0) return 0;
+    return (size_t)head_splits(K) * (size_t)head_rows_padded(M) * (size_t)N * 4;
+}
+
+ISX_API int isx_head_linear_fwd_rows(const float* x, int64_t M, int64_t K, const float* w, int N, const float* bias, float* y, float* ws, size_t ws_bytes,
+                                     isx_stream_t stream) {
+    ISX_REQUIRE(M >= 0 && M < (1 << 24) && K > 0 && K % 32 == 0 && K < (1ll << 31) && N > 0 && N % 64 == 0 && (int64_t)192 * K * 4 < (1ll << 32),
+                "isx_head_linear_fwd_rows: bad shape M=%lld K=%lld N=%d (K %% 32 == 0, N %% 64 == 0)", (long long)M, (long long)K, N);
+    if (M == 0) return ISX_OK;
+    ISX_REQUIRE(x && w && y && ws, "isx_head_linear_fwd_rows: null pointer");
+    ISX_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)ws) % 16) == 0, "isx_head_linear_fwd_rows: x, w and ws must be 16-B aligned");
+    const int S = head_splits(K);
+    const int64_t Mp = head_rows_padded(M);
+    ISX_REQUIRE(ws_bytes >= (size_t)S * (size_t)Mp * (size_t)N * 4, "isx_head_linear_fwd_rows: workspace of %zu bytes, need %zu", ws_bytes, (size_t)S * (size_t)Mp * (size_t)N * 4);
+    const int nk = (int)(K / kHeadBK), kt_per = (nk + S - 1) / S;
+    hipStream_t st = (hipStream_t)stream;
+    if (Mp == 64)
+        hipLaunchKernelGGL((head_fwd_gemm_kernel<1, 1, true>), dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, x, (int)Mp, w, N, (int)K, kt_per, ws, 1, (int)M);
+    else if (Mp == 128)
+        hipLaunchKernelGGL((head_fwd_gemm_kernel<2, 1, true>), dim3((unsigned)(N / 64), (unsigned)S), dim3(256), 0, st, x, (int)Mp, w, N, (int)K, kt_per, ws, 1, (int)M);
+    else if (N % 128 == 0)
+        hipLaunchKernelGGL((head_fwd_gemm_kernel<3, 2, true>), dim3((unsigned)((Mp / 192) * (N / 128)), (unsigned)S), dim3(256), 0, st, x, (int)Mp, w, N, (int)K, kt_per, ws,
+                           (int)(Mp / 192), (int)M);
+    else
+        hipLaunchKernelGGL((head_fwd_gemm_kernel<3, 1, true>), dim3((unsigned)((Mp / 192) * (N / 64)), (unsigned)S), dim3(256), 0, st, x, (int)Mp, w, N, (int)K, kt_per, ws,
+                           (int)(Mp / 192), (int)M);
+    ISX_CHECK_LAUNCH("isx_head_linear_fwd_rows(gemm)");
+    const int64_t total = M * N;
+    hipLaunchKernelGGL(head_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ws, S, Mp * (int64_t)N, total, N, bias, y);
+    ISX_CHECK_LAUNCH("isx_head_linear_fwd_rows(reduce)");
     return ISX_OK;
 }
 
@@ -186,6 +349,27 @@ ISX_API int isx_head_linear_dgrad(const float* dyT, int64_t Mp, int N, const flo
         hipLaunchKernelGGL((wgrad_gemm_kernel<1, 1>), dim3((unsigned)((Mp / 64) * (K / 64)), 1, 1), dim3(256), 0, st, dyT, (int64_t)N, (int)Mp, w, (int)K, g, 1, dx, K,
                            (int)(K / 64), nk, 1, (float*)nullptr);
     ISX_CHECK_LAUNCH("isx_head_linear_dgrad");
+    return ISX_OK;
+}
+
+// Weight gradient of y = x . w^T over R rows and torch.optim.SGD's update of w, fused (see head_sgd_kernel): dy: (R, N), x: (R, K), w: (N, K) updated
+// in place, mom: (N, K) momentum buffer updated in place (NULL when momentum == 0); first != 0: the buffer is (re)initialised with the gradient, as
+// torch does on the first step.  N % 128 == 0, K % 128 == 0, 16-B aligned pointers.  (Reference: the optimizer step of utils/train_general.py:53
+// on the Linear of model/siamese.py:104-114.)
+ISX_API int isx_head_sgd_step(const float* dy, const float* x, int64_t R, int N, int64_t K, float* w, float* mom, int first, float lr, float momentum,
+                              float dampening, float weight_decay, int nesterov, isx_stream_t stream) {
+    ISX_REQUIRE(R >= 0 && N > 0 && N % 128 == 0 && K > 0 && K % 128 == 0 && (int64_t)128 * K * 4 < (1ll << 31),
+                "isx_head_sgd_step: bad shape R=%lld N=%d K=%lld (N %% 128 == 0, K %% 128 == 0, 128 rows of w below 2 GiB)", (long long)R, N, (long long)K);
+    ISX_REQUIRE(w && (R == 0 || (dy && x)) && (momentum == 0.0f || mom), "isx_head_sgd_step: null pointer");
+    ISX_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)w | (uintptr_t)mom) % 16) == 0, "isx_head_sgd_step: pointers must be 16-B aligned");
+    ISX_REQUIRE(!(nesterov && (momentum <= 0.0f || dampening != 0.0f)), "isx_head_sgd_step: Nesterov momentum requires a momentum and zero dampening");
+    const int64_t tiles = (int64_t)(N / 128) * (K / 128);
+    ISX_REQUIRE(tiles < (1ll << 31), "isx_head_sgd_step: too many tiles");
+    SgdParams sp;
+    sp.lr = lr; sp.momentum = momentum; sp.dampening = dampening; sp.weight_decay = weight_decay;
+    sp.nesterov = nesterov ? 1 : 0; sp.first = first ? 1 : 0; sp.use_momentum = momentum != 0.0f ? 1 : 0;
+    hipLaunchKernelGGL(head_sgd_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, dy, x, R, N, K, w, mom, sp, (int)(K / 128));
+    ISX_CHECK_LAUNCH("isx_head_sgd_step");
     return ISX_OK;
 }
 

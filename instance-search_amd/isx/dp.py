@@ -240,10 +240,13 @@ class RowSink(object):
     """Collects the (x, dy) rows `RowDeferredLinear` produces during the backward passes of ONE optimizer step, in the order they are
     produced (micro-batch order), and turns them into the weight gradients at the end of the step."""
 
-    def __init__(self, weights, group=None):
+    def __init__(self, weights, group=None, optimizer=None):
+        """optimizer: the step's torch.optim.SGD, or None.  With it, a deferred weight that libisx can handle is UPDATED by the kernel that forms
+        its gradient (isx_head_sgd_step: no gradient tensor, `weight.grad` stays None and the optimizer's own step skips the weight)."""
         self.weights = list(weights)
         self.ids = dict((id(w), k) for k, w in enumerate(self.weights))
         self.group = group
+        self.optimizer = optimizer
         self.x = [[] for _ in self.weights]
         self.dy = [[] for _ in self.weights]
 
@@ -298,12 +301,46 @@ class RowSink(object):
                 else:
                     x, dy = w.new_zeros((0, w.size(1))), w.new_zeros((0, w.size(0)))
                 x, dy = self._gather_rows(x, self.group), self._gather_rows(dy, self.group)
+                self.x[k], self.dy[k] = [], []
+                if self.optimizer is not None and fused_sgd_from_rows(self.optimizer, w, dy, x):
+                    continue
                 g = weight_gradient_from_rows(dy, x)
                 if w.grad is not None and w.grad.shape == g.shape and w.grad.dtype == g.dtype:
                     w.grad.copy_(g)
                 else:
                     w.grad = g
-                self.x[k], self.dy[k] = [], []
+
+
+def fused_sgd_from_rows(optimizer, w, dy, x):
+    """Weight gradient dy^T x over the rows of the mini-batch + torch.optim.SGD's update of `w` in ONE libisx kernel (isx_head_sgd_step): the
+    gradient is never written.  The momentum buffer is the optimizer's own state entry (created on the first step, as torch does), so a
+    state_dict / a re-created optimizer (annealing) behaves as with torch's step.  Returns False -- nothing done -- when the case is not the
+    kernel's (CPU tensors, widths that are not multiples of 128, an optimizer that is not a plain SGD, maximize / differentiable)."""
+    if not (type(optimizer) is torch.optim.SGD and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
+            and w.size(0) % 128 == 0 and w.size(1) % 128 == 0 and 128 * w.size(1) * 4 < 2 ** 31 and x.dtype == torch.float32 and dy.dtype == torch.float32):
+        return False
+    group = next((g for g in optimizer.param_groups if any(p is w for p in g['params'])), None)
+    if group is None or group.get('maximize') or group.get('differentiable'):
+        return False
+    from ._lib import check, lib
+    mom, first, buf = float(group['momentum']), 0, None
+    if mom != 0.0:
+        state = optimizer.state[w]
+        buf = state.get('momentum_buffer')
+        if buf is None:
+            buf = state['momentum_buffer'] = torch.empty_like(w)       # written in full by the first step (buf = g)
+            first = 1
+    x, dy = x.contiguous(), dy.contiguous()
+    lr = group['lr']
+    check(lib().isx_head_sgd_step(dy.data_ptr(), x.data_ptr(), x.size(0), w.size(0), w.size(1), w.data_ptr(), buf.data_ptr() if buf is not None else None, first,
+                                  float(lr), mom, float(group['dampening']), float(group['weight_decay']), 1 if group['nesterov'] else 0,
+                                  torch.cuda.current_stream().cuda_stream), "isx_head_sgd_step")
+    w.grad = None                    # the optimizer's step skips a parameter without a gradient
+    try:                             # the kernel wrote w behind autograd's back: move its version counter as an in-place op would (caches keyed on it)
+        torch._C._autograd._unsafe_set_version_counter([w], [w._version + 1])
+    except (AttributeError, TypeError):
+        pass
+    return True
 
 
 def weight_gradient_from_rows(dy, x):

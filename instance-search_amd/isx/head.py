@@ -49,25 +49,12 @@ class HeadEngine(object):
         """f_all: (M, C, h, w) trunk output of all local rows (no graph).  Returns (descriptors (M, D), context for backward)."""
         M = f_all.size(0)
         lin = self.lin
-        K, N = lin.in_features, lin.out_features
         x0 = f_all.reshape(M, -1)                                   # logical (C, h, w) order whatever the memory format
         if not x0.is_contiguous():
             x0 = x0.contiguous()
         x1 = ops.l2norm_shift_rows(x0, self.shift.param.detach())
-        Mp = (M + 63) // 64 * 64
-        if Mp == M:
-            xT = x1.t().contiguous()
-        else:
-            xT = x1.new_zeros((K, Mp))
-            xT[:, :M] = x1.t()
-        S = lib().isx_head_linear_splits(K)
-        need = S * Mp * N
-        if self._ws is None or self._ws.numel() < need or self._ws.device != x1.device:
-            self._ws = torch.empty(need, dtype=torch.float32, device=x1.device)
-        y = torch.empty((M, N), dtype=torch.float32, device=x1.device)
         b = lin.bias
-        check(lib().isx_head_linear_fwd(xT.data_ptr(), M, Mp, K, lin.weight.data_ptr(), N, b.data_ptr() if b is not None else None, y.data_ptr(),
-                                        self._ws.data_ptr(), self._ws.numel() * 4, _stream()), "isx_head_linear_fwd")
+        y = ops.head_linear(x1, lin.weight.detach(), b.detach() if b is not None else None)      # rows as stored: no transposed copy
         d = ops.l2norm_rows(y)
         return d, (x0, x1, y, tuple(f_all.shape))
 

@@ -71,6 +71,35 @@ def l2norm_shift_rows(x, shift=None, eps=EPS):
     return y
 
 
+_HEAD_WS = {}
+
+
+def head_linear_applicable(rows, weight):
+    return (rows.is_cuda and rows.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous() and rows.dim() == 2
+            and weight.dim() == 2 and weight.size(1) % 32 == 0 and weight.size(0) % 64 == 0 and 192 * weight.size(1) * 4 < 2 ** 32 and rows.size(0) < 2 ** 24)
+
+
+def head_linear(rows, weight, bias=None):
+    """y = rows . weight^T + bias on libisx's split-K GEMM (isx_head_linear_fwd_rows): a row's result does not depend on how many rows ride along,
+    and it is the same kernel the training step runs -- one implementation of DescriptorNet's Linear (reference model/siamese.py:104-122).
+    rows: (M, K) fp32, weight: (N, K) as nn.Linear stores it, K % 32 == 0, N % 64 == 0."""
+    rows = _f32(rows, "rows")
+    weight = _on_current_device(weight, "weight")
+    M, K = rows.shape
+    N = weight.size(0)
+    y = torch.empty((M, N), dtype=torch.float32, device=rows.device)
+    if M == 0:
+        return y
+    need = lib().isx_head_linear_rows_workspace(M, K, N) // 4
+    key = rows.device.index
+    ws = _HEAD_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _HEAD_WS[key] = torch.empty(need, dtype=torch.float32, device=rows.device)
+    check(lib().isx_head_linear_fwd_rows(rows.data_ptr(), M, K, weight.data_ptr(), N, bias.data_ptr() if bias is not None else None, y.data_ptr(), ws.data_ptr(),
+                                         ws.numel() * 4, _stream()), "isx_head_linear_fwd_rows")
+    return y
+
+
 def gap_l2(fmap, eps=EPS, out=None):
     """Global average pool + L2 of a logical (B,C,H,W) feature map.  A channels-last tensor (the
     layout NHWC convolutions produce) is consumed in place by the NHWC kernel -- no transpose."""

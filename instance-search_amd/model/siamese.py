@@ -269,8 +269,20 @@ def _apply_head(head, rows):
     if _fast(rows, head):
         from isx import ops
         lin = head[2]
-        return F.linear(ops.l2norm_shift_rows(rows.float(), head[1].param.detach()), lin.weight, lin.bias)
+        return _linear_rows(ops.l2norm_shift_rows(rows.float(), head[1].param.detach()), lin.weight, lin.bias)
     return head(rows)
+
+
+def _linear_rows(rows, weight, bias):
+    """The descriptor head's Linear on GPU rows outside autograd: libisx's split-K GEMM (isx_head_linear_fwd_rows) -- the kernel the training step
+    runs, so the per-epoch mining pass, the evaluation and the training forward of the same weights produce the same bits, and a descriptor does
+    not depend on the batch it was computed in.  Shapes the kernel does not cover (K % 32, N % 64) keep torch's GEMM."""
+    from isx import ops
+    if not rows.is_contiguous():
+        rows = rows.contiguous()
+    if ops.head_linear_applicable(rows, weight):
+        return ops.head_linear(rows, weight.detach(), bias.detach() if bias is not None else None)
+    return F.linear(rows, weight, bias)
 
 
 class DescriptorNet(nn.Module):
@@ -405,7 +417,7 @@ class RegionDescriptorNet(nn.Module):
             flat_idx, _ = ops.region_topk(c[0].float(), k)
             rows = ops.region_gather_l2(x[0].float(), kh, kw, flat_idx, c.size(3), self.feature_reduc1[1].param.detach())
             lin = self.feature_reduc1[2]
-            acc = F.linear(rows, lin.weight, lin.bias).sum(0, keepdim=True)
+            acc = _linear_rows(rows, lin.weight, lin.bias).sum(0, keepdim=True)
         else:
             c_maxv = c.max(1)[0].view(-1)
             # canonical tie-break (score desc, index asc): a stable descending sort
@@ -434,10 +446,10 @@ class RegionDescriptorNet(nn.Module):
             # Linear weight with their columns permuted once to that order -- the same dot products, summed in another order
             shift_hwc, w_hwc = self._hwc_head(x.size(1), kh, kw)
             rows = ops.region_gather_l2_nhwc(x, kh, kw, flat_idx, c.size(3), shift_hwc)
-            acc = F.linear(rows.view(B * k, -1), w_hwc, lin.bias).view(B, k, -1).sum(1)
+            acc = _linear_rows(rows.view(B * k, -1), w_hwc, lin.bias).view(B, k, -1).sum(1)
         else:
             rows = ops.region_gather_l2(x.float(), kh, kw, flat_idx, c.size(3), self.feature_reduc1[1].param.detach())
-            acc = F.linear(rows.view(B * k, -1), lin.weight, lin.bias).view(B, k, -1).sum(1)
+            acc = _linear_rows(rows.view(B * k, -1), lin.weight, lin.bias).view(B, k, -1).sum(1)
         cls_out = c.new_zeros(B, c.size(1), self.k)
         cls_out[:, :, :k] = c.flatten(2).gather(2, flat_idx[:, None, :].expand(B, c.size(1), k))
         return self.feature_reduc2(acc), cls_out

@@ -235,7 +235,8 @@ class _Stepper(object):
             pre = self._precompute(local, len(mine), batch_args) if mine else None
         self.flat.zero_grad()
         losses = []
-        with dp.RowSink(self.deferred) as sink:
+        fuse = optimizer if getattr(P, 'train_fused_head_sgd', True) else None       # head weight: gradient + SGD update as one kernel (isx/dp.py)
+        with dp.RowSink(self.deferred, optimizer=fuse) as sink:
             eng = head = None
             batched = getattr(self.P, 'train_suffix_batched', True)
             if self.mode == 'tree' and pre is not None and len(set(len(l) for l in mine)) == 1 and batched:

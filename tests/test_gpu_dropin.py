@@ -170,6 +170,31 @@ def test_get_embeddings_is_independent_of_the_batch_size(monkeypatch):
         assert torch.equal(v, first), k
 
 
+def test_descriptor_net_is_independent_of_the_batch_size_and_matches_the_training_forward():
+    """ONE implementation of the descriptor head (reference model/siamese.py:104-122): inference (the per-epoch mining pass, the evaluation) runs
+    the Linear(100352 -> D) on isx_head_linear_fwd_rows, the kernel of the training step -- a descriptor is bit-identical whether its image rides
+    in a batch of 3, 16 or 64 (three row-tile shapes of the kernel), and identical to what the training forward (isx/head.HeadEngine, all
+    micro-batches in one pass) computes from the same weights."""
+    from isx import backbones
+    from isx.head import HeadEngine
+    from model.siamese import DescriptorNet, TuneClassif
+    from utils.dataset import synthetic_images
+    torch.manual_seed(0)
+    net = DescriptorNet(TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5), 256, (7, 7)).cuda().eval()
+    net.feature_reduc1[1].param.data.normal_(0, 0.002)
+    imgs = torch.stack(list(synthetic_images(70, seed=3))).cuda()
+    with torch.no_grad():
+        ref = torch.cat([net(imgs[i:i + 64]) for i in range(0, 70, 64)], 0)
+        for bs in (3, 16, 35):
+            got = torch.cat([net(imgs[i:i + bs]) for i in range(0, 70, bs)], 0)
+            assert torch.equal(got, ref), bs
+        assert float((ref.norm(dim=1) - 1).abs().max()) < 1e-5
+        # the training step's head pass on the same trunk output: the same bits
+        f = net._trunk.inference(net.features, imgs[:48])
+        d, _ = HeadEngine(net).forward(f)
+        assert torch.equal(d, ref[:48])
+
+
 def test_bench_size_step_is_batch_independent():
     """BASELINE configs[1] at its full size (1024 images of 224 x 224 per launch) through the SAME trunk the bench times: at this size every
     convolution runs in 128x128 tiles with 64x64 tails, the stage-1 blocks in the fused kernels, the stem in four rounds of workgroups --

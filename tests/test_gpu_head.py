@@ -139,3 +139,49 @@ def test_weight_gradient_from_rows_on_the_tn_kernel():
         pad = dp.weight_gradient_from_rows(torch.cat([dy, torch.zeros(5, n_out, device="cuda")]), torch.cat([x, torch.zeros(5, n_in, device="cuda")]))
         assert torch.equal(pad, got)
         assert _rel(got, dy.t().mm(x)) <= 1e-5
+
+
+@pytest.mark.parametrize("nesterov", [False, True])
+def test_fused_weight_gradient_and_sgd_step(nesterov):
+    """isx_head_sgd_step through isx/dp.fused_sgd_from_rows: the weight gradient is bit for bit the TN kernel's (one chain over the rows), and three
+    optimizer steps -- the first creates the momentum buffer -- track torch.optim.SGD stepping on that gradient tensor (the arithmetic differs only by
+    fma contraction inside torch's kernel: 1e-6 of the weight scale); the optimizer's own step() then leaves the weight alone (no .grad)."""
+    from isx import dp
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for R, n_out, n_in in ((192, 256, 1280), (77, 128, 100352)):
+        w0 = torch.randn(n_out, n_in, device="cuda", generator=g) * 0.01
+        w_f = torch.nn.Parameter(w0.clone())
+        w_t = torch.nn.Parameter(w0.clone())
+        kw = dict(lr=1e-2, momentum=0.9, weight_decay=5e-4, nesterov=nesterov)
+        opt_f, opt_t = torch.optim.SGD([w_f], **kw), torch.optim.SGD([w_t], **kw)
+        for step in range(3):
+            x = torch.randn(R, n_in, device="cuda", generator=g)
+            dy = torch.randn(R, n_out, device="cuda", generator=g)
+            assert dp.fused_sgd_from_rows(opt_f, w_f, dy, x)
+            assert w_f.grad is None
+            opt_f.step()                                              # must not touch w_f
+            w_t.grad = dp.weight_gradient_from_rows(dy, x)
+            opt_t.step()
+            scale = float(w_t.abs().max())
+            assert float((w_f - w_t).abs().max()) <= 1e-6 * scale, (step, float((w_f - w_t).abs().max()), scale)
+            bf, bt = opt_f.state[w_f]["momentum_buffer"], opt_t.state[w_t]["momentum_buffer"]
+            assert float((bf - bt).abs().max()) <= 1e-6 * float(bt.abs().max())
+        # the update is a function of the rows only: a second weight stepped with the same rows lands on the same bits
+        w_g = torch.nn.Parameter(w0.clone())
+        opt_g = torch.optim.SGD([w_g], **kw)
+        g2 = torch.Generator(device="cuda").manual_seed(5)
+        xs = [(torch.randn(R, n_in, device="cuda", generator=g2), torch.randn(R, n_out, device="cuda", generator=g2)) for _ in range(2)]
+        w_h = torch.nn.Parameter(w0.clone())
+        opt_h = torch.optim.SGD([w_h], **kw)
+        for x, dy in xs:
+            dp.fused_sgd_from_rows(opt_g, w_g, dy, x)
+            dp.fused_sgd_from_rows(opt_h, w_h, torch.cat([dy, torch.zeros(3, n_out, device="cuda")]), torch.cat([x, torch.zeros(3, n_in, device="cuda")]))
+        assert torch.equal(w_g, w_h)                                   # zero rows appended: the same chain, the same bits
+
+
+def test_fused_sgd_declines_what_the_kernel_does_not_cover():
+    from isx import dp
+    w = torch.nn.Parameter(torch.zeros(100, 64, device="cuda"))         # widths that are not multiples of 128
+    assert not dp.fused_sgd_from_rows(torch.optim.SGD([w], lr=0.1), w, torch.zeros(4, 100, device="cuda"), torch.zeros(4, 64, device="cuda"))
+    w2 = torch.nn.Parameter(torch.zeros(128, 128, device="cuda"))
+    assert not dp.fused_sgd_from_rows(torch.optim.Adam([w2], lr=0.1), w2, torch.zeros(4, 128, device="cuda"), torch.zeros(4, 128, device="cuda"))

@@ -24,6 +24,34 @@ sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
 import torch  # noqa: E402
 
 
+def step_flop(net, triplets):
+    """Algorithmic FLOP of one optimizer step: 2 x MACs of every convolution of the trunk at 224 x 224 (x 1 frozen, x 3 trained: forward, input
+    gradient, weight gradient) and of the head's Linear (x 3), for 3 images per triplet.  Shapes from a meta-device pass over a copy of the trunk."""
+    import copy
+    import torch.nn as nn
+    feats = copy.deepcopy(net.features).to("meta")
+    macs = {"frozen": 0.0, "trained": 0.0}
+
+    def hook(m, inp, out):
+        k = out.shape[2] * out.shape[3] * m.out_channels * (m.in_channels // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+        macs["trained" if m.weight.requires_grad else "frozen"] += k
+
+    hs = [m.register_forward_hook(hook) for m in feats.modules() if isinstance(m, nn.Conv2d)]
+    for (n, p), (_, q) in zip(net.features.named_parameters(), feats.named_parameters()):
+        q.requires_grad_(p.requires_grad)
+    with torch.no_grad():
+        feats(torch.empty(1, 3, 224, 224, device="meta"))
+    for h in hs:
+        h.remove()
+    images = 3 * triplets
+    lin = [m for m in net.modules() if isinstance(m, nn.Linear)]
+    head = sum(m.in_features * m.out_features * (3 if m.weight.requires_grad else 1) for m in lin)
+    out = {"frozen_trunk_forward": 2.0 * macs["frozen"] * images, "trained_trunk_fwd_dgrad_wgrad": 6.0 * macs["trained"] * images,
+           "head_linear_fwd_dgrad_wgrad": 2.0 * head * images}
+    out["total"] = sum(out.values())
+    return out
+
+
 def run_config(name, args, world, rank, local):
     from train import siamese_descriptor as sd
     from utils.dataset import get_pos_couples, synthetic_image_set
@@ -38,15 +66,25 @@ def run_config(name, args, world, rank, local):
     te = synthetic_image_set(64, args.labels, seed=2)
     n_couples = sum(len(v) for v in get_pos_couples(tr).values())
     n_steps = n_couples // P.train_batch_size
-    marks = []
-    real = sd.mine_epoch_negatives
+    # marks: A[e] = an epoch begins (its embedding pass starts), B[e] = its negatives are mined (the optimizer steps start).  Epoch e costs
+    # A[e + 1] - A[e] (embedding pass + similarity matrix + mining + steps), its steps alone A[e + 1] - B[e]; the first epoch (warm-up: workspaces,
+    # momentum buffers, code objects) is dropped and the MEDIAN over the others reported with min / max -- the last epoch has no A[e + 1] and is
+    # not counted either (args.epochs >= 3).
+    A, B = [], []
+    real_mine, real_sim = sd.mine_epoch_negatives, sd.get_similarities
 
-    def spy(*a, **k):                       # called once per epoch, before the training batches
+    def spy_sim(*a, **k):
         torch.cuda.synchronize()
-        marks.append(time.perf_counter())
-        return real(*a, **k)
+        A.append(time.perf_counter())
+        return real_sim(*a, **k)
 
-    sd.mine_epoch_negatives = spy
+    def spy_mine(*a, **k):
+        r = real_mine(*a, **k)
+        torch.cuda.synchronize()
+        B.append(time.perf_counter())
+        return r
+
+    sd.mine_epoch_negatives, sd.get_similarities = spy_mine, spy_sim
     dp.STATS.clear()
     import utils.train_general as tg
     tg.PHASES = {} if args.phases else None
@@ -54,18 +92,29 @@ def run_config(name, args, world, rank, local):
     try:
         net, _ = sd.main(tr, tr, te)
     finally:
-        sd.mine_epoch_negatives = real
+        sd.mine_epoch_negatives, sd.get_similarities = real_mine, real_sim
     torch.cuda.synchronize()
     t1 = time.perf_counter()
-    marks.append(t1)
-    per_epoch = [b - a for a, b in zip(marks[:-1], marks[1:])]
-    steady = per_epoch[-1]
+    per_epoch = [b - a for a, b in zip(A[:-1], A[1:])]
+    per_steps = [a1 - b for b, a1 in zip(B[:-1], A[1:])]
+    steady_e, steady_s = (per_epoch[1:] or per_epoch), (per_steps[1:] or per_steps)
+    med = lambda v: sorted(v)[len(v) // 2]
+    steady = med(steady_e)
+    step_ms = 1e3 * med(steady_s) / max(n_steps, 1)
     trainable = sum(p.numel() for p in net.parameters() if p.requires_grad)
+    flop = step_flop(net, P.train_batch_size)
     out = {"untrained_blocks": P.untrained_blocks, "trainable_parameters": trainable,
            "trainable_modules": sorted(set(n.rsplit(".", 2)[0] if n.startswith("features.") else n.rsplit(".", 1)[0]
                                            for n, p in net.named_parameters() if p.requires_grad)),
            "triplets_per_epoch": n_couples, "optimizer_steps_per_epoch": n_steps, "epoch_seconds": per_epoch, "total_seconds": t1 - t0,
-           "triplets_per_s": n_couples / steady, "images_fwd_bwd_per_s": 3 * n_couples / steady,
+           "statistic": "median over epochs 2 .. %d (first epoch dropped)" % (len(per_epoch)),
+           "triplets_per_s": n_couples / steady, "triplets_per_s_min_max": [n_couples / max(steady_e), n_couples / min(steady_e)],
+           "images_fwd_bwd_per_s": 3 * n_couples / steady,
+           "ms_per_step": step_ms, "ms_per_step_min_max": [1e3 * min(steady_s) / max(n_steps, 1), 1e3 * max(steady_s) / max(n_steps, 1)],
+           "roofline": {"bound": "mfma", "peak": 157.3, "unit": "TFLOP/s", "algorithmic_flop_per_step": flop["total"], "phases_flop": flop,
+                        "ms_per_step": step_ms, "achieved": flop["total"] / (step_ms * 1e-3) / 1e12, "frac": flop["total"] / (step_ms * 1e-3) / 157.3e12,
+                        "counts": "forward of the frozen convolutions, forward + input gradient + weight gradient of the trained ones and of the head's "
+                                  "Linear, %d images per step; the epoch's embedding pass and mining are outside ms_per_step" % (3 * P.train_batch_size)},
            "exchange": dict(dp.STATS)}
     if tg.PHASES:
         steps = n_steps * args.epochs
@@ -80,7 +129,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=512)
     ap.add_argument("--labels", type=int, default=64)
-    ap.add_argument("--epochs", type=int, default=2)
+    ap.add_argument("--epochs", type=int, default=5, help=">= 3: the first epoch is dropped, the last has no end mark")
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--configs", default="reference,frozen")
     ap.add_argument("--phases", action="store_true", help="synchronise and time the phases of the training step (diagnostic: the totals are slower)")
