@@ -736,7 +736,7 @@ def main():
             import bench_train
             import io
             import contextlib
-            targs = _ap.Namespace(images=512, labels=64, epochs=5, backbone="resnet50", configs="reference,frozen", phases=False)
+            targs = _ap.Namespace(images=512, labels=64, epochs=5, backbone="resnet50", configs="reference,frozen", phases=False, no_fused_sgd=False)
             res_t = {}
             from train import siamese_descriptor as _sd
             saved_p = dict(_sd.P.__dict__)

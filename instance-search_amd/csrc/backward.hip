@@ -15,19 +15,22 @@
 //
 // Every sum runs in a fixed order (k-ordered MFMA chains over the pixels, fixed-shape block reductions): the gradient of a
 // micro-batch does not depend on what else is in flight, which the canonical gradient tree of isx/dp.py relies on.
+#include <stdlib.h>
+
 #include "wgrad_kernel.hpp"
 
 namespace isx {
 
 int launch_gemm_masked(const float* A, int64_t M, const float* Bt, int64_t N, int D, float* C, const float* mask, const float* add, hipStream_t st);
 
-// number of pixel splits of a weight-gradient launch: enough workgroups to fill the chip (~4 per CU), at least 4 k-tiles each; a function of
+// number of pixel splits of a weight-gradient launch: enough workgroups to fill the chip (~2 per CU), at least 4 k-tiles each; a function of
 // the SHAPE only, so the summation tree of a micro-batch is the same whatever runs around it
 static int wgrad_splits(int64_t K, int Cin, int Cout, int taps) {
     const bool big = Cout % 128 == 0 && Cin % 128 == 0 && (int64_t)(Cout / 128) * (Cin / 128) * taps >= 512;
     const int64_t tiles = (big ? (int64_t)(Cout / 128) * (Cin / 128) : (int64_t)(Cout / 64) * (Cin / 64)) * taps;
     const int64_t nk = (K + 31) / 32;
-    int64_t s = (1024 + tiles - 1) / tiles;
+    static const int64_t target = [] { const char* e = getenv("ISX_WGRAD_TARGET"); const long long v = e ? atoll(e) : 0; return (int64_t)(v >= 64 ? v : 512); }();   // A/B knob; round 5: 1024 -> 512 workgroups per launch of ONE leaf (fewer, longer partial chains: step 24.8 -> 24.5 ms)
+    int64_t s = (target + tiles - 1) / tiles;
     if (s > nk / 4) s = nk / 4;
     if (s > 16) s = 16;
     return (int)(s < 1 ? 1 : s);

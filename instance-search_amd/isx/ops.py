@@ -83,9 +83,12 @@ def head_linear(rows, weight, bias=None):
     """y = rows . weight^T + bias on libisx's split-K GEMM (isx_head_linear_fwd_rows): a row's result does not depend on how many rows ride along,
     and it is the same kernel the training step runs -- one implementation of DescriptorNet's Linear (reference model/siamese.py:104-122).
     rows: (M, K) fp32, weight: (N, K) as nn.Linear stores it, K % 32 == 0, N % 64 == 0."""
-    rows = _f32(rows, "rows")
-    weight = _on_current_device(weight, "weight")
+    rows, weight = _f32(rows, "rows"), _f32(weight, "weight")
+    if bias is not None:
+        bias = _f32(bias, "bias")
     M, K = rows.shape
+    if weight.dim() != 2 or weight.size(1) != K or K % 32 != 0 or weight.size(0) % 64 != 0:
+        raise _lib.IsxError("head_linear: rows (%d, %d) against weight %s (K %% 32 == 0, N %% 64 == 0)" % (M, K, tuple(weight.shape)))
     N = weight.size(0)
     y = torch.empty((M, N), dtype=torch.float32, device=rows.device)
     if M == 0:

@@ -182,11 +182,11 @@ def test_descriptor_net_is_independent_of_the_batch_size_and_matches_the_trainin
     torch.manual_seed(0)
     net = DescriptorNet(TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5), 256, (7, 7)).cuda().eval()
     net.feature_reduc1[1].param.data.normal_(0, 0.002)
-    imgs = torch.stack(list(synthetic_images(70, seed=3))).cuda()
+    imgs = torch.stack(list(synthetic_images(150, seed=3))).cuda()
     with torch.no_grad():
-        ref = torch.cat([net(imgs[i:i + 64]) for i in range(0, 70, 64)], 0)
-        for bs in (3, 16, 35):
-            got = torch.cat([net(imgs[i:i + bs]) for i in range(0, 70, bs)], 0)
+        ref = torch.cat([net(imgs[i:i + 64]) for i in range(0, 150, 64)], 0)
+        for bs in (3, 16, 75, 150):                                  # row tiles of 64, 64, 128 and 192 rows
+            got = torch.cat([net(imgs[i:i + bs]) for i in range(0, 150, bs)], 0)
             assert torch.equal(got, ref), bs
         assert float((ref.norm(dim=1) - 1).abs().max()) < 1e-5
         # the training step's head pass on the same trunk output: the same bits

@@ -162,8 +162,8 @@ def test_fused_weight_gradient_and_sgd_step(nesterov):
             opt_f.step()                                              # must not touch w_f
             w_t.grad = dp.weight_gradient_from_rows(dy, x)
             opt_t.step()
-            scale = float(w_t.abs().max())
-            assert float((w_f - w_t).abs().max()) <= 1e-6 * scale, (step, float((w_f - w_t).abs().max()), scale)
+            scale = float(w_t.detach().abs().max())
+            assert float((w_f - w_t).detach().abs().max()) <= 1e-6 * scale, (step, float((w_f - w_t).detach().abs().max()), scale)
             bf, bt = opt_f.state[w_f]["momentum_buffer"], opt_t.state[w_t]["momentum_buffer"]
             assert float((bf - bt).abs().max()) <= 1e-6 * float(bt.abs().max())
         # the update is a function of the rows only: a second weight stepped with the same rows lands on the same bits

@@ -62,6 +62,7 @@ def run_config(name, args, world, rank, local):
     P.train_epochs, P.train_batch_size, P.train_micro_batch, P.test_batch_size = args.epochs, 64, 8, 128
     P.train_loss_int, P.train_test_int, P.train_epoch_switch = 10 ** 9, 10 ** 9, 1
     P.untrained_blocks = -1 if name == "frozen" else None          # None: the reference's table
+    P.train_fused_head_sgd = not args.no_fused_sgd
     tr = synthetic_image_set(args.images, args.labels, seed=1)
     te = synthetic_image_set(64, args.labels, seed=2)
     n_couples = sum(len(v) for v in get_pos_couples(tr).values())
@@ -132,6 +133,7 @@ def main():
     ap.add_argument("--epochs", type=int, default=5, help=">= 3: the first epoch is dropped, the last has no end mark")
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--configs", default="reference,frozen")
+    ap.add_argument("--no-fused-sgd", action="store_true", help="A/B: the head weight through a dW tensor and torch's optimizer (round 4)")
     ap.add_argument("--phases", action="store_true", help="synchronise and time the phases of the training step (diagnostic: the totals are slower)")
     args = ap.parse_args()
     import torch.distributed as dist
