@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1: keep the search stage of a step (query all-gather, GEMM, top-k, result exchange) on the main stream "
                          "(default: on a second stream behind the next step's trunk)")
+    ap.add_argument("--decode-images", type=int, default=16384, help="images of the decode-inclusive ingest leg (JPEG files -> descriptors); 0 skips it")
     ap.add_argument("--ingest-images", type=int, default=65536,
                     help="images of the non-resident streaming-ingest side measurement (0 = skip); host memory: 4096 distinct uint8 images, the rest views")
     ap.add_argument("--no-train-bench", action="store_true", help="skip the siamese-training side measurement (BASELINE configs[3] on one GPU)")
@@ -291,6 +292,9 @@ def compact_line(full, detail_file=None):
     if isinstance(ig, dict):
         line["ingest_streaming"] = _pick(ig, ("error", "images", "resident_images_per_s", "extract_pcie_inclusive_images_per_s", "streamed_over_resident",
                                               "descriptors_identical"))
+    dg = full.get("ingest_decode")
+    if isinstance(dg, dict):
+        line["ingest_decode"] = _pick(dg, ("error", "images", "cores", "images_per_s", "decode_only_images_per_s", "decode_bound", "descriptors_identical_to_decode_first"))
     tr = full.get("training")
     if isinstance(tr, dict):
         line["training"] = _pick(tr, ("error", "reference_config_triplets_per_s", "frozen_trunk_triplets_per_s", "reference_over_frozen", "reference_config", "statistic"))
@@ -313,7 +317,7 @@ def compact_line(full, detail_file=None):
     for key in ("value", "ms_per_step", "dist_per_s"):          # the contract's scalars keep their digits
         if key in full:
             line[key] = full[key]
-    for victim in ("families", "training", "ingest_streaming", "exchange", "extraction_regions", "retrieval_shard", "roofline_step"):      # never expected: a safety net
+    for victim in ("families", "training", "ingest_decode", "ingest_streaming", "exchange", "extraction_regions", "retrieval_shard", "roofline_step"):      # never expected: a safety net
         if len(json.dumps(line)) <= MAX_LINE_BYTES:
             break
         line.pop(victim, None)
@@ -719,11 +723,82 @@ def main():
                 "first_pass_with_upload_images_per_s": n / t_up, "descriptors_identical": same,
                 "path": "train.classif_finetune.get_embeddings -> train._common.BatchStager (2 pinned buffers, copy stream, look-ahead 1)"}
 
+    def ingest_decode_bench():
+        """Extraction FROM FILES: 2048 JPEG files (224 x 224, smooth pattern + noise, quality 90) written to a scratch folder, a 16 384-entry gallery
+        cycling through them as train._common.LazyImage entries, through get_embeddings (decode pool -> pinned staging -> copy stream -> trunk).
+        The same files decoded by the pool alone give the host's decode rate: whichever is lower bounds an evaluation run on a real folder."""
+        import shutil
+        import tempfile
+        from concurrent.futures import ThreadPoolExecutor
+        import numpy as np
+        from PIL import Image
+        from test import _common as C
+        from train import _common as TC
+        from train import classif_finetune as cf
+        n_files, n = 2048, args.decode_images
+        tmp = tempfile.mkdtemp(prefix="isx_decode_")
+        rng = np.random.default_rng(3)
+
+        def write(i):
+            low = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8) if False else np.random.default_rng(i).integers(0, 256, (8, 8, 3), dtype=np.uint8)
+            im = np.asarray(Image.fromarray(low).resize((224, 224), Image.BICUBIC), dtype=np.int16)
+            im = np.clip(im + np.random.default_rng(10 ** 6 + i).integers(-12, 13, im.shape), 0, 255).astype(np.uint8)
+            Image.fromarray(im).save(os.path.join(tmp, "%05d.jpg" % i), quality=90)
+
+        workers = TC.decode_workers()
+        try:
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                list(pool.map(write, range(n_files)))
+            file_bytes = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp)) / float(n_files)
+            load = lambda f: C.to_raw_tensor(C.imread_rgb(f))
+            files = [os.path.join(tmp, "%05d.jpg" % (i % n_files)) for i in range(n)]
+            t0_ = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                for _ in pool.map(load, files[:4096]):
+                    pass
+            decode_only = 4096 / (time.perf_counter() - t0_)
+            first = load(files[0])
+            data = [(TC.LazyImage(f, load, first.shape, first.dtype), "l%d" % (i % 100), f) for i, f in enumerate(files)]
+            P = cf.P
+            saved = dict(P.__dict__)
+            TC.RAW_INGEST["mean"], TC.RAW_INGEST["std"] = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+            try:
+                P.cuda_device, P.embeddings_classify, P.embeddings_fc7, P.test_pre_proc, P.test_batch_size = local, False, False, True, 64
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                slab = cf.get_embeddings(net, data, local, 2048)
+                torch.cuda.synchronize()
+                t_pipe = time.perf_counter() - t0_
+                # the same files decoded up front (the reference's way), then extracted from RAM: descriptors must be identical
+                eager = [(load(f), lab, f) for _, lab, f in data[:1024]]
+                TC.drop_resident()
+                slab_e = cf.get_embeddings(net, eager, local, 2048)
+                same = bool(torch.equal(slab[:1024], slab_e))
+            finally:
+                TC.drop_resident()
+                TC.RAW_INGEST["mean"] = TC.RAW_INGEST["std"] = None
+                P.__dict__.clear(); P.__dict__.update(saved)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        rate = n / t_pipe
+        ips = world * B * args.steps / dt                      # the headline rate of this run (inputs resident in HBM)
+        return {"images": n, "files": n_files, "format": "JPEG 224x224 quality 90, %.0f KB per file, PIL decode" % (file_bytes / 1e3), "cores": workers,
+                "images_per_s": rate, "decode_only_images_per_s": decode_only, "decode_bound": bool(rate < 0.9 * ips),
+                "fraction_of_resident_rate": rate / ips, "descriptors_identical_to_decode_first": same,
+                "path": "test._common.load_sets(lazy) form: LazyImage -> decode pool (3 batches ahead) -> BatchStager pinned staging -> copy stream -> trunk"}
+
     if args.ingest_images > 0 and rank == 0 and args.backbone_dtype == "f32" and not args.no_fold_bn:
         try:
             ingest_result = ingest_bench()
         except Exception as e:
             ingest_result = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    ingest_decode_result = None
+    if args.decode_images > 0 and rank == 0 and args.backbone_dtype == "f32" and not args.no_fold_bn:
+        try:
+            ingest_decode_result = ingest_decode_bench()
+        except Exception as e:
+            ingest_decode_result = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
 
     # side measurement: next-scope row f1 (BASELINE configs[3] on ONE GPU) -- siamese triplet training of DescriptorNet(ResNet-50) on the
@@ -881,6 +956,8 @@ def main():
             line["extraction_regions"] = regions_result
         if ingest_result is not None:
             line["ingest_streaming"] = ingest_result
+        if ingest_decode_result is not None:
+            line["ingest_decode"] = ingest_decode_result
         if training_result is not None:
             line["training"] = training_result
         if world > 1:

@@ -175,6 +175,18 @@ class ShardedGallery(object):
         lo, hi = shard_bounds(gallery.size(0), ws, rk)
         return cls(gallery[lo:hi], lo, group)
 
+    @classmethod
+    def from_slab(cls, path, device, group=None, fast=True):
+        """This rank's contiguous row range of a descriptor slab file (isx/slab.py), read straight into its device: every rank maps only its own
+        1/P of the file (mmap -> pinned staging -> HBM) -- the gallery is extracted once and searched by any number of ranks, where the reference
+        re-extracts it on every run (test/classif_finetune_test.py:80-81)."""
+        from . import slab
+        ws = dist.get_world_size(group) if dist.is_initialized() else 1
+        rk = dist.get_rank(group) if dist.is_initialized() else 0
+        lo, hi = shard_bounds(slab.slab_info(path)["rows"], ws, rk)
+        shard, _ = slab.load_slab(path, device, rows=(lo, hi))
+        return cls(shard, lo, group, fast=fast)
+
     def _workspace(self, M, k):
         if not self.shard.is_cuda:
             return None

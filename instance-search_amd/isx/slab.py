@@ -27,27 +27,92 @@ _HDR = struct.Struct("<8sQIIQ32x")
 CHUNK_ROWS = 1 << 16            # 512 MB staging pieces at D = 2048
 
 
+class SlabWriter(object):
+    """Streaming writer: the header is written first (N and D are known: the extraction loop fills a slab of that shape), row blocks are appended
+    as they come -- from the host or from the GPU, CHUNK_ROWS at a time through one reusable pinned buffer -- and `close` adds the labels and
+    moves the file into place.  No copy of the whole array is ever made (round 4's save_slab held descriptors + `tobytes()`: 2 x 8.2 GB at 1 M x 2048)."""
+
+    def __init__(self, path, rows, dim, has_labels=False, normalised=True):
+        self.path, self.tmp, self.N, self.D = path, path + ".tmp", int(rows), int(dim)
+        self.label_off = DATA_OFFSET + ((self.N * self.D * 4 + 4095) // 4096) * 4096 if has_labels else 0
+        self.f = open(self.tmp, "wb")
+        self.f.write(_HDR.pack(MAGIC, self.N, self.D, 1 if normalised else 0, self.label_off))
+        self.f.seek(DATA_OFFSET)
+        self.written = 0
+        self._pin = None
+
+    def append(self, block):
+        """block: (n, D) fp32 rows that follow the rows written so far (torch tensor on any device, or ndarray)."""
+        if isinstance(block, torch.Tensor):
+            block = block.detach()
+            if block.dim() != 2 or block.size(1) != self.D or block.dtype != torch.float32:
+                raise ValueError("slab rows must be (n, %d) float32, got %s %s" % (self.D, tuple(block.shape), block.dtype))
+            for r0 in range(0, block.size(0), CHUNK_ROWS):
+                piece = block[r0:r0 + CHUNK_ROWS]
+                if piece.is_cuda:
+                    if self._pin is None or self._pin.size(0) < piece.size(0):
+                        self._pin = torch.empty((min(CHUNK_ROWS, max(piece.size(0), 1)), self.D), dtype=torch.float32).pin_memory()
+                    host = self._pin[:piece.size(0)]
+                    host.copy_(piece)
+                else:
+                    host = piece.contiguous()
+                host.numpy().tofile(self.f)
+                self.written += piece.size(0)
+        else:
+            a = np.ascontiguousarray(block, dtype=np.float32)
+            if a.ndim != 2 or a.shape[1] != self.D:
+                raise ValueError("slab rows must be (n, %d), got %s" % (self.D, a.shape))
+            a.tofile(self.f)
+            self.written += a.shape[0]
+        if self.written > self.N:
+            raise ValueError("more rows appended (%d) than the slab was opened for (%d)" % (self.written, self.N))
+
+    def close(self, labels=None):
+        if self.written != self.N:
+            self.f.close()
+            os.unlink(self.tmp)
+            raise ValueError("slab opened for %d rows, %d appended" % (self.N, self.written))
+        if self.label_off:
+            lab = labels.detach().cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
+            lab = np.ascontiguousarray(lab, dtype=np.int32)
+            if lab.shape != (self.N,):
+                raise ValueError("labels must have shape (%d,)" % self.N)
+            self.f.seek(self.label_off)
+            lab.tofile(self.f)
+        elif labels is not None:
+            raise ValueError("the slab was opened without labels")
+        self.f.close()
+        os.replace(self.tmp, self.path)
+
+
 def save_slab(path, descriptors, labels=None, normalised=True):
-    """Write (N, D) fp32 descriptors (torch tensor on any device, or ndarray) and optional int labels."""
-    d = descriptors.detach().cpu().numpy() if isinstance(descriptors, torch.Tensor) else np.asarray(descriptors)
-    d = np.ascontiguousarray(d, dtype=np.float32)
-    N, D = d.shape
-    label_off = 0
-    if labels is not None:
-        lab = labels.detach().cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
-        lab = np.ascontiguousarray(lab, dtype=np.int32)
-        if lab.shape != (N,):
-            raise ValueError("labels must have shape (%d,)" % N)
-        label_off = DATA_OFFSET + ((N * D * 4 + 4095) // 4096) * 4096
-    tmp = path + ".tmp"
-    with open(tmp, "wb") as f:
-        f.write(_HDR.pack(MAGIC, N, D, 1 if normalised else 0, label_off))
-        f.seek(DATA_OFFSET)
-        f.write(d.tobytes())
-        if labels is not None:
-            f.seek(label_off)
-            f.write(lab.tobytes())
-    os.replace(tmp, path)
+    """Write (N, D) fp32 descriptors (torch tensor on any device, or ndarray) and optional int labels, row block by row block (SlabWriter)."""
+    N, D = descriptors.shape
+    w = SlabWriter(path, N, D, has_labels=labels is not None, normalised=normalised)
+    w.append(descriptors if isinstance(descriptors, torch.Tensor) else np.asarray(descriptors))
+    w.close(labels)
+
+
+def save_gallery(path, descriptors, ref_set, labels):
+    """A gallery as the evaluation entry points hold it -- the descriptor slab of `ref_set` ((image, label, path) tuples) and the run's sorted
+    label list -- as a slab file + `<path>.labels.json` (label names: the slab stores their indices)."""
+    import json
+    ids = dict((lab, i) for i, lab in enumerate(labels))
+    save_slab(path, descriptors, torch.tensor([ids[lab] for _, lab, _ in ref_set], dtype=torch.int32))
+    with open(path + ".labels.json", "w") as f:
+        json.dump({"labels": list(labels), "paths": [p for _, _, p in ref_set]}, f)
+
+
+def load_gallery(path, device="cpu", rows=None):
+    """(descriptors, ref_set, labels) of save_gallery: ref_set = [(None, label, path)] -- what the metrics read of a gallery item."""
+    import json
+    desc, lab = load_slab(path, device, rows)
+    with open(path + ".labels.json") as f:
+        side = json.load(f)
+    names, paths = side["labels"], side["paths"]
+    lo = 0 if rows is None else rows[0]
+    ref_set = [(None, names[int(i)], paths[lo + j]) for j, i in enumerate(lab.tolist())]
+    return desc, ref_set, names
 
 
 def slab_info(path):

@@ -56,11 +56,13 @@ def to_raw_tensor(img):
     return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
 
 
-def load_sets(dataset_full, labels, raw=False):
+def load_sets(dataset_full, labels, raw=False, lazy=None):
     """(test_set, test_train_set) as lists of (normalised tensor, label, path); fills `labels`
     with the sorted label set of the reference (gallery) images; queries whose label is
     unknown are dropped (reference test/classif_finetune_test.py:62-73).  raw=True keeps folder images
-    as uint8 (H,W,3) tensors and registers mean/std for the GPU-side ToTensor + Normalize."""
+    as uint8 (H,W,3) tensors and registers mean/std for the GPU-side ToTensor + Normalize.
+    lazy (default: raw and ISX_LAZY_INGEST != 0): the GALLERY of a folder dataset carries train._common.LazyImage entries -- decoded batch by
+    batch on a thread pool while the previous batch runs, never all in RAM; the queries (classified AND embedded: read twice) are decoded up front."""
     if is_synthetic(dataset_full):
         _, o = synthetic_spec(dataset_full)
         size = (3, o['size'], o['size'])
@@ -80,7 +82,14 @@ def load_sets(dataset_full, labels, raw=False):
         load = lambda f: to_raw_tensor(imread_rgb(f))
     else:
         load = lambda f: to_normalised_tensor(imread_rgb(f), mean, std)
-    ref = [(im, lab, f) for im, (f, lab) in zip(_decode_all(load, [f for f, _ in ref_files]), ref_files)]
+    if lazy is None:
+        lazy = raw and os.environ.get("ISX_LAZY_INGEST", "1") != "0"
+    if lazy and ref_files:
+        from train import _common as TC
+        first = load(ref_files[0][0])
+        ref = [(TC.LazyImage(f, load, first.shape, first.dtype), lab, f) for f, lab in ref_files]
+    else:
+        ref = [(im, lab, f) for im, (f, lab) in zip(_decode_all(load, [f for f, _ in ref_files]), ref_files)]
     qry_files = [(f, lab) for f, lab in qry_files if lab in labels]
     qry = [(im, lab, f) for im, (f, lab) in zip(_decode_all(load, [f for f, _ in qry_files]), qry_files)]
     return qry, ref
@@ -97,6 +106,28 @@ def _decode_all(load, files):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=workers) as pool:
         return list(pool.map(load, files))
+
+
+def gallery_embeddings(get_embeddings, net, ref_set, device, out_size, labels, save_slab=None, gallery_slab=None):
+    """(gallery descriptors, gallery set) of an evaluation run.  Default: extracted, as the reference does on every run
+    (test/classif_finetune_test.py:80-81).  --save-slab=<file>: the extracted slab is also written to disk (isx/slab.py: row blocks streamed from
+    the GPU, labels, + <file>.labels.json); --gallery-slab=<file>: nothing is extracted -- the slab is read back (mmap -> pinned staging -> HBM)
+    and the run ranks against it; the label set of the file must be the run's."""
+    from isx import slab
+    if gallery_slab:
+        dev = 'cuda:%d' % device if device >= 0 else 'cpu'
+        desc, slab_set, names = slab.load_gallery(gallery_slab, dev)
+        if list(names) != list(labels):
+            raise ValueError('--gallery-slab: %s was written for another label set (%d labels, this run has %d)' % (gallery_slab, len(names), len(labels)))
+        if desc.size(1) != out_size:
+            raise ValueError('--gallery-slab: %s holds %d-d descriptors, this run computes %d-d ones' % (gallery_slab, desc.size(1), out_size))
+        print('Gallery: {0} descriptors read from {1}'.format(desc.size(0), gallery_slab))
+        return desc, slab_set
+    emb = get_embeddings(net, ref_set, device, out_size)
+    if save_slab:
+        slab.save_gallery(save_slab, emb, ref_set, labels)
+        print('Gallery: {0} descriptors written to {1}'.format(emb.size(0), save_slab))
+    return emb, ref_set
 
 
 def evaluate_retrieval(test_embeddings, ref_embeddings, test_set, ref_set, device, labels, dba):
@@ -139,6 +170,8 @@ def run_cli(argv, usage, spec, required, main, P):
             val = check_model(arg, usage)
         elif kind == 'file':
             val = check_file(arg, label, True, usage)
+        elif kind == 'path':
+            val = arg
         elif kind == 'int':
             val = check_int(arg, label, usage)
         else:
@@ -173,4 +206,6 @@ O_MODEL = '--model=\t<name>\tAlexNet, ResNet152 or ResNet50 to specify the type 
 O_DEVICE = '--device=\t<int>\tThe GPU device used for testing. If negative, CPU is used.\n'
 O_DBA = ('--dba=\t<int>\tUse DBA with given k. If k = 0, do not use DBA. If k<0, use all neighbors within the '
          'same instance.\n')
+O_SLAB = ('--save-slab=\t<file>\t(extension) Also write the gallery descriptors to this slab file.\n'
+          '--gallery-slab=\t<file>\t(extension) Read the gallery descriptors from this slab file instead of extracting them.\n')
 O_BATCH = '--batch=\t<int>\tThe batch size to use.\n'

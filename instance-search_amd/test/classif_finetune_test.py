@@ -22,11 +22,11 @@ def usage():
         '--weights=\t<file>\tThe filename containing weights of a network trained for sub-region classification.\n',
         C.O_DEVICE,
         '--classify=\t<bool>\tTrue/yes/y/1 if the classification feature should be tested. Otherwise, convolutional '
-        'features are tested.\n', C.O_BATCH, C.O_DBA,
+        'features are tested.\n', C.O_BATCH, C.O_DBA, C.O_SLAB,
         '--fc7=\t<bool>\t(extension) AlexNet only: test the 4096-d fc7 activation (classifier[:6]) instead of pool5.\n'])
 
 
-def main(dataset_full, model, weights, device, classify, batch_size, dba, fc7=False):
+def main(dataset_full, model, weights, device, classify, batch_size, dba, fc7=False, save_slab=None, gallery_slab=None):
     dataset_id = C.dataset_id_of(dataset_full)
     del labels[:]
     print('Loading and transforming train/test sets.')
@@ -52,13 +52,14 @@ def main(dataset_full, model, weights, device, classify, batch_size, dba, fc7=Fa
     c, t = test_classif_net(class_net, test_set)
     print('Classification (TEST): {0} / {1} - acc: {2:.4f}'.format(c, t, float(c) / t))
     test_embeddings = get_embeddings(class_net, test_set, device, out_size)
-    ref_embeddings = get_embeddings(class_net, test_train_set, device, out_size)
+    ref_embeddings, test_train_set = C.gallery_embeddings(get_embeddings, class_net, test_train_set, device, out_size, labels, save_slab, gallery_slab)
     return C.evaluate_retrieval(test_embeddings, ref_embeddings, test_set, test_train_set, device, labels, dba)
 
 
 if __name__ == '__main__':
     C.run_cli(sys.argv[1:], usage,
               {'dataset': ('dataset', 'dataset'), 'model': ('model', 'model'), 'weights': ('file', 'initialization weights'),
-               'device': ('int', 'device'), 'classify': ('bool', 'classify'), 'batch': ('int', 'batch'), 'dba': ('int', 'dba'), 'fc7': ('bool', 'fc7')},
+               'device': ('int', 'device'), 'classify': ('bool', 'classify'), 'batch': ('int', 'batch'), 'dba': ('int', 'dba'), 'save-slab': ('path', 'slab file to write'), 'gallery-slab': ('file', 'slab file to read'), 'fc7': ('bool', 'fc7')},
               ('dataset', 'model', 'device', 'classify', 'batch'),
-              lambda dataset, model, weights, device, classify, batch, dba, fc7=None: main(dataset, model, weights, device, classify, batch, dba, bool(fc7)), P)
+              lambda dataset, model, weights, device, classify, batch, dba, fc7=None, save_slab=None, gallery_slab=None:
+              main(dataset, model, weights, device, classify, batch, dba, bool(fc7), save_slab, gallery_slab), P)

@@ -14,10 +14,10 @@ def usage():
     C.usage_text(sys.argv[0], [
         C.O_DATASET, C.O_MODEL,
         '--weights=\t<file>\tThe filename containing weights of a network trained for sub-region classification.\n',
-        C.O_DEVICE, C.O_DBA])
+        C.O_DEVICE, C.O_DBA, C.O_SLAB])
 
 
-def main(dataset_full, model, weights, device, dba):
+def main(dataset_full, model, weights, device, dba, save_slab=None, gallery_slab=None):
     dataset_id = C.dataset_id_of(dataset_full)
     del labels[:]
     print('Loading and transforming train/test sets.')
@@ -35,13 +35,13 @@ def main(dataset_full, model, weights, device, dba):
     c, t = test_classif_net(class_net, test_set)
     print('Classification (TEST): {0} / {1} - acc: {2:.4f}'.format(c, t, float(c) / t))
     test_embeddings = get_embeddings(class_net, test_set, device, len(labels))
-    ref_embeddings = get_embeddings(class_net, test_train_set, device, len(labels))
+    ref_embeddings, test_train_set = C.gallery_embeddings(get_embeddings, class_net, test_train_set, device, len(labels), labels, save_slab, gallery_slab)
     return C.evaluate_retrieval(test_embeddings, ref_embeddings, test_set, test_train_set, device, labels, dba)
 
 
 if __name__ == '__main__':
     C.run_cli(sys.argv[1:], usage,
               {'dataset': ('dataset', 'dataset'), 'model': ('model', 'model'), 'weights': ('file', 'initialization weights'),
-               'device': ('int', 'device'), 'dba': ('int', 'dba')},
+               'device': ('int', 'device'), 'dba': ('int', 'dba'), 'save-slab': ('path', 'slab file to write'), 'gallery-slab': ('file', 'slab file to read')},
               ('dataset', 'model', 'device'),
-              lambda dataset, model, weights, device, dba: main(dataset, model, weights, device, dba), P)
+              lambda dataset, model, weights, device, dba, save_slab=None, gallery_slab=None: main(dataset, model, weights, device, dba, save_slab, gallery_slab), P)

@@ -15,10 +15,10 @@ def usage():
         C.O_DATASET, C.O_MODEL,
         '--weights=\t<file>\tThe filename containing weights of a network trained as region siamese descriptor.\n',
         C.O_DEVICE, '--feature-dim=\t<int>\tThe dimension of the descriptor.\n',
-        '--regions-k=\t<int>\tThe number of regions to use.\n', C.O_DBA])
+        '--regions-k=\t<int>\tThe number of regions to use.\n', C.O_DBA, C.O_SLAB])
 
 
-def main(dataset_full, model, weights, device, feature_dim, regions_k, dba):
+def main(dataset_full, model, weights, device, feature_dim, regions_k, dba, save_slab=None, gallery_slab=None):
     dataset_id = C.dataset_id_of(dataset_full)
     del labels[:]
     print('Loading and transforming train/test sets.')
@@ -37,13 +37,14 @@ def main(dataset_full, model, weights, device, feature_dim, regions_k, dba):
     net = get_siamese_net()
     prepare_for_inference(net, P)
     test_embeddings = get_embeddings(net, test_set, device, net.feature_size)
-    ref_embeddings = get_embeddings(net, test_train_set, device, net.feature_size)
+    ref_embeddings, test_train_set = C.gallery_embeddings(get_embeddings, net, test_train_set, device, net.feature_size, labels, save_slab, gallery_slab)
     return C.evaluate_retrieval(test_embeddings, ref_embeddings, test_set, test_train_set, device, labels, dba)
 
 
 if __name__ == '__main__':
     C.run_cli(sys.argv[1:], usage,
               {'dataset': ('dataset', 'dataset'), 'model': ('model', 'model'), 'weights': ('file', 'initialization weights'),
-               'device': ('int', 'device'), 'feature-dim': ('int', 'feature-dim'), 'regions-k': ('int', 'regions-k'), 'dba': ('int', 'dba')},
+               'device': ('int', 'device'), 'feature-dim': ('int', 'feature-dim'), 'regions-k': ('int', 'regions-k'), 'dba': ('int', 'dba'), 'save-slab': ('path', 'slab file to write'), 'gallery-slab': ('file', 'slab file to read')},
               ('dataset', 'model', 'device', 'feature_dim', 'regions_k'),
-              lambda dataset, model, weights, device, feature_dim, regions_k, dba: main(dataset, model, weights, device, feature_dim, regions_k, dba), P)
+              lambda dataset, model, weights, device, feature_dim, regions_k, dba, save_slab=None, gallery_slab=None:
+              main(dataset, model, weights, device, feature_dim, regions_k, dba, save_slab, gallery_slab), P)

@@ -27,6 +27,72 @@ def normalise_u8_batch(x_u8, device):
     return (x - m) / s_
 
 
+# Lazy ingest: the reference decodes a whole folder into a Python list before the first launch
+# (test/classif_finetune_test.py:62-73, utils/image.py:211-214); a 1 M-image gallery is 150 GB of decoded pixels -- more than the host has -- and
+# the GPU waits for the last file before it sees the first.  A folder dataset can instead carry LazyImage entries: the usual (image, label, path)
+# tuples whose image is decoded when a batch needs it, on a pool of threads (PIL's decoders release the GIL), a bounded number of batches ahead
+# of the trunk (BatchStager) and dropped once stacked into the pinned staging buffer.  Labels and paths are plain as ever.
+_DECODE_POOL = None
+
+
+def decode_workers():
+    return int(os.environ.get("ISX_DECODE_THREADS", "0")) or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+
+
+def _decode_pool():
+    global _DECODE_POOL
+    if _DECODE_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _DECODE_POOL = ThreadPoolExecutor(max_workers=max(1, decode_workers()))
+    return _DECODE_POOL
+
+
+class LazyImage(object):
+    """Stands where the image tensor of a (image, label, path) tuple stands; `shape` / `dtype` are those of the decoded image (all images of a
+    lazy set share them -- the reference's datasets are pre-sized, train/global_p.py image_sizes), `get()` returns the tensor."""
+    __slots__ = ("path", "load", "shape", "dtype", "_fut")
+    is_cuda = False
+
+    def __init__(self, path, load, shape, dtype):
+        self.path, self.load, self.shape, self.dtype, self._fut = path, load, tuple(shape), dtype, None
+
+    def _decode(self):
+        t = self.load(self.path)
+        if tuple(t.shape) != self.shape or t.dtype != self.dtype:
+            raise RuntimeError("lazy ingest needs same-sized images: %s is %s %s, the set's first image %s %s (ISX_LAZY_INGEST=0 decodes ragged folders up front)"
+                               % (self.path, tuple(t.shape), t.dtype, self.shape, self.dtype))
+        return t
+
+    def prefetch(self):
+        if self._fut is None:
+            self._fut = _decode_pool().submit(self._decode)
+
+    def get(self):
+        self.prefetch()
+        return self._fut.result()
+
+    def release(self):
+        self._fut = None
+
+
+def is_lazy(dataset):
+    return len(dataset) > 0 and isinstance(dataset[0][0], LazyImage)
+
+
+def resolve_images(ims):
+    """Tensors of a list of images, LazyImage entries decoded (in parallel) and released."""
+    if not any(isinstance(im, LazyImage) for im in ims):
+        return ims
+    for im in ims:
+        if isinstance(im, LazyImage):
+            im.prefetch()
+    out = [im.get() if isinstance(im, LazyImage) else im for im in ims]
+    for im in ims:
+        if isinstance(im, LazyImage):
+            im.release()
+    return out
+
+
 # Resident datasets: the reference keeps a dataset as a Python list of per-image CPU tensors and stacks + copies a batch
 # at every step (train/siamese_descriptor.py:95-137, train/classif_finetune.py:92-104); on a 288 GB GPU the whole set
 # (uint8 pixels with the raw ingest, or fp32 tensors) is copied to HBM ONCE and batches are row gathers on the device.
@@ -99,7 +165,7 @@ class ResidentImages(object):
 def make_resident(dataset, device):
     """Register the images of `dataset` ((tensor, label, path) tuples) as a device-resident block; no-op on the CPU, for
     ragged image sizes, or beyond RESIDENT_BUDGET_BYTES."""
-    if device < 0 or not dataset:
+    if device < 0 or not dataset or is_lazy(dataset):
         return None
     ims = [im for im, _, _ in dataset]
     if any(r.covers(ims) for r in _RESIDENT):
@@ -121,6 +187,7 @@ def drop_resident():
 
 def stage_images(ims, device):
     """A list of same-shaped image tensors (fp32 CHW, or uint8 HWC for the raw ingest) -> one device batch, normalised."""
+    ims = resolve_images(ims)
     if device >= 0:
         for r in _RESIDENT:
             if r.covers(ims):
@@ -152,11 +219,12 @@ class BatchStager(object):
     def __init__(self, dataset, batch_size, trans, device, force_streaming=None):
         self.dataset, self.bs, self.trans, self.device = dataset, int(batch_size), trans, device
         self.streaming = False
+        self.lazy = is_lazy(dataset)
         if device >= 0 and trans is None and self.bs > 0 and len(dataset) > 0 and torch.cuda.is_available():
             ims = [im for im, _, _ in dataset]
             first = ims[0]
-            uniform = not any(im.shape != first.shape or im.dtype != first.dtype or im.is_cuda for im in ims)
-            resident = any(r.covers(ims) for r in _RESIDENT)
+            uniform = not any(tuple(im.shape) != tuple(first.shape) or im.dtype != first.dtype or im.is_cuda for im in ims)
+            resident = not self.lazy and any(r.covers(ims) for r in _RESIDENT)
             self.streaming = uniform and not resident if force_streaming is None else bool(force_streaming) and uniform
         if self.streaming:
             dev = torch.device('cuda', device)
@@ -173,6 +241,14 @@ class BatchStager(object):
     def _submit(self, start):
         slot = (start // self.bs) & 1
         chunk = [im for im, _, _ in self.dataset[start:start + self.bs]]
+        if self.lazy:
+            # decode-ahead: the files of this batch and of the next two are with the decoder threads before this call blocks on the first image --
+            # batch i + 2 is being decoded while batch i + 1 is stacked / copied and the trunk runs batch i; at most three batches are decoded in RAM
+            for im, _, _ in self.dataset[start:start + 3 * self.bs]:
+                im.prefetch()
+            lazy_chunk, chunk = chunk, [im.get() for im in chunk]
+            for im in lazy_chunk:
+                im.release()
         if self.copied[slot] is not None:
             self.copied[slot].synchronize()                      # the pinned buffer is free once its previous copy has left it
         _parallel_stack(chunk, self.host[slot])

@@ -531,3 +531,52 @@ def test_row_segments_choice_is_a_divisor_and_bounded():
         assert S >= 2 and N % S == 0 and N // S >= max(k, 1024) and S * k <= 4096 and S <= 64
     for M, N, k in ((5000, 100000, 100), (1000, 10000, 100), (3, 100003, 7), (10, 100000, 300)):
         assert ops._row_segments(M, N, k) == 0
+
+
+def test_lazy_gallery_ingest_matches_the_decoded_list(tmp_path, monkeypatch):
+    """train._common.LazyImage: the gallery of a folder dataset as (LazyImage, label, path) tuples -- labels / paths / len / slices are those of the
+    decoded list, a staged batch has the same bytes, a finished batch drops its decoded images, a ragged folder is refused with a clear message
+    (reference test/classif_finetune_test.py:62-73 decodes the whole folder before the first batch)."""
+    import numpy as np
+    from PIL import Image
+    from test import _common as C
+    from train import _common as TC
+    root = tmp_path / "CLICIDE_video_224sq"
+    (root / "test").mkdir(parents=True)
+    (tmp_path / "data").mkdir()
+    (tmp_path / "data" / "CLICIDE_224sq_train_ms.txt").write_text("0.485 0.456 0.406\n0.229 0.224 0.225\n")
+    rng = np.random.default_rng(0)
+    for lab in "ab":
+        for i in range(5):
+            Image.fromarray(rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)).save(root / ("%s-%d.png" % (lab, i)))
+        Image.fromarray(rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)).save(root / "test" / ("%s-9.png" % lab))
+    monkeypatch.chdir(tmp_path)
+    l1, l2 = [], []
+    q, ref = C.load_sets(str(root), l1, raw=True, lazy=True)
+    q2, ref2 = C.load_sets(str(root), l2, raw=True, lazy=False)
+    assert TC.is_lazy(ref) and not TC.is_lazy(q) and not TC.is_lazy(ref2) and l1 == l2
+    assert [t[1:] for t in ref] == [t[1:] for t in ref2] and tuple(ref[0][0].shape) == (32, 32, 3) and ref[0][0].dtype == torch.uint8
+    assert TC.make_resident(ref, 0) is None                                   # a lazy set is never copied wholesale
+    for a in range(0, 10, 4):
+        assert torch.equal(TC.stage_batch(ref[a:a + 4], None, -1), TC.stage_batch(ref2[a:a + 4], None, -1))
+    assert all(t[0]._fut is None for t in ref)                                # decoded images are dropped once staged
+    Image.fromarray(rng.integers(0, 256, (16, 32, 3), dtype=np.uint8)).save(root / "b-7.png")
+    _, ragged = C.load_sets(str(root), [], raw=True, lazy=True)
+    with pytest.raises(RuntimeError, match="same-sized"):
+        TC.stage_batch(ragged, None, -1)
+
+
+def test_gallery_slab_cli_round_trip_on_the_cpu(tmp_path, capsys):
+    """--save-slab / --gallery-slab of the evaluation mains (extension; the reference re-extracts the gallery every run, test/classif_finetune_test.py:80-81):
+    the second run ranks against the file and prints the same result line; a slab of another label set is refused."""
+    from test import classif_finetune_test as T
+    spec = "synthetic:CLICIDE_video_224sq:n=24:q=6:labels=4"
+    f = str(tmp_path / "g.slab")
+    torch.manual_seed(0)                                                      # the class-score layer is random-initialised per run
+    r1 = T.main(spec, "alexnet", "", -1, True, 8, 0, save_slab=f)
+    torch.manual_seed(0)
+    r2 = T.main(spec, "alexnet", "", -1, True, 8, 0, gallery_slab=f)
+    out = capsys.readouterr().out
+    assert r1 == r2 and "descriptors written to" in out and "descriptors read from" in out
+    with pytest.raises(ValueError, match="another label set"):
+        T.main("synthetic:CLICIDE_video_224sq:n=24:q=6:labels=5", "alexnet", "", -1, True, 8, 0, gallery_slab=f)

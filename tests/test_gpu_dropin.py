@@ -311,6 +311,63 @@ def test_folder_dataset_raw_ingest_end_to_end(tmp_path, capsys, monkeypatch):
     np.testing.assert_allclose(host(q_raw), host(q_f32), rtol=1e-5, atol=1e-6)
 
 
+def test_folder_pipeline_lazy_decode_and_gallery_slab(tmp_path, capsys, monkeypatch):
+    """f4 + f2 as a pipeline (reference test/classif_finetune_test.py:62-73, 80-82: decode everything, extract everything, every run): the gallery
+    of a folder dataset is decoded batch by batch on the thread pool while the previous batch runs (train._common.LazyImage + BatchStager) --
+    descriptors bit-identical to the decode-everything-first path; --save-slab writes them, --gallery-slab ranks against the file without
+    touching the gallery images -- same P@1 / mAP / descriptors; ShardedGallery.from_slab searches the file's rows like the tensor in memory."""
+    from PIL import Image
+    from isx import ops, retrieval
+    from test import _common as C
+    from test import classif_finetune_test
+    from train import _common as TC
+    rng = np.random.default_rng(5)
+    root = tmp_path / "CLICIDE_video_224sq"
+    (root / "test").mkdir(parents=True)
+    (tmp_path / "data").mkdir()
+    (tmp_path / "data" / "CLICIDE_224sq_train_ms.txt").write_text("0.485 0.456 0.406\n0.229 0.224 0.225\n")
+    for lab in ("a", "b", "c", "d"):
+        for i in range(9):
+            Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(root / ("%s-%d.png" % (lab, i)))
+        Image.fromarray(rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)).save(root / "test" / ("%s-9.png" % lab))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(TC, "_MIN_DEVICE_BATCH_PIXELS", 0)              # batches of 4: nine gallery batches through the decode-ahead
+    seen, lazy_flags = [], []
+    real_eval, real_load = C.evaluate_retrieval, C.load_sets
+
+    def spy(test_embeddings, ref_embeddings, test_set, ref_set, *a, **k):
+        seen.append((test_embeddings.clone(), ref_embeddings.clone(), [r[1:] for r in ref_set]))
+        return real_eval(test_embeddings, ref_embeddings, test_set, ref_set, *a, **k)
+
+    def load(dataset_full, labels, raw=False, lazy=None):
+        out = real_load(dataset_full, labels, raw=raw, lazy=lazy)
+        lazy_flags.append(TC.is_lazy(out[1]))
+        return out
+
+    monkeypatch.setattr(C, "evaluate_retrieval", spy)
+    monkeypatch.setattr(C, "load_sets", load)
+    slab_file = str(tmp_path / "gallery.slab")
+    r_lazy = classif_finetune_test.main(str(root), "resnet50", "", 0, False, 4, 0, save_slab=slab_file)
+    monkeypatch.setenv("ISX_LAZY_INGEST", "0")
+    r_eager = classif_finetune_test.main(str(root), "resnet50", "", 0, False, 4, 0)
+    monkeypatch.delenv("ISX_LAZY_INGEST")
+    decoded = []
+    monkeypatch.setattr(TC.LazyImage, "get", lambda self: decoded.append(self.path) or (_ for _ in ()).throw(AssertionError("gallery image decoded")))
+    r_slab = classif_finetune_test.main(str(root), "resnet50", "", 0, False, 4, 0, gallery_slab=slab_file)
+    out = capsys.readouterr().out
+    assert lazy_flags == [True, False, True] and not decoded
+    assert "descriptors written to" in out and "descriptors read from" in out
+    (q1, g1, s1), (q2, g2, s2), (q3, g3, s3) = seen
+    assert g1.shape == (36, 2048) and torch.equal(g1, g2) and torch.equal(q1, q2)          # lazy pipeline == decode-first, bit for bit
+    assert torch.equal(g3, g1) and torch.equal(q3, q1) and s3 == s1                          # the slab round trip
+    assert r_lazy == r_eager == r_slab
+    # a sharded gallery straight from the file: same canonical top-k as the tensor in memory
+    sg = retrieval.ShardedGallery.from_slab(slab_file, "cuda:0")
+    ts, ti = sg.local_search(q1, 5)
+    ws_, wi_ = ops.cosine_topk(q1, g1, 5)
+    assert torch.equal(ti, wi_) and torch.equal(ts, ws_)
+
+
 def test_bench_multi_rank_code_path_on_one_gpu():
     """`python bench.py --gpus 2` from a BARE command line (no torchrun around it): the parent starts the two ranks itself
     before touching the GPU.  Two ranks share cuda:0 over gloo here (ISX_BENCH_ONE_DEVICE=1): query all-gather, per-shard

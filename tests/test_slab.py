@@ -1,4 +1,6 @@
 """Descriptor-slab file format (isx/slab.py): round trip, row ranges (= gallery shards), errors."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -47,3 +49,24 @@ def test_gpu_load_streams_through_pinned_staging(tmp_path):
     slab.save_slab(p, E, torch.arange(70000, dtype=torch.int32))
     e, l = slab.load_slab(p, device="cuda", rows=(100, 69000))
     assert e.is_cuda and torch.equal(e.cpu(), E[100:69000]) and torch.equal(l.cpu(), torch.arange(100, 69000, dtype=torch.int32))
+
+
+def test_slab_writer_streams_row_blocks(tmp_path):
+    """SlabWriter: header first, row blocks appended from tensors / arrays, labels at close; a short or long stream is refused and leaves no file."""
+    from isx import slab
+    d = torch.randn(300, 24)
+    p = str(tmp_path / "s.slab")
+    w = slab.SlabWriter(p, 300, 24, has_labels=True)
+    w.append(d[:100]); w.append(d[100:120].numpy()); w.append(d[120:])
+    w.close(torch.arange(300, dtype=torch.int32))
+    got, lab = slab.load_slab(p)
+    assert torch.equal(got, d) and torch.equal(lab, torch.arange(300, dtype=torch.int32))
+    w = slab.SlabWriter(str(tmp_path / "t.slab"), 10, 24)
+    w.append(d[:4])
+    with pytest.raises(ValueError):
+        w.close()
+    assert not os.path.exists(str(tmp_path / "t.slab")) and not os.path.exists(str(tmp_path / "t.slab.tmp"))
+    ref = [(None, "l%d" % (i % 3), "p%d" % i) for i in range(300)]
+    slab.save_gallery(p, d, ref, ["l0", "l1", "l2"])
+    g, rs, names = slab.load_gallery(p, rows=(10, 20))
+    assert torch.equal(g, d[10:20]) and rs[0] == (None, "l1", "p10") and names == ["l0", "l1", "l2"]
