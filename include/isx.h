@@ -404,15 +404,21 @@ size_t isx_head_linear_rows_workspace(int64_t M, int64_t K, int N);
 int isx_head_linear_fwd_rows(const float* x, int64_t M, int64_t K, const float* w, int N, const float* bias, float* y, float* ws,
                              size_t ws_bytes, isx_stream_t stream);
 
-/* The input gradient of the same Linear for all rows at once: dx[m][k] = sum_n dy[m][n] w[n][k], one k-ordered chain over n per
- * output whatever M.  dyT: (N, Mp) = dy TRANSPOSED, zero-padded to Mp (a multiple of 64); w: (N, K); dx: (Mp, K).  K % 64 == 0. */
+/* The input gradient of the same Linear for all rows at once: dx[m][k] = sum_n dy[m][n] w[n][k] whatever M, summed in two levels: the N output
+ * features form isx_head_groups(N) consecutive groups (8, or 1 when N % 256 != 0), one k-ordered chain per group, the group sums added in group
+ * order.  dyT: (N, Mp) = dy TRANSPOSED, zero-padded to Mp (a multiple of 64); w: (N, K); dx: (Mp, K).  K % 64 == 0.
+ * isx_head_linear_dgrad_parts: the chains of `groups` groups of Ng features, not added -- parts (groups, Mp, K) -- for a head sharded by output
+ * features across data-parallel ranks (isx/shard_head.py): adding all groups' parts in group order gives isx_head_linear_dgrad's bits. */
+int isx_head_groups(int64_t N);
 int isx_head_linear_dgrad(const float* dyT, int64_t Mp, int N, const float* w, int64_t K, float* dx, isx_stream_t stream);
+int isx_head_linear_dgrad_parts(const float* dyT, int64_t Mp, int Ng, int groups, const float* w, int64_t K, float* parts,
+                                isx_stream_t stream);
 
 /* The weight gradient of the same Linear over the R rows of a whole mini-batch AND torch.optim.SGD's update of the weight, as ONE
  * kernel (reference: the optimizer of train/siamese_descriptor.py:136-139 stepped from utils/train_general.py:53 on the 822 MB weight of
  * model/siamese.py:104-114): g[n][k] = sum_r dy[r][n] x[r][k] (one fp32 fma chain over the rows in row order), then per element
  *   g += weight_decay * w;  buf = first ? g : momentum * buf + (1 - dampening) * g;  w -= lr * (nesterov ? g + momentum * buf : buf)
- * dy: (R, N), x: (R, K), w / mom: (N, K) updated in place (mom NULL when momentum == 0).  N % 128 == 0, K % 128 == 0.  No dW tensor:
+ * dy: (R, N), x: (R, K), w / mom: (N, K) updated in place (mom NULL when momentum == 0).  N % 64 == 0, K % 128 == 0.  No dW tensor:
  * 4 passes over the weight's size per step instead of 7. */
 int isx_head_sgd_step(const float* dy, const float* x, int64_t R, int N, int64_t K, float* w, float* mom, int first, float lr,
                       float momentum, float dampening, float weight_decay, int nesterov, isx_stream_t stream);

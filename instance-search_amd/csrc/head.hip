@@ -142,9 +142,11 @@ __global__ __launch_bounds__(256) void head_reduce_kernel(const float* __restric
 // Tile 128 x 128 of the (N, K) weight per workgroup, R reduced in k-tiles of 32 rows (a tail of rows is zero-filled: fma(0, 0, acc) = acc).
 struct SgdParams { float lr, momentum, dampening, weight_decay; int nesterov, first, use_momentum; };
 
+// TM: 128 (2) or 64 (1) rows of the weight per tile -- a shard of a sharded head can be as narrow as 64 output features; the tile only groups outputs
+template <int TM>
 __global__ __launch_bounds__(256) void head_sgd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t R, int N, int64_t K,
                                                        float* __restrict__ w, float* __restrict__ mom, SgdParams sp, int tiles_k) {
-    constexpr int TM = 2, TN = 2, BK = 32, BM = 128, BN = 128, LDA = BM + 4, LDB = BN + 4;
+    constexpr int TN = 2, BK = 32, BM = 64 * TM, BN = 128, LDA = BM + 4, LDB = BN + 4;
     constexpr int CA = BM / 4, CB = BN / 4, NA = BK * CA / 256, NB = BK * CB / 256;
     __shared__ float lds[BK * (LDA + LDB)];
     float* As = lds;
@@ -326,49 +328,77 @@ ISX_API int isx_head_linear_fwd_rows(const float* x, int64_t M, int64_t K, const
     return ISX_OK;
 }
 
-// dx = dy . w for M rows at once (the input gradient of y = x . w^T): dx[m][k] = sum_n dy[m][n] * w[n][k], one k-ordered fp32 chain over n per
-// output -- no split, whatever M.  dyT: (N, Mp) = dy TRANSPOSED, zero-padded to Mp (a multiple of 64); w: (N, K); dx: (Mp, K) (rows >= M: padding).
-// K % 64 == 0.  Both operands are K-major for this contraction (rows indexed by n), so the tiles go to LDS as they lie (wgrad_gemm_kernel).
+// dx = dy . w for M rows at once (the input gradient of y = x . w^T): dx[m][k] = sum_n dy[m][n] * w[n][k].  Canonical summation (round 5): the N
+// output features are cut into isx_head_groups(N) = 8 consecutive GROUPS (1 when N is not a multiple of 256); per group one k-ordered fp32 chain over
+// its n, the group sums added in group order into a second accumulator -- whatever M.  A data-parallel run shards the head by output features:
+// rank r holds the groups [r G / P, (r + 1) G / P) of w, computes THEIR chains for all rows (isx_head_linear_dgrad_parts) and the owner of a row adds
+// the G pieces in group order: the same bits as this call on one GPU.  dyT: (N, Mp) = dy TRANSPOSED, zero-padded to Mp (a multiple of 64); w: (N, K);
+// dx: (Mp, K) (rows >= M: padding).  K % 64 == 0.  Both operands are K-major for this contraction (rows indexed by n): tiles go to LDS as they lie.
+static int head_groups(int64_t N) { return N % 256 == 0 ? 8 : 1; }
+ISX_API int isx_head_groups(int64_t N) { return N > 0 ? head_groups(N) : 0; }
+
+template <bool FOLD>
+static void launch_head_dgrad(const float* dyT, int64_t Mp, int64_t Nrows, const float* w, int64_t K, float* out, int splits, int kt_per, int fold_kt, hipStream_t st) {
+    WgradGeom g;
+    g.ident = 1; g.H = g.W = g.Ho = g.Wo = 1; g.stride = 1;
+    if (Mp == 192)            // all rows in ONE 192 x 64 tile: the weight is read once
+        hipLaunchKernelGGL((wgrad_gemm_kernel<3, 1, FOLD>), dim3((unsigned)(K / 64), 1, (unsigned)splits), dim3(256), 0, st, dyT, Nrows, (int)Mp, w, (int)K, g, 1, out, K,
+                           (int)(K / 64), kt_per, splits, (float*)nullptr, fold_kt);
+    else if (Mp % 128 == 0 && K % 128 == 0)
+        hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2, FOLD>), dim3((unsigned)((Mp / 128) * (K / 128)), 1, (unsigned)splits), dim3(256), 0, st, dyT, Nrows, (int)Mp, w, (int)K,
+                           g, 1, out, K, (int)(K / 128), kt_per, splits, (float*)nullptr, fold_kt);
+    else
+        hipLaunchKernelGGL((wgrad_gemm_kernel<1, 1, FOLD>), dim3((unsigned)((Mp / 64) * (K / 64)), 1, (unsigned)splits), dim3(256), 0, st, dyT, Nrows, (int)Mp, w, (int)K, g,
+                           1, out, K, (int)(K / 64), kt_per, splits, (float*)nullptr, fold_kt);
+}
+
 ISX_API int isx_head_linear_dgrad(const float* dyT, int64_t Mp, int N, const float* w, int64_t K, float* dx, isx_stream_t stream) {
     ISX_REQUIRE(Mp >= 0 && Mp % 64 == 0 && Mp < (1 << 24) && N > 0 && K > 0 && K % 64 == 0 && K < (1ll << 31),
                 "isx_head_linear_dgrad: bad shape Mp=%lld N=%d K=%lld (Mp %% 64 == 0, K %% 64 == 0)", (long long)Mp, N, (long long)K);
     if (Mp == 0) return ISX_OK;
     ISX_REQUIRE(dyT && w && dx, "isx_head_linear_dgrad: null pointer");
     ISX_REQUIRE((((uintptr_t)dyT | (uintptr_t)w | (uintptr_t)dx) % 16) == 0, "isx_head_linear_dgrad: pointers must be 16-B aligned");
-    WgradGeom g;
-    g.ident = 1; g.H = g.W = g.Ho = g.Wo = 1; g.stride = 1;
-    const int nk = (N + 31) / 32;
-    hipStream_t st = (hipStream_t)stream;
-    if (Mp == 192)            // all rows in ONE 192 x 64 tile: the weight is read once
-        hipLaunchKernelGGL((wgrad_gemm_kernel<3, 1>), dim3((unsigned)(K / 64), 1, 1), dim3(256), 0, st, dyT, (int64_t)N, (int)Mp, w, (int)K, g, 1, dx, K,
-                           (int)(K / 64), nk, 1, (float*)nullptr);
-    else if (Mp % 128 == 0 && K % 128 == 0)
-        hipLaunchKernelGGL((wgrad_gemm_kernel<2, 2>), dim3((unsigned)((Mp / 128) * (K / 128)), 1, 1), dim3(256), 0, st, dyT, (int64_t)N, (int)Mp, w, (int)K, g, 1, dx, K,
-                           (int)(K / 128), nk, 1, (float*)nullptr);
-    else
-        hipLaunchKernelGGL((wgrad_gemm_kernel<1, 1>), dim3((unsigned)((Mp / 64) * (K / 64)), 1, 1), dim3(256), 0, st, dyT, (int64_t)N, (int)Mp, w, (int)K, g, 1, dx, K,
-                           (int)(K / 64), nk, 1, (float*)nullptr);
+    const int nk = (N + 31) / 32, G = head_groups(N);
+    if (G > 1) launch_head_dgrad<true>(dyT, Mp, N, w, K, dx, 1, nk, nk / G, (hipStream_t)stream);
+    else launch_head_dgrad<false>(dyT, Mp, N, w, K, dx, 1, nk, 0, (hipStream_t)stream);
     ISX_CHECK_LAUNCH("isx_head_linear_dgrad");
+    return ISX_OK;
+}
+
+// The chains of `groups` consecutive groups of Ng output features each, NOT added: parts[g][m][k] = sum over the n of group g of dy[m][n] * w[n][k].
+// dyT: (groups * Ng, Mp) = this rank's rows of dy^T, w: (groups * Ng, K) = its rows of the weight, parts: (groups, Mp, K).  Ng % 32 == 0, K % 64 == 0.
+// Adding the parts of ALL groups in group order gives isx_head_linear_dgrad's result bit for bit.
+ISX_API int isx_head_linear_dgrad_parts(const float* dyT, int64_t Mp, int Ng, int groups, const float* w, int64_t K, float* parts, isx_stream_t stream) {
+    ISX_REQUIRE(Mp >= 0 && Mp % 64 == 0 && Mp < (1 << 24) && Ng > 0 && Ng % 32 == 0 && groups >= 1 && groups <= 65535 && K > 0 && K % 64 == 0 && K < (1ll << 31),
+                "isx_head_linear_dgrad_parts: bad shape Mp=%lld Ng=%d groups=%d K=%lld (Mp %% 64 == 0, Ng %% 32 == 0, K %% 64 == 0)", (long long)Mp, Ng, groups, (long long)K);
+    if (Mp == 0) return ISX_OK;
+    ISX_REQUIRE(dyT && w && parts, "isx_head_linear_dgrad_parts: null pointer");
+    ISX_REQUIRE((((uintptr_t)dyT | (uintptr_t)w | (uintptr_t)parts) % 16) == 0, "isx_head_linear_dgrad_parts: pointers must be 16-B aligned");
+    // split s of the TN kernel owns the k-tiles [s * kt_per, (s + 1) * kt_per) of the reduction and writes its own (Mp, K) partial
+    launch_head_dgrad<false>(dyT, Mp, (int64_t)groups * Ng, w, K, parts, groups, Ng / 32, 0, (hipStream_t)stream);
+    ISX_CHECK_LAUNCH("isx_head_linear_dgrad_parts");
     return ISX_OK;
 }
 
 // Weight gradient of y = x . w^T over R rows and torch.optim.SGD's update of w, fused (see head_sgd_kernel): dy: (R, N), x: (R, K), w: (N, K) updated
 // in place, mom: (N, K) momentum buffer updated in place (NULL when momentum == 0); first != 0: the buffer is (re)initialised with the gradient, as
-// torch does on the first step.  N % 128 == 0, K % 128 == 0, 16-B aligned pointers.  (Reference: the optimizer step of utils/train_general.py:53
+// torch does on the first step.  N % 64 == 0, K % 128 == 0, 16-B aligned pointers.  (w, mom, dy may be the rows / columns of ONE shard of the layer.)  (Reference: the optimizer step of utils/train_general.py:53
 // on the Linear of model/siamese.py:104-114.)
 ISX_API int isx_head_sgd_step(const float* dy, const float* x, int64_t R, int N, int64_t K, float* w, float* mom, int first, float lr, float momentum,
                               float dampening, float weight_decay, int nesterov, isx_stream_t stream) {
-    ISX_REQUIRE(R >= 0 && N > 0 && N % 128 == 0 && K > 0 && K % 128 == 0 && (int64_t)128 * K * 4 < (1ll << 31),
-                "isx_head_sgd_step: bad shape R=%lld N=%d K=%lld (N %% 128 == 0, K %% 128 == 0, 128 rows of w below 2 GiB)", (long long)R, N, (long long)K);
+    ISX_REQUIRE(R >= 0 && N > 0 && N % 64 == 0 && K > 0 && K % 128 == 0 && (int64_t)128 * K * 4 < (1ll << 31),
+                "isx_head_sgd_step: bad shape R=%lld N=%d K=%lld (N %% 64 == 0, K %% 128 == 0, 128 rows of w below 2 GiB)", (long long)R, N, (long long)K);
     ISX_REQUIRE(w && (R == 0 || (dy && x)) && (momentum == 0.0f || mom), "isx_head_sgd_step: null pointer");
     ISX_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)w | (uintptr_t)mom) % 16) == 0, "isx_head_sgd_step: pointers must be 16-B aligned");
     ISX_REQUIRE(!(nesterov && (momentum <= 0.0f || dampening != 0.0f)), "isx_head_sgd_step: Nesterov momentum requires a momentum and zero dampening");
-    const int64_t tiles = (int64_t)(N / 128) * (K / 128);
+    const int bm = N % 128 == 0 ? 128 : 64;
+    const int64_t tiles = (int64_t)(N / bm) * (K / 128);
     ISX_REQUIRE(tiles < (1ll << 31), "isx_head_sgd_step: too many tiles");
     SgdParams sp;
     sp.lr = lr; sp.momentum = momentum; sp.dampening = dampening; sp.weight_decay = weight_decay;
     sp.nesterov = nesterov ? 1 : 0; sp.first = first ? 1 : 0; sp.use_momentum = momentum != 0.0f ? 1 : 0;
-    hipLaunchKernelGGL(head_sgd_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, dy, x, R, N, K, w, mom, sp, (int)(K / 128));
+    if (bm == 128) hipLaunchKernelGGL(head_sgd_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, dy, x, R, N, K, w, mom, sp, (int)(K / 128));
+    else hipLaunchKernelGGL(head_sgd_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, dy, x, R, N, K, w, mom, sp, (int)(K / 128));
     ISX_CHECK_LAUNCH("isx_head_sgd_step");
     return ISX_OK;
 }

@@ -24,10 +24,13 @@ __device__ __forceinline__ int64_t wgrad_src_row(const WgradGeom& g, int64_t p, 
 // (the consumer, bn_fold_backward_kernel, adds the partials in split order: a fixed summation tree, no atomics).  The blocks of
 // (tile_n = 0, tap = 0) also produce the partial COLUMN SUMS of A (the bias gradient) from the A tiles they stage anyway.
 // N1 % (64 TM) == 0, N2 % (64 TN) == 0.
-template <int TM, int TN>
+// FOLD > 0 (the descriptor head's input gradient, head.hip): the reduction is summed in two levels -- a chain per FOLD k-tiles, the chains added in
+// order into a second accumulator (gemm_tile.hpp) -- so that a run whose reduction is SHARDED across ranks (every rank a few of the chains,
+// isx_head_linear_dgrad_parts) lands on the same bits.  fold_kt: k-tiles per chain.
+template <int TM, int TN, bool FOLD = false>
 __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict__ A, int64_t K, int N1, const float* __restrict__ Bm, int N2,
                                                          WgradGeom g, int taps, float* __restrict__ C, int64_t ldc, int tiles_n, int kt_per,
-                                                         int splits, float* __restrict__ colsum) {
+                                                         int splits, float* __restrict__ colsum, int fold_kt = 0) {
     constexpr int BK = 32, BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + 4;       // +4: rows stay 16-B aligned for the float4 stores
     constexpr int CA = BM / 4, CB = BN / 4, NA = BK * CA / 256, NB = BK * CB / 256;
     __shared__ float lds[BK * (LDA + LDB)];
@@ -87,12 +90,34 @@ __global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict
     const int64_t kt0 = (int64_t)sub * kt_per;
     const int64_t kt1 = kt0 + kt_per < nk_all ? kt0 + kt_per : nk_all;
     float csum = 0.0f;
+    f32x16 tot[FOLD ? TM : 1][FOLD ? TN : 1];
+    if constexpr (FOLD) zero_tiles(tot);
     if (kt0 < kt1) {
         load(kt0 * BK);
         store();
         __syncthreads();
         const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
         const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+        if constexpr (FOLD) {
+            for (int64_t kt = kt0; kt < kt1;) {
+                const int64_t kend = kt + fold_kt < kt1 ? kt + fold_kt : kt1;
+                for (; kt < kend; ++kt) {
+                    const bool more = kt + 1 < kt1;
+                    if (more) load((kt + 1) * BK);
+                    mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
+                    __syncthreads();
+                    if (more) {
+                        store();
+                        __syncthreads();
+                    }
+                }
+                fold_chunk<TM, TN>(tot, acc);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];
+        } else
         for (int64_t kt = kt0; kt < kt1; ++kt) {
             const bool more = kt + 1 < kt1;
             if (more) load((kt + 1) * BK);

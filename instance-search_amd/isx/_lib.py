@@ -74,6 +74,8 @@ _SIGNATURES = {
     "isx_head_linear_dgrad": (C.c_int, [VP, I64, I32, VP, I64, VP, VP]),
     "isx_head_linear_rows_workspace": (SZ, [I64, I64, I32]),
     "isx_head_linear_fwd_rows": (C.c_int, [VP, I64, I64, VP, I32, VP, VP, VP, SZ, VP]),
+    "isx_head_groups": (C.c_int, [I64]),
+    "isx_head_linear_dgrad_parts": (C.c_int, [VP, I64, I32, I32, VP, I64, VP, VP]),
     "isx_head_sgd_step": (C.c_int, [VP, VP, I64, I32, I64, VP, VP, I32, F32, F32, F32, F32, I32, VP]),
     "isx_colsum_leaves": (C.c_int, [VP, I32, I32, I64, VP, VP]),
     "isx_comm_unique_id_bytes": (C.c_int, []),

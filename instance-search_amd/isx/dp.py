@@ -240,9 +240,13 @@ class RowSink(object):
     """Collects the (x, dy) rows `RowDeferredLinear` produces during the backward passes of ONE optimizer step, in the order they are
     produced (micro-batch order), and turns them into the weight gradients at the end of the step."""
 
-    def __init__(self, weights, group=None, optimizer=None):
+    def __init__(self, weights, group=None, optimizer=None, shards=None):
         """optimizer: the step's torch.optim.SGD, or None.  With it, a deferred weight that libisx can handle is UPDATED by the kernel that forms
-        its gradient (isx_head_sgd_step: no gradient tensor, `weight.grad` stays None and the optimizer's own step skips the weight)."""
+        its gradient (isx_head_sgd_step: no gradient tensor, `weight.grad` stays None and the optimizer's own step skips the weight).
+        shards: {id(weight): isx.shard_head.HeadShard} -- weights sharded by output features across the ranks this step (their rows never come
+        here: the shard exchanges them itself); leaf_ids: the global micro-batch indices of the rows about to go through a sharded head."""
+        self.shards = dict(shards or {})
+        self.leaf_ids = []
         self.weights = list(weights)
         self.ids = dict((id(w), k) for k, w in enumerate(self.weights))
         self.group = group
@@ -252,6 +256,9 @@ class RowSink(object):
 
     def accepts(self, weight):
         return id(weight) in self.ids
+
+    def shard_for(self, weight):
+        return self.shards.get(id(weight))
 
     def add(self, weight, x, dy):
         k = self.ids[id(weight)]
@@ -294,8 +301,12 @@ class RowSink(object):
         """dW = dY^T X over the rows of the whole mini-batch (every rank's, rank order) -> weight.grad, for every deferred weight."""
         STATS.pop("rows_all_gather_bytes_received", None)
         STATS["row_deferred_weight_bytes"] = sum(4 * w.numel() for w in self.weights)      # what an all-reduce of these gradients would move (x 2 (P-1)/P)
+        for sh in self.shards.values():
+            sh.finish(self.optimizer)
         with torch.no_grad():
             for k, w in enumerate(self.weights):
+                if id(w) in self.shards:
+                    continue
                 if self.x[k]:
                     x, dy = torch.cat(self.x[k], 0), torch.cat(self.dy[k], 0)
                 else:
@@ -317,7 +328,7 @@ def fused_sgd_from_rows(optimizer, w, dy, x):
     state_dict / a re-created optimizer (annealing) behaves as with torch's step.  Returns False -- nothing done -- when the case is not the
     kernel's (CPU tensors, widths that are not multiples of 128, an optimizer that is not a plain SGD, maximize / differentiable)."""
     if not (type(optimizer) is torch.optim.SGD and w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
-            and w.size(0) % 128 == 0 and w.size(1) % 128 == 0 and 128 * w.size(1) * 4 < 2 ** 31 and x.dtype == torch.float32 and dy.dtype == torch.float32):
+            and w.size(0) % 64 == 0 and w.size(1) % 128 == 0 and 128 * w.size(1) * 4 < 2 ** 31 and x.dtype == torch.float32 and dy.dtype == torch.float32):
         return False
     group = next((g for g in optimizer.param_groups if any(p is w for p in g['params'])), None)
     if group is None or group.get('maximize') or group.get('differentiable'):
@@ -336,11 +347,17 @@ def fused_sgd_from_rows(optimizer, w, dy, x):
                                   float(lr), mom, float(group['dampening']), float(group['weight_decay']), 1 if group['nesterov'] else 0,
                                   torch.cuda.current_stream().cuda_stream), "isx_head_sgd_step")
     w.grad = None                    # the optimizer's step skips a parameter without a gradient
-    try:                             # the kernel wrote w behind autograd's back: move its version counter as an in-place op would (caches keyed on it)
-        torch._C._autograd._unsafe_set_version_counter([w], [w._version + 1])
+    bump_version(w)
+    return True
+
+
+def bump_version(t):
+    """A libisx kernel (or a write through .data) changed `t` behind autograd's back: move its version counter as an in-place op would, for the
+    caches keyed on it (model/nn_utils._derived, RegionDescriptorNet._hwc_head)."""
+    try:
+        torch._C._autograd._unsafe_set_version_counter([t], [t._version + 1])
     except (AttributeError, TypeError):
         pass
-    return True
 
 
 def weight_gradient_from_rows(dy, x):

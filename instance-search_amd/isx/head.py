@@ -45,8 +45,10 @@ class HeadEngine(object):
         return (lin.weight.is_cuda and lin.weight.dtype == torch.float32 and lin.weight.is_contiguous() and lin.in_features % 64 == 0
                 and lin.out_features % 64 == 0 and h[1].param.numel() == lin.in_features)
 
-    def forward(self, f_all):
-        """f_all: (M, C, h, w) trunk output of all local rows (no graph).  Returns (descriptors (M, D), context for backward)."""
+    def forward(self, f_all, shard=None, leaf_ids=None):
+        """f_all: (M, C, h, w) trunk output of all local rows (no graph).  Returns (descriptors (M, D), context for backward).
+        shard / leaf_ids: the Linear is sharded by output features across the ranks this step (isx/shard_head.HeadShard) -- the rows of every
+        rank go through this rank's slice of the weight, the column slices are exchanged."""
         M = f_all.size(0)
         lin = self.lin
         x0 = f_all.reshape(M, -1)                                   # logical (C, h, w) order whatever the memory format
@@ -54,15 +56,20 @@ class HeadEngine(object):
             x0 = x0.contiguous()
         x1 = ops.l2norm_shift_rows(x0, self.shift.param.detach())
         b = lin.bias
-        y = ops.head_linear(x1, lin.weight.detach(), b.detach() if b is not None else None)      # rows as stored: no transposed copy
+        sctx = None
+        if shard is not None:
+            y, sctx = shard.forward(x1, leaf_ids)
+            y = y.contiguous()
+        else:
+            y = ops.head_linear(x1, lin.weight.detach(), b.detach() if b is not None else None)      # rows as stored: no transposed copy
         d = ops.l2norm_rows(y)
-        return d, (x0, x1, y, tuple(f_all.shape))
+        return d, (x0, x1, y, tuple(f_all.shape), shard, sctx)
 
     def backward(self, ctx, dd, leaves, sink, flat_all, slices):
         """dd: (M, D) gradient wrt the descriptors; `leaves` consecutive micro-batches of equal row count.  The small parameters' gradients
         go to row l of flat_all (per-leaf flat gradient buffers) at the parameters' slices, the Linear's (x, dy) rows to `sink`.
         Returns the gradient wrt the trunk output, shaped (M, C, h, w)."""
-        x0, x1, y, shape = ctx
+        x0, x1, y, shape, shard, sctx = ctx
         M, K = x1.shape
         lin = self.lin
         N = lin.out_features
@@ -70,7 +77,7 @@ class HeadEngine(object):
         if R * leaves != M:
             raise _lib.IsxError("head engine: %d rows are not %d equal micro-batches" % (M, leaves))
         dy = ops.l2norm_rows_bwd(y, dd.contiguous())
-        if lin.weight.requires_grad:
+        if lin.weight.requires_grad and shard is None:
             if sink is None or not sink.accepts(lin.weight):
                 raise _lib.IsxError("head engine: the Linear weight needs the training step's RowSink")
             sink.add(lin.weight, x1, dy)
@@ -79,15 +86,18 @@ class HeadEngine(object):
             check(lib().isx_colsum_leaves(dy.data_ptr(), leaves, R, N, gb.data_ptr(), _stream()), "isx_colsum_leaves")
             lo, hi = slices[lin.bias]
             flat_all[:, lo:hi].copy_(gb)
-        Mp = (M + 63) // 64 * 64
-        if Mp == M:
-            dyT = dy.t().contiguous()
+        if shard is not None:
+            dx1 = shard.backward(sctx, dy).contiguous()        # every rank's chains of its feature groups, this rank's rows summed in group order
         else:
-            dyT = dy.new_zeros((N, Mp))
-            dyT[:, :M] = dy.t()
-        dx1 = torch.empty((Mp, K), dtype=torch.float32, device=dy.device)
-        check(lib().isx_head_linear_dgrad(dyT.data_ptr(), Mp, N, lin.weight.data_ptr(), K, dx1.data_ptr(), _stream()), "isx_head_linear_dgrad")
-        dx1 = dx1[:M]
+            Mp = (M + 63) // 64 * 64
+            if Mp == M:
+                dyT = dy.t().contiguous()
+            else:
+                dyT = dy.new_zeros((N, Mp))
+                dyT[:, :M] = dy.t()
+            dx1 = torch.empty((Mp, K), dtype=torch.float32, device=dy.device)
+            check(lib().isx_head_linear_dgrad(dyT.data_ptr(), Mp, N, lin.weight.data_ptr(), K, dx1.data_ptr(), _stream()), "isx_head_linear_dgrad")
+            dx1 = dx1[:M]
         if self.shift.param.requires_grad:
             gs = torch.empty((leaves, K), dtype=torch.float32, device=dy.device)
             check(lib().isx_colsum_leaves(dx1.data_ptr(), leaves, R, K, gs.data_ptr(), _stream()), "isx_colsum_leaves")

@@ -103,24 +103,35 @@ class _RowDeferredLinearFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
+        from isx import dp
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        sink = dp.current_sink()
+        ctx.shard = sink.shard_for(weight) if sink is not None and x.dim() == 2 else None
+        if ctx.shard is not None:
+            # the layer is sharded by output features across the ranks this step (isx/shard_head.py): rows and column slices are exchanged inside
+            y, ctx.shard_ctx = ctx.shard.forward(x, sink.leaf_ids)
+            return y
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, dy):
         from isx import dp
         x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = dy.mm(weight) if ctx.needs_input_grad[0] else None
+        if ctx.shard is not None:
+            dy = dy.contiguous()
+            dx = ctx.shard.backward(ctx.shard_ctx, dy)      # also records this pass's rows for the shard's weight update
+            return dx, None, (dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None)
+        x2, dy2 = x.reshape(-1, x.size(-1)), dy.reshape(-1, dy.size(-1)).contiguous()      # any leading dimensions, as nn.Linear
+        dx = dy2.mm(weight).view_as(x) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[1]:
             sink = dp.current_sink()
             if sink is not None and sink.accepts(weight):
-                sink.add(weight, x, dy)                    # dW = dY^T X is formed ONCE per optimizer step, over every micro-batch's (and rank's) rows
+                sink.add(weight, x2, dy2)                  # dW = dY^T X is formed ONCE per optimizer step, over every micro-batch's (and rank's) rows
             else:
-                dw = dp.weight_gradient_from_rows(dy, x)
-        db = dy.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+                dw = dp.weight_gradient_from_rows(dy2, x2)
+        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 

@@ -117,6 +117,21 @@ class _Stepper(object):
         else:
             self.flat = dp.GradAllReducer(rest)
             self.exchange = None
+        # The descriptor head sharded by output features (isx/shard_head.py): rank r forms and applies the update of ITS rows of the 822 MB weight
+        # only.  On the GPU the single process needs no shard object (its kernels already compute the canonical sums); on the CPU it does, so
+        # that 1, 2, 4, 8 processes issue the same (micro-batch, feature group) GEMMs.
+        self.shards = {}
+        if mode == 'tree' and getattr(P, 'train_head_shard', True):
+            from isx import shard_head
+            for m in net.modules():
+                if isinstance(m, RowDeferredLinear) and m.weight.requires_grad and shard_head.shardable(m.weight, self.world) \
+                        and (self.world > 1 or not m.weight.is_cuda):
+                    self.shards[id(m.weight)] = shard_head.HeadShard(m.weight, m.bias)
+
+    def sync_head(self):
+        """All ranks' rows of a sharded head to every rank (before anything reads the whole weight: embedding pass, evaluation, checkpoint)."""
+        for sh in self.shards.values():
+            sh.sync()
 
     # -- one micro-batch ---------------------------------------------------------------------------------------------------------
     def _forward_backward(self, triplets, offset, mini_size, batch_args, pre, arm=False):
@@ -189,7 +204,8 @@ class _Stepper(object):
         ph.__enter__()
         if head is not None:
             from model.siamese import _SplitRows
-            d_all, hctx = head.forward(y_all)
+            shard = sink.shard_for(head.lin.weight) if sink is not None else None
+            d_all, hctx = head.forward(y_all, shard=shard, leaf_ids=list(sink.leaf_ids) if shard is not None else None)
             dd = torch.empty_like(d_all)
             for j in range(L):
                 d = d_all[j * rows:(j + 1) * rows].detach().requires_grad_(True)
@@ -236,7 +252,16 @@ class _Stepper(object):
         self.flat.zero_grad()
         losses = []
         fuse = optimizer if getattr(P, 'train_fused_head_sgd', True) else None       # head weight: gradient + SGD update as one kernel (isx/dp.py)
-        with dp.RowSink(self.deferred, optimizer=fuse) as sink:
+        # sharded head this step?  decided from what EVERY rank knows (mini-batch size, micro-batch size, world): equal micro-batches, the same
+        # number on every rank (GPU) / a multiple of the 8 feature groups' rank counts (CPU: one rule for every world size, see __init__)
+        n_leaves = -(-n // mb)
+        shard_ok = bool(self.shards) and n % mb == 0 and self.mode == 'tree' and n_leaves % (self.world if next(iter(self.shards.values())).weight.is_cuda else 8) == 0
+        if self.shards and not shard_ok:
+            self.sync_head()                          # the replicated path below reads and updates the whole weight
+        with dp.RowSink(self.deferred, optimizer=(optimizer if shard_ok else fuse), shards=(self.shards if shard_ok else None)) as sink:
+            for sh in sink.shards.values():
+                sh.begin_step(len(mine))
+            sink.leaf_ids = list(range(lo, hi))
             eng = head = None
             batched = getattr(self.P, 'train_suffix_batched', True)
             if self.mode == 'tree' and pre is not None and len(set(len(l) for l in mine)) == 1 and batched:
@@ -254,6 +279,7 @@ class _Stepper(object):
                     self.exchange.allreduce_(self.flat.flat)
             elif self.mode == 'tree':
                 def leaf(i):
+                    sink.leaf_ids = [i]
                     losses.append(self._forward_backward(mine[i - lo], offsets[i - lo], n, batch_args, pre))
                     return self.flat.take()
                 self.flat.put(dp.tree_sum(lo, hi, leaf))
@@ -297,14 +323,19 @@ def train_gen(train_type, P, test_print, test_net, net, train_set, testset_tuple
             # identical couple order (and random fall-back negatives) on every rank -- and, with P.train_seed set, in a single process,
             # so that runs with 1, 2, 4, 8 ranks train on the same triplets (the reference leaves `random` unseeded)
             random.seed((getattr(P, 'train_seed', 0) or 0) + epoch)
+        stepper.sync_head()                     # the epoch's embedding pass reads the whole head
         dataset, batch_args = create_epoch(epoch, train_set, testset_tuple)
 
         def one(state, start, is_final, mini_batch):
             count, score, running = state
             loss = stepper.step(optimizer, mini_batch, batch_args)
+            t = P.train_test_int
+            if (t > 0 and count % t == t - 1) or (t <= 0 and is_final):
+                stepper.sync_head()             # output_stats evaluates the net now
             running, score = output_stats(train_type, P, test_print, test_net, net, testset_tuple, epoch, count, is_final, loss,
                                           running, score)
             return count + 1, score, running
 
         _, best_score, _ = fold_batches(one, (0, best_score, 0.0), dataset, P.train_batch_size, cut_end=True)
+    stepper.sync_head()
     return best_score

@@ -81,12 +81,12 @@ def test_pos_couples_and_shuffle():
 class _TinyNet(nn.Module):
     """Stands in for DescriptorNet in the loop tests: features + a descriptor head, 3 inputs in training."""
 
-    def __init__(self):
+    def __init__(self, head_out=8):
         super().__init__()
         from model.custom_modules import RowDeferredLinear
         self.features = nn.Sequential(nn.Conv2d(3, 4, 3, stride=2), nn.BatchNorm2d(4), nn.ReLU())
-        self.head = RowDeferredLinear(4 * 3 * 3, 8)          # as DescriptorNet's head: weight gradient from the step's (x, dy) rows
-        self.feature_size = 8
+        self.head = RowDeferredLinear(4 * 3 * 3, head_out)   # as DescriptorNet's head: weight gradient from the step's (x, dy) rows
+        self.feature_size = head_out
 
     def one(self, x):
         y = self.head(self.features(x).flatten(1))
@@ -96,7 +96,7 @@ class _TinyNet(nn.Module):
         return (self.one(a), self.one(p), self.one(n)) if self.training and n is not None else self.one(a)
 
 
-def _run_training(rank, world, port, out, train_bn=False, save_all=False, mode="tree", batch=8, micro=2):
+def _run_training(rank, world, port, out, train_bn=False, save_all=False, mode="tree", batch=8, micro=2, head_out=8, stats_out=None):
     sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
     torch.set_num_threads(1)                # same CPU kernels (and summation order) whatever the number of processes
     if world > 1:
@@ -108,11 +108,11 @@ def _run_training(rank, world, port, out, train_bn=False, save_all=False, mode="
     import torch.optim as optim
     torch.manual_seed(1000 * rank)          # replicas start from DIFFERENT weights: train_gen must broadcast rank 0's
     random.seed(0)
-    net = _TinyNet()
+    net = _TinyNet(head_out)
     P = sd.P
     P.cuda_device, P.train_epochs, P.train_batch_size, P.train_micro_batch = -1, 2, batch, micro
     P.train_grad_exchange = mode
-    P.train_loss_int, P.train_test_int, P.test_batch_size, P.feature_dim, P.train_seed = 1000, 1000, 8, 8, 5
+    P.train_loss_int, P.train_test_int, P.test_batch_size, P.feature_dim, P.train_seed = 1000, 1000, 8, head_out, 5
     P.train_epoch_switch, P.train_pre_proc, P.train_loss_avg = 1, True, False
     P.train_bn = bool(train_bn)
     g = torch.Generator().manual_seed(1)
@@ -138,6 +138,9 @@ def _run_training(rank, world, port, out, train_bn=False, save_all=False, mode="
             return real_train_gen(*a2, **k)
         sd.train_gen = seeded_train_gen
     sd.train_siam_triplets_pos_couples(net, ds, (ds[:4], ds), TripletLoss(P.triplet_margin, False), opt)
+    if stats_out and rank == 0:
+        from isx import dp as _dp
+        torch.save(dict(_dp.STATS), stats_out)
     if rank == 0 or save_all:
         torch.save({k: v.clone() for k, v in net.state_dict().items()}, out + (".%d" % rank if save_all else ""))
     if world > 1:
@@ -173,6 +176,34 @@ def test_data_parallel_training_is_bit_identical_to_single_process(tmp_path, wor
         assert set(a) == set(b)
         for k in a:
             assert torch.equal(a[k], b[k]), (r, k, float((a[k].float() - b[k].float()).abs().max()))
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_head_training_is_bit_identical_to_single_process(tmp_path, world):
+    """The descriptor head sharded by OUTPUT FEATURES across the ranks (isx/shard_head.py; reference model/siamese.py:104-114 is one replicated
+    822 MB weight): 8 micro-batches on 2 / 4 / 8 ranks, every rank computing its feature groups' slice of the head for the rows of ALL ranks,
+    forming and applying the update of ITS rows of the weight only, the input gradient assembled from the ranks' per-group chains in group
+    order -- and the whole state dict of every rank after 2 epochs of SGD with momentum is BIT FOR BIT the single process's.  The stale rows
+    of the other ranks are refreshed by the sync before each epoch's embedding pass and at the end; the exchange counters say the head moved
+    rows, not a weight gradient."""
+    single, dpf, stats = str(tmp_path / "single.pt"), str(tmp_path / "dp.pt"), str(tmp_path / "stats.pt")
+    mp.spawn(_run_training, args=(1, 0, single, False, False, "tree", 16, 2, 256), nprocs=1, join=True)
+    mp.spawn(_run_training, args=(world, _free_port(), dpf, False, True, "tree", 16, 2, 256, stats), nprocs=world, join=True)
+    a = torch.load(single)
+    assert _moved_from(a, 256) > 1e-3
+    for r in range(world):
+        b = torch.load(dpf + ".%d" % r)
+        assert set(a) == set(b)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (r, k, float((a[k].float() - b[k].float()).abs().max()))
+    st = torch.load(stats)
+    assert st.get("head_shard_bytes_received", 0) > 0 and "rows_all_gather_bytes_received" not in st
+
+
+def _moved_from(a, head_out):
+    torch.manual_seed(0)
+    init = _TinyNet(head_out).state_dict()
+    return sum(float((a[k].float() - init[k].float()).abs().sum()) for k in a)
 
 
 def test_data_parallel_allreduce_mode_matches_single_process(tmp_path):
@@ -427,7 +458,7 @@ def test_minibatch_trunk_precompute_is_bit_identical():
         for per_minibatch in (True, False):
             torch.manual_seed(0); random.seed(0)
             P = sd.P
-            P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), 32      # every convolution in libisx: batch-invariant bits
+            P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), feature_dim      # every convolution in libisx: batch-invariant bits
             P.train_epochs, P.train_batch_size, P.train_micro_batch, P.test_batch_size = 2, 12, 4, 16
             P.train_loss_int, P.untrained_blocks, P.train_epoch_switch, P.train_lr, P.train_pre_proc = 1000, -1, 1, 1e-2, True
             P.train_trunk_per_minibatch = per_minibatch
@@ -470,7 +501,7 @@ def test_untrained_blocks_follow_the_reference_table():
     assert first_trainable(frozen.features) == len(frozen.features)
 
 
-def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch, micro, mined, replay, batched=True):
+def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch, micro, mined, replay, batched=True, feature_dim=32):
     """One run of train.siamese_descriptor.main on the reference configuration (ResNet-50, untrained_blocks from the table).  `mined`:
     list receiving the mined negatives per epoch; `replay`: a previous run's list to use instead of mining."""
     import copy
@@ -490,7 +521,7 @@ def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch,
             it = iter(replay)
             sd.mine_epoch_negatives = lambda *a, **k: next(it)
         P = sd.P
-        P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), 32
+        P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), feature_dim
         P.train_epochs, P.train_batch_size, P.train_micro_batch, P.test_batch_size = epochs, batch, micro, 16
         P.train_loss_int, P.train_epoch_switch, P.train_lr, P.train_pre_proc = 1000, 1, 1e-3, True
         P.untrained_blocks = None                                  # the reference's table: 15 for ResNet-50
@@ -593,32 +624,39 @@ def test_batched_suffix_is_bit_identical_to_leaf_by_leaf():
     assert moved > 0
 
 
-def _train_reference_two_ranks_one_gpu(rank, world, port, out, batch=16, micro=4):
+def _train_reference_two_ranks_one_gpu(rank, world, port, out, batch=16, micro=4, feature_dim=32):
     """worker of test_ranks_on_one_gpu_match_single_process: rank `rank` of `world`, every rank on cuda:0, gloo process group"""
     sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    _, state = _train_reference_config(True, True, 2, 32, batch, micro, [], None)
+    _, state = _train_reference_config(True, True, 2, 32, batch, micro, [], None, feature_dim=feature_dim)
     if rank == 0:
+        from isx import dp as _dp
         torch.save({k: v.cpu() for k, v in state.items()}, out)
+        torch.save(dict(_dp.STATS), out + ".stats")
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,batch,micro", [(2, 16, 4), (4, 64, 8)])
-def test_ranks_on_one_gpu_match_single_process(tmp_path, world, batch, micro):
+@pytest.mark.parametrize("world,batch,micro,feature_dim", [(2, 16, 4, 32), (4, 64, 8, 32), (4, 64, 8, 256)])
+def test_ranks_on_one_gpu_match_single_process(tmp_path, world, batch, micro, feature_dim):
     """Data-parallel training of the REAL net with the REAL kernels: DescriptorNet(ResNet-50) on the reference configuration, `world` ranks
     (all on cuda:0, gloo -- the box has one GPU; RCCL replaces only the transport) x their subtree of the micro-batches of every step, HIP
     prefix + batched suffix engine + head engine + row-deferred head gradient + TreeExchange, against ONE process with all micro-batches: the
     whole state dict BIT-IDENTICAL after two epochs (mining included: no replay).  (4, 64, 8) is the reference's step -- 64 triplets as 8
-    micro-batches of 8: one process runs 192 rows per pass (192-row tiles in the head GEMMs), each of the 4 ranks 48 (64-row tiles)."""
+    micro-batches of 8: one process runs 192 rows per pass (192-row tiles in the head GEMMs), each of the 4 ranks 48 (64-row tiles).
+    feature_dim 256: a head wide enough for the 8 feature groups -- the ranks run it SHARDED by output features (isx/shard_head.py: each rank its
+    64 features' slice of the forward for all rows, its rows of the fused gradient + SGD kernel, its groups' chains of the input gradient), the
+    single process the plain kernels: the same bits."""
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_train_reference_two_ranks_one_gpu, args=(world, _free_port(), out, batch, micro), nprocs=world, join=True)
+    mp.spawn(_train_reference_two_ranks_one_gpu, args=(world, _free_port(), out, batch, micro, feature_dim), nprocs=world, join=True)
     b = torch.load(out)
-    init, a = _train_reference_config(True, True, 2, 32, batch, micro, [], None)
+    st = torch.load(out + ".stats")
+    assert (st.get("head_shard_bytes_received", 0) > 0) == (feature_dim % 256 == 0)
+    init, a = _train_reference_config(True, True, 2, 32, batch, micro, [], None, feature_dim=feature_dim)
     moved = 0.0
     for k in a:
         assert torch.equal(a[k].cpu(), b[k]), (k, float((a[k].cpu().float() - b[k].float()).abs().max()))
