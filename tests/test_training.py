@@ -458,7 +458,7 @@ def test_minibatch_trunk_precompute_is_bit_identical():
         for per_minibatch in (True, False):
             torch.manual_seed(0); random.seed(0)
             P = sd.P
-            P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), feature_dim      # every convolution in libisx: batch-invariant bits
+            P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim = 0, "resnet50", (7, 7), 32      # every convolution in libisx: batch-invariant bits
             P.train_epochs, P.train_batch_size, P.train_micro_batch, P.test_batch_size = 2, 12, 4, 16
             P.train_loss_int, P.untrained_blocks, P.train_epoch_switch, P.train_lr, P.train_pre_proc = 1000, -1, 1, 1e-2, True
             P.train_trunk_per_minibatch = per_minibatch
