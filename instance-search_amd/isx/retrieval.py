@@ -96,12 +96,36 @@ class NativeComm(object):
 _NATIVE_COMMS = {}            # torch.distributed group -> the libisx communicator opened over it (one per process and group)
 
 
+_NATIVE_OFF = set()           # groups whose communicator could not be opened on EVERY rank: they exchange over torch.distributed
+
+
 def native_comm_for(group=None):
     """The libisx RCCL communicator of `group`, opened on first use (a collective: every rank of the group gets here together, at its
-    first exchange) and kept for the life of the process."""
+    first exchange) and kept for the life of the process.  Opening can fail on SOME ranks only (after the unique-id broadcast, say): the ranks
+    agree on the outcome with one all-reduce(MIN) of a success flag over the torch group before any of them takes a path -- otherwise the ones
+    that succeeded would wait in a native all-gather for ranks that went to torch.distributed (round-4 ADVICE).  Returns None when the group
+    stays on torch.distributed."""
+    if group in _NATIVE_OFF:
+        return None
     nc = _NATIVE_COMMS.get(group)
     if nc is None:
-        nc = _NATIVE_COMMS[group] = NativeComm(group)
+        err = None
+        try:
+            nc = NativeComm(group)
+        except Exception as e:                               # librccl not loadable / communicator refused
+            err = e
+        ok = torch.tensor([0 if nc is None else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            import sys
+            if nc is not None:
+                nc.close()
+            print("isx.retrieval: libisx RCCL communicator unavailable on %s (%s); exchanging over torch.distributed"
+                  % ("this rank" if err is not None else "another rank", "%s: %s" % (type(err).__name__, err) if err is not None else "agreed by all-reduce"),
+                  file=sys.stderr)
+            _NATIVE_OFF.add(group)
+            return None
+        _NATIVE_COMMS[group] = nc
     return nc
 
 
@@ -116,7 +140,7 @@ def exchange_backend(group=None, cuda=True):
     import os
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return "none (one rank)"
-    if cuda and dist.get_backend(group) == "nccl" and os.environ.get("ISX_NATIVE_COMM", "1") != "0":
+    if cuda and dist.get_backend(group) == "nccl" and os.environ.get("ISX_NATIVE_COMM", "1") != "0" and group not in _NATIVE_OFF:
         return "isx_shard_topk_allgather (libisx: one grouped ncclAllGather pair over RCCL)"
     return "torch.distributed all_gather_into_tensor x 2 (%s)" % dist.get_backend(group)
 
@@ -129,13 +153,7 @@ def exchange_topk(s, i, group=None, native_comm=None):
     if native_comm is None and (not dist.is_initialized() or dist.get_world_size(group) == 1):
         return s[None], i[None]
     if native_comm is None and s.is_cuda and exchange_backend(group).startswith("isx_"):
-        try:
-            native_comm = native_comm_for(group)
-        except Exception as e:                               # librccl not loadable / communicator refused: every rank fails alike (same library, same node)
-            import os
-            import sys
-            print("isx.retrieval: libisx RCCL communicator unavailable (%s: %s); exchanging over torch.distributed" % (type(e).__name__, e), file=sys.stderr)
-            os.environ["ISX_NATIVE_COMM"] = "0"              # exchange_backend() reports the path actually taken from here on
+        native_comm = native_comm_for(group)                 # None: the ranks agreed to stay on torch.distributed (module state, not os.environ)
     if native_comm is not None and s.is_cuda:
         if native_comm.nranks == 1:
             return s[None], i[None]

@@ -178,7 +178,16 @@ class _SplitTrunk(object):
         with torch.no_grad():
             return self.folded(x.contiguous(memory_format=torch.channels_last)), split
 
-    _engines = {}
+    @staticmethod
+    def _engine_of(features, split, mods):
+        """The SuffixEngine of `features[split:]`, cached ON the features module (it dies with the net; a class-level dict keyed by id() kept
+        every net of a process alive -- round-4 ADVICE) and rebuilt when the block list changed.  False: the blocks are not the engine's."""
+        from isx.suffix import SuffixEngine
+        cache = features.__dict__.setdefault('_isx_suffix_engines', {})
+        eng = cache.get(split)
+        if eng is None or (eng is not False and eng.blocks != mods):
+            eng = cache[split] = SuffixEngine(mods) if SuffixEngine.applicable(mods) else False
+        return eng
 
     @classmethod
     def suffix(cls, features, f, split):
@@ -189,12 +198,7 @@ class _SplitTrunk(object):
         if (SUFFIX_ENGINE and mods and f.is_cuda and f.dtype == torch.float32 and torch.is_grad_enabled() and not f.requires_grad
                 and any(p.requires_grad for m in mods for p in m.parameters())):
             from isx.suffix import SuffixEngine
-            key = (id(features), split)
-            eng = cls._engines.get(key)
-            if eng is None or (eng is not False and eng.blocks != mods):
-                eng = cls._engines[key] = SuffixEngine(mods) if SuffixEngine.applicable(mods) else False
-                if len(cls._engines) > 8:
-                    cls._engines.pop(next(iter(cls._engines)))
+            eng = cls._engine_of(features, split, mods)
             if eng and SuffixEngine.applicable(mods):
                 return eng(f)
         for m in mods:
@@ -334,10 +338,7 @@ class DescriptorNet(nn.Module):
         if not mods or not any(p.requires_grad for m in mods for p in m.parameters()):
             return None
         from isx.suffix import SuffixEngine
-        key = (id(self.features), self._trunk.split)
-        eng = _SplitTrunk._engines.get(key)
-        if eng is None or (eng is not False and eng.blocks != mods):
-            eng = _SplitTrunk._engines[key] = SuffixEngine(mods) if SuffixEngine.applicable(mods) else False
+        eng = _SplitTrunk._engine_of(self.features, self._trunk.split, mods)
         return eng if eng and SuffixEngine.applicable(mods) else None
 
     def head_engine(self):

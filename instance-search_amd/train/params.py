@@ -24,7 +24,13 @@ class Params(object):
         """The table's entry for the CURRENT cnn_model unless a value was assigned (P.untrained_blocks = -1 freezes the whole
         trunk: descriptor-head-only training, this repo's round-2/3 benchmark configuration)."""
         v = self.__dict__.get('_untrained_blocks')
-        return UNTRAINED_BLOCKS.get(str(self.cnn_model).lower(), -1) if v is None else v
+        if v is not None:
+            return v
+        try:
+            return UNTRAINED_BLOCKS[str(self.cnn_model).lower()]       # an unknown backbone is an error, as in the reference (train/*_p.py:48)
+        except KeyError:
+            raise KeyError("no untrained_blocks entry for cnn_model %r (known: %s): assign P.untrained_blocks explicitly"
+                           % (self.cnn_model, ", ".join(sorted(UNTRAINED_BLOCKS))))
 
     @untrained_blocks.setter
     def untrained_blocks(self, v):

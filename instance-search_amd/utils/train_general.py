@@ -264,7 +264,9 @@ class _Stepper(object):
             sink.leaf_ids = list(range(lo, hi))
             eng = head = None
             batched = getattr(self.P, 'train_suffix_batched', True)
-            if self.mode == 'tree' and pre is not None and len(set(len(l) for l in mine)) == 1 and batched:
+            # batched engines need equal micro-batches; decided from the MINI-BATCH (n % mb == 0: every leaf of every rank has mb triplets), not from
+            # this rank's leaves, so that every rank and the single-process run take the same numeric path (round-4 ADVICE)
+            if self.mode == 'tree' and pre is not None and mine and n % mb == 0 and batched:
                 eng = getattr(self.net, 'suffix_engine', lambda: None)()
                 head = getattr(self.net, 'head_engine', lambda: None)()
             if eng is not None or head is not None:
