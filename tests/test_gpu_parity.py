@@ -172,6 +172,19 @@ def test_cosine_sim_bitexact(ops, M, N, D):
     assert np.abs(sim - ref).max() <= 1e-5
 
 
+def test_cosine_sim_configs2_size_sampled_against_the_oracle(ops):
+    """BASELINE configs[2]'s retrieval leg at ITS size -- 1 000 queries x 100 000 gallery rows of 464-d class-score descriptors (the clipped k-tail
+    of csrc/gemm_tile.hpp load_tile: D a multiple of 4 but not of the k-tile; 128x128 tiles for the whole rounds + a second launch of 64x64 tiles
+    for the remaining columns): 24 query rows x all columns and all rows x 64 columns spread over both launches, bit for bit against the oracle."""
+    rng = np.random.default_rng(464)
+    Q, G = unit(rng, 1000, 464), unit(rng, 100000, 464)
+    sim = host(ops.cosine_sim(dev(Q), dev(G)))
+    rows = np.r_[0:8, 500:508, 992:1000]
+    np.testing.assert_array_equal(sim[rows], O.cosine_sim(Q[rows], G))
+    cols = np.r_[0:16, 50000:50016, 98290:98306, 99984:100000]
+    np.testing.assert_array_equal(sim[:, cols], O.cosine_sim(Q, G[cols]))
+
+
 def test_cosine_sim_mfma_layout(ops):
     # A = I against an ASYMMETRIC B catches swapped row/col maps (guide section 3)
     n = 128
