@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : (TM * TN == 4 && !GRAD) ? I
 __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv3x3_tail_kernel(const float* __restrict__ x, int64_t M, const float* __restrict__ Wt, int64_t N, Conv3x3Geom g,
                                                               float* __restrict__ C, TileMap tm_big, TileMap tm_small, int64_t m_split,
                                                               const float* __restrict__ bias, const float* __restrict__ res, int relu) {
-    __shared__ float lds[16 * (128 + 128 + 2 * lds_pad(16))];                        // = 32 * (64 + 64 + 2 * lds_pad(32)) floats
-    static_assert(16 * (128 + 128 + 2 * lds_pad(16)) >= 32 * (64 + 64 + 2 * lds_pad(32)), "LDS of the small tile");
+    constexpr int kBig = 16 * (128 + 128 + 2 * lds_pad(16));
+    __shared__ float lds[kBig > kTailLdsFloats ? kBig : kTailLdsFloats];
     const int nbig = tm_big.tiles_m * tm_big.tiles_n;                                // a multiple of 8: the XCD of a block is the same in both numberings
     int tile_m, tile_n;
     if ((int)blockIdx.x < nbig) {
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv3x3_tail_kernel(co
         conv3x3_tile<2, 2, 16>(lds, x, M, Wt, N, g, C, (int64_t)tile_m * 128, (int64_t)tile_n * 128, bias, res, relu);
     } else {
         tile_of_block(tm_small, tile_m, tile_n, (int)blockIdx.x - nbig, tm_small.tiles_m * tm_small.tiles_n);
-        conv3x3_tile<1, 1, 32>(lds, x, M, Wt, N, g, C, m_split + (int64_t)tile_m * 64, (int64_t)tile_n * 64, bias, res, relu);
+        conv3x3_tile<ISX_TAIL_TM, 1, 32>(lds, x, M, Wt, N, g, C, m_split + (int64_t)tile_m * (64 * ISX_TAIL_TM), (int64_t)tile_n * 64, bias, res, relu);
     }
 }
 
@@ -73,7 +73,7 @@ static void launch_conv3x3(const float* x, int64_t M, const float* w, int64_t N,
         TileMap small;
         small.m_active = nullptr;
         tm.tiles_m = (int)(split / 128);
-        small.tiles_m = (int)((M - split + 63) / 64);
+        small.tiles_m = (int)((M - split + 64 * ISX_TAIL_TM - 1) / (64 * ISX_TAIL_TM));
         small.tiles_n = (int)((N + 63) / 64);
         hipLaunchKernelGGL(conv3x3_tail_kernel, dim3((unsigned)(tm.tiles_m * tm.tiles_n + small.tiles_m * small.tiles_n)), dim3(256), 0, st, x, M, w, N, g, y,
                            tm, small, split, bias, res, relu);
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256, TM * TN == 1 ? 6 : TM * TN == 4 ? ISX_WG_PER_C
 __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_dual_tail_kernel(const float* __restrict__ t, const float* __restrict__ x, int64_t M, const float* __restrict__ Wt,
                                                                    int64_t N, DualGeom g, float* __restrict__ C, TileMap tm_big, TileMap tm_small,
                                                                    int64_t m_split, const float* __restrict__ bias, int relu) {
-    __shared__ float lds[16 * (128 + 128 + 2 * lds_pad(16))];
+    constexpr int kBig = 16 * (128 + 128 + 2 * lds_pad(16));
+    __shared__ float lds[kBig > kTailLdsFloats ? kBig : kTailLdsFloats];
     const int nbig = tm_big.tiles_m * tm_big.tiles_n;
     int tile_m, tile_n;
     if ((int)blockIdx.x < nbig) {
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_dual_tail_kern
         conv1x1_dual_tile<2, 2, 16>(lds, t, x, M, Wt, N, g, C, (int64_t)tile_m * 128, (int64_t)tile_n * 128, bias, relu);
     } else {
         tile_of_block(tm_small, tile_m, tile_n, (int)blockIdx.x - nbig, tm_small.tiles_m * tm_small.tiles_n);
-        conv1x1_dual_tile<1, 1, 32>(lds, t, x, M, Wt, N, g, C, m_split + (int64_t)tile_m * 64, (int64_t)tile_n * 64, bias, relu);
+        conv1x1_dual_tile<ISX_TAIL_TM, 1, 32>(lds, t, x, M, Wt, N, g, C, m_split + (int64_t)tile_m * (64 * ISX_TAIL_TM), (int64_t)tile_n * 64, bias, relu);
     }
 }
 
@@ -241,7 +242,7 @@ static void launch_dual(const float* t, const float* x, int64_t M, const float* 
         TileMap small;
         small.m_active = nullptr;
         tm.tiles_m = (int)(split / 128);
-        small.tiles_m = (int)((M - split + 63) / 64);
+        small.tiles_m = (int)((M - split + 64 * ISX_TAIL_TM - 1) / (64 * ISX_TAIL_TM));
         small.tiles_n = (int)((N + 63) / 64);
         hipLaunchKernelGGL(conv1x1_dual_tail_kernel, dim3((unsigned)(tm.tiles_m * tm.tiles_n + small.tiles_m * small.tiles_n)), dim3(256), 0, st, t, x, M, w, N, g,
                            y, tm, small, split, bias, relu);

@@ -242,8 +242,8 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_tail_kernel(const float* __restrict__ Q, int64_t M, const float* __restrict__ G, int64_t N, int D,
                                                               float* __restrict__ C, int64_t ldc, TileMap tm_big, TileMap tm_small, int64_t m_split,
                                                               const float* __restrict__ bias, uint8_t* __restrict__ res, int relu) {
-    __shared__ float lds[16 * (128 + 128 + 2 * lds_pad(16))];
-    static_assert(16 * (128 + 128 + 2 * lds_pad(16)) >= 32 * (64 + 64 + 2 * lds_pad(32)), "LDS of the small tile");
+    constexpr int kBig = 16 * (128 + 128 + 2 * lds_pad(16));
+    __shared__ float lds[kBig > kTailLdsFloats ? kBig : kTailLdsFloats];
     const int nbig = tm_big.tiles_m * tm_big.tiles_n;                 // a multiple of 8: a block's XCD is the same in both numberings
     int tile_m, tile_n;
     if ((int)blockIdx.x < nbig) {
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_tail_kernel(co
         cosine_gemm_tile<ALIGNED, 2, 2, 2, 16>(lds, Q, M, G, N, D, C, ldc, (int64_t)tile_m * 128, (int64_t)tile_n * 128, bias, res, relu);
     } else {
         tile_of_block(tm_small, tile_m, tile_n, (int)blockIdx.x - nbig, tm_small.tiles_m * tm_small.tiles_n);
-        cosine_gemm_tile<ALIGNED, 1, 1, 2, 32>(lds, Q, M, G, N, D, C, ldc, m_split + (int64_t)tile_m * 64, (int64_t)tile_n * 64, bias, res, relu);
+        cosine_gemm_tile<ALIGNED, ISX_TAIL_TM, 1, 2, 32>(lds, Q, M, G, N, D, C, ldc, m_split + (int64_t)tile_m * (64 * ISX_TAIL_TM), (int64_t)tile_n * 64, bias, res, relu);
     }
 }
 
@@ -364,7 +364,7 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
         TileMap big, small;
         big.m_active = small.m_active = nullptr;
         big.tiles_m = (int)(split / 128); big.tiles_n = (int)((N + 127) / 128);
-        small.tiles_m = (int)((M - split + 63) / 64); small.tiles_n = (int)((N + 63) / 64);
+        small.tiles_m = (int)((M - split + 64 * ISX_TAIL_TM - 1) / (64 * ISX_TAIL_TM)); small.tiles_n = (int)((N + 63) / 64);
         const dim3 grid((unsigned)(big.tiles_m * big.tiles_n + small.tiles_m * small.tiles_n)), block(256);
         if (aligned) hipLaunchKernelGGL((conv1x1_tail_kernel<true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, big, small, split, thr, gmax, relu);
         else hipLaunchKernelGGL((conv1x1_tail_kernel<false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, big, small, split, thr, gmax, relu);

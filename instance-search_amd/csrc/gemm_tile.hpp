@@ -271,6 +271,10 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, con
 // addresses once; with the chunk fold in the loop it re-derived them with a v_add_u32 in front of every ds_read2 instead (15 VALU instructions
 // among the 32 MFMAs of a k-tile; the two-level kernels ran 10 % below the one-chain ones at ANY chunk length).  The empty asm makes each
 // address an opaque 32-bit LDS pointer that cannot be rematerialised.
+#ifndef ISX_TAIL_TM
+#define ISX_TAIL_TM 1           // tail tiles of the 128x128 convolution launches: 64 ISX_TAIL_TM rows x 64 columns (A/B: 2)
+#endif
+constexpr int kTailLdsFloats = 32 * (64 * ISX_TAIL_TM + 64 + 2);      // BK = 32 stage of a tail tile (lds_pad(32) = 1 per operand)
 #ifndef ISX_PIN_KTILE
 #define ISX_PIN_KTILE 1
 #endif
