@@ -128,6 +128,7 @@ SPLIT_TRUNK = os.environ.get("ISX_SPLIT_TRUNK", "1") != "0"
 SUFFIX_ENGINE = os.environ.get("ISX_SUFFIX_ENGINE", "1") != "0"
 # A/B switch: ISX_HEAD_ENGINE=0 keeps the descriptor head of a training step on torch autograd, micro-batch by micro-batch.
 HEAD_ENGINE = os.environ.get("ISX_HEAD_ENGINE", "1") != "0"
+PREFIX_CACHE_BUDGET = int(os.environ.get("ISX_PREFIX_CACHE_GB", "96")) << 30      # HBM the prefix-feature cache of ONE resident set may take
 
 
 def first_trainable(features):
@@ -154,6 +155,8 @@ class _SplitTrunk(object):
         self.folded = None
         self.key = None
         self.split = 0
+        self.cache = {}                 # id(resident set) -> [set, features (N, C, h, w) or None, have (N,) bool]: prefix features by image row
+        self.cache_stats = {"rows_served": 0, "rows_computed": 0}
 
     @staticmethod
     def enabled(features):
@@ -164,6 +167,12 @@ class _SplitTrunk(object):
 
     def prefix(self, features, x):
         """frozen prefix of `features` on x -> (feature tensor without graph, index the suffix starts at)"""
+        split = self._refresh(features, x)
+        with torch.no_grad():
+            return self.folded(x.contiguous(memory_format=torch.channels_last)), split
+
+    def _refresh(self, features, x):
+        """(Re)build the folded prefix when its weights / buffers / split changed; returns the split index."""
         split = first_trainable(features)
         mods = list(features)[:split]
         # the folded copy is stale as soon as any weight or BN buffer of the prefix is written in place (load_state_dict) or replaced, or
@@ -175,8 +184,45 @@ class _SplitTrunk(object):
             from .nn_utils import fold_batch_norm
             self.folded = fold_batch_norm(nn.Sequential(*mods)).to(x.device).to(memory_format=torch.channels_last)
             self.key, self.split = key, split
-        with torch.no_grad():
-            return self.folded(x.contiguous(memory_format=torch.channels_last)), split
+            self.cache = {}             # features of another prefix
+        return split
+
+    def prefix_cached(self, features, xs):
+        """Prefix features of image batches that are ROWS OF A RESIDENT SET (train/_common.ResidentImages.gather leaves the provenance on the
+        tensor): looked up in an HBM table of the set's prefix features, the rows not seen yet computed first (launches of up to 512 images).
+        A frozen prefix with frozen BatchNorm maps an image to the same bits whatever batch it rides in (the kernels are batch-invariant:
+        tests/test_gpu_dropin.py), the preprocessed images do not change between steps, and an epoch of the reference's training touches every
+        image a dozen times (36 steps x 192 images from a 512-image set; utils/train_general.py:51-74 recomputes the trunk per micro-batch): the
+        table removes the repeats, bit for bit the same training.  288 GB of HBM hold the 0.8 MB per image of ~100 k images next to everything
+        else (PREFIX_CACHE_BUDGET).  None: not applicable (images of no / several sets, table over budget)."""
+        srcs = [getattr(x, "_isx_rows", None) for x in xs]
+        if any(s is None for s in srcs) or len(set(id(s[0]) for s in srcs)) != 1:
+            return None
+        R = srcs[0][0]
+        idx = torch.cat([s[1] for s in srcs])
+        self._refresh(features, xs[0])                               # a prefix whose weights changed drops its table
+        ent = self.cache.get(id(R))
+        if ent is None:
+            probe, _ = self.prefix(features, xs[0][:1])
+            N = R.data.size(0)
+            if N * probe[0].numel() * 4 > PREFIX_CACHE_BUDGET:
+                return None
+            feat = torch.empty((N,) + tuple(probe.shape[1:]), dtype=torch.float32, device=probe.device).contiguous(memory_format=torch.channels_last)
+            ent = self.cache[id(R)] = [R, feat, torch.zeros(N, dtype=torch.bool, device=probe.device)]
+        _, feat, have = ent
+        missing = idx[~have[idx]]
+        if missing.numel():
+            rows = torch.unique(missing)
+            for a in range(0, rows.numel(), 512):
+                r = rows[a:a + 512]
+                f, _ = self.prefix(features, R.normalised_rows(r))
+                feat[r] = f
+            have[rows] = True
+            self.cache_stats["rows_computed"] += int(rows.numel())
+        self.cache_stats["rows_served"] += int(idx.numel())
+        f = feat.index_select(0, idx)
+        return tuple(f.split([x.size(0) for x in xs], 0))
+
 
     @staticmethod
     def _engine_of(features, split, mods):
@@ -315,7 +361,7 @@ class DescriptorNet(nn.Module):
         p = next(self.features.parameters(), None)
         return bool(self.training and p is not None and p.is_cuda and _SplitTrunk.enabled(self.features))
 
-    def precompute_trunk(self, *xs):
+    def precompute_trunk(self, *xs, cache=False):
         """Training with a frozen trunk PREFIX and frozen BatchNorm (the reference's configurations: stem + layers 1-3 frozen, layer4
         trained; or everything frozen with untrained = -1): the prefix output of an image does not depend on the batch it rides in and needs
         no autograd graph, so the prefix of a whole mini-batch runs as ONE launch of the folded inference trunk instead of once per
@@ -325,6 +371,10 @@ class DescriptorNet(nn.Module):
             return None
         if not self._trunk.usable(self.features, xs[0]) or len(set(tuple(x.shape[1:]) for x in xs)) != 1:
             return None
+        if cache:                              # P.train_prefix_cache: rows of a resident set are looked up, not recomputed (_SplitTrunk.prefix_cached)
+            got = self._trunk.prefix_cached(self.features, xs)
+            if got is not None:
+                return got
         sizes = [x.size(0) for x in xs]
         f, _ = self._trunk.prefix(self.features, torch.cat(xs, 0))
         return tuple(f.split(sizes, 0))

@@ -19,8 +19,12 @@ def normalise_u8_batch(x_u8, device):
         raise RuntimeError("uint8 images in the dataset but no mean/std registered (train._common.RAW_INGEST)")
     if device >= 0:
         from isx import ops
+        src = getattr(x_u8, "_isx_rows", None)
         x_u8 = x_u8 if x_u8.is_cuda else x_u8.pin_memory().cuda(non_blocking=True)
-        return ops.images_u8_to_f32(x_u8.contiguous(), mean, std, channels_last=True)
+        y = ops.images_u8_to_f32(x_u8.contiguous(), mean, std, channels_last=True)
+        if src is not None:
+            y._isx_rows = src                   # which rows of which resident set these images are (model/siamese.py prefix-feature cache)
+        return y
     x = x_u8.permute(0, 3, 1, 2).float().div_(255.0)
     m = torch.tensor(list(mean)).view(1, -1, 1, 1)
     s_ = torch.tensor(list(std)).view(1, -1, 1, 1)
@@ -159,7 +163,14 @@ class ResidentImages(object):
 
     def gather(self, ims):
         idx = torch.tensor([self.index[id(im)] for im in ims], dtype=torch.int64, device=self.data.device)
-        return self.data.index_select(0, idx)
+        x = self.data.index_select(0, idx)
+        x._isx_rows = (self, idx)               # provenance: lets a frozen trunk prefix look its features up instead of recomputing them
+        return x
+
+    def normalised_rows(self, rows):
+        """The network input of the given rows of the set (fp32, normalised)."""
+        x = self.data.index_select(0, rows)
+        return normalise_u8_batch(x, self.data.device.index) if x.dtype == torch.uint8 else x
 
 
 def make_resident(dataset, device):

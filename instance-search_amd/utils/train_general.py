@@ -162,7 +162,8 @@ class _Stepper(object):
             return None
         rng_state = random.getstate()
         inputs, targets = self.make_batch(local, len(local), **batch_args)
-        feats = self.net.precompute_trunk(*inputs)
+        feats = (self.net.precompute_trunk(*inputs, cache=True) if getattr(self.P, 'train_prefix_cache', False)
+                 else self.net.precompute_trunk(*inputs))
         if feats is None:                            # (CPU tensors, ragged shapes): the batch is built again per micro-batch, from the same random state
             random.setstate(rng_state)
             return None

@@ -501,7 +501,7 @@ def test_untrained_blocks_follow_the_reference_table():
     assert first_trainable(frozen.features) == len(frozen.features)
 
 
-def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch, micro, mined, replay, batched=True, feature_dim=32):
+def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch, micro, mined, replay, batched=True, feature_dim=32, prefix_cache=False):
     """One run of train.siamese_descriptor.main on the reference configuration (ResNet-50, untrained_blocks from the table).  `mined`:
     list receiving the mined negatives per epoch; `replay`: a previous run's list to use instead of mining."""
     import copy
@@ -526,12 +526,16 @@ def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch,
         P.train_loss_int, P.train_epoch_switch, P.train_lr, P.train_pre_proc = 1000, 1, 1e-3, True
         P.untrained_blocks = None                                  # the reference's table: 15 for ResNet-50
         P.train_suffix_batched = batched
+        P.train_prefix_cache = prefix_cache
         assert P.untrained_blocks == 15
         torch.manual_seed(0); random.seed(0)
         init = {k: v.detach().clone() for k, v in sd.get_siamese_net().state_dict().items()}
         torch.manual_seed(0); random.seed(0)
         net, _ = sd.main(tr, tr, te)
         assert net.trunk_precomputable() == split_trunk
+        if prefix_cache:
+            st = net._trunk.cache_stats
+            assert st["rows_computed"] <= n_images and st["rows_served"] > 4 * st["rows_computed"], st      # every image computed once, served many times
         return init, {k: v.detach().clone() for k, v in net.state_dict().items()}
     finally:
         ms.SPLIT_TRUNK, ms.SUFFIX_ENGINE = old
@@ -638,6 +642,17 @@ def _train_reference_two_ranks_one_gpu(rank, world, port, out, batch=16, micro=4
         torch.save(dict(_dp.STATS), out + ".stats")
     dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_prefix_feature_cache_trains_the_same_bits():
+    """P.train_prefix_cache: the frozen prefix's features of the resident training images come from an HBM table (each image computed once, in
+    launches of its own) instead of being recomputed at every use (reference utils/train_general.py:51-74: the trunk runs per micro-batch) --
+    two epochs on the reference configuration end in the SAME state dict, bit for bit: the kernels are batch-invariant."""
+    _, a = _train_reference_config(True, True, 2, 32, 16, 4, [], None)
+    _, b = _train_reference_config(True, True, 2, 32, 16, 4, [], None, prefix_cache=True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
 
 
 @pytest.mark.gpu
