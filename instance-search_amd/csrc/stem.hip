@@ -44,6 +44,19 @@ constexpr int ST_ROWCHUNKS = ST_RSF / 4;       // 16-B chunks per staged row: 17
 
 struct StemGeom { int H, W, Hc, Wc, Hp, Wp, steps, bands; };
 
+// a += t on the 16 accumulator registers of one MFMA tile, IN PLACE (as vector arithmetic hipcc allocated a third tile for the sum: 135 spills)
+__device__ __forceinline__ void add_tile_inplace(f32x16& a, const f32x16& t) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        f32x2_t x = {a[2 * p], a[2 * p + 1]};
+        const f32x2_t y = {t[2 * p], t[2 * p + 1]};
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(y));
+        a[2 * p] = x[0];
+        a[2 * p + 1] = x[1];
+    }
+}
+
 // NCB: column bands per image (1: images up to 224 wide, the tile covers the whole width).
 template <int NCB>
 __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restrict__ x, StemGeom g, const float* __restrict__ w_ohwi,
@@ -160,39 +173,67 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
         const int wc_left = g.Wc - 112 * cb;                                    // convolution columns of the image from this band's first one on
 
         // two-level sum (gemm_tile.hpp): the chain restarts after filter rows 2 and 5 (63 + 63 + 21 terms; the zero-weight slot that pads a filter
-        // row to 22 adds fma(x, 0, acc) = acc) and the three chunk sums are added in order: tot = ((0 + c0) + c1) + c2
-        f32x16 acc[7], tot[7];
-#pragma unroll
-        for (int b = 0; b < 7; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[b][e] = 0.0f, tot[b][e] = 0.0f;
+        // row to 22 adds fma(x, 0, acc) = acc) and the three chunk sums are added in order: ((0 + c0) + c1) + c2.  A second accumulator set next
+        // to all seven tiles does not fit (2 x 112 VGPRs + 80): chunk 0 runs on all seven tiles as before and its chains BECOME the running sums
+        // (0 + c0 = c0: a chain from +0 is never -0); chunks 1 and 2 then go through the k loop in groups of 3 + 2 + 2 column blocks with a
+        // small temporary accumulator set per group, added element by element IN PLACE (v_pk_add_f32 on the register pairs of the tile).
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc[7];
         const float* const ap = in_lds + buf * ST_BUF_F + a_lane;
-        float av[2][7], bv[2];
+        {
+            float av[2][7], bv[2];
 #pragma unroll
-        for (int b = 0; b < 7; ++b) av[0][b] = ap[24 * b];
-        bv[0] = bp[0];
+            for (int b = 0; b < 7; ++b) av[0][b] = ap[24 * b];
+            bv[0] = bp[0];
 #pragma unroll
-        for (int s = 0; s < 77; ++s) {
-            if (s + 1 < 77) {
-                const int kh = (s + 1) / 11, sp = (s + 1) % 11;
+            for (int s = 0; s < 33; ++s) {                                      // filter rows 0-2: 11 k-steps per row
+                if (s + 1 < 33) {
+                    const int kh = (s + 1) / 11, sp = (s + 1) % 11;
 #pragma unroll
-                for (int b = 0; b < 7; ++b) av[(s + 1) & 1][b] = ap[kh * ST_RSF + 2 * sp + 24 * b];
-                bv[(s + 1) & 1] = bp[(22 * kh + 2 * sp) * 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int b = 0; b < 7; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][b], bv[s & 1], acc[b], 0, 0, 0);
-            if (s == 32 || s == 65) {                                           // filter rows 0-2 / 3-5 done (11 k-steps per row)
-#pragma unroll
-                for (int b = 0; b < 7; ++b) {
-                    tot[b] += acc[b];
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[b][e] = 0.0f;
+                    for (int b = 0; b < 7; ++b) av[(s + 1) & 1][b] = ap[kh * ST_RSF + 2 * sp + 24 * b];
+                    bv[(s + 1) & 1] = bp[(22 * kh + 2 * sp) * 64];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < 7; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][b], bv[s & 1], s == 0 ? zero : acc[b], 0, 0, 0);
             }
         }
+        auto later_chunks = [&](auto b0_, auto nb_) {
+            constexpr int B0 = decltype(b0_)::value, NB = decltype(nb_)::value;
+            f32x16 t[NB];
+            float av[2][NB], bv[2];
 #pragma unroll
-        for (int b = 0; b < 7; ++b) acc[b] = tot[b] + acc[b];
+            for (int b = 0; b < NB; ++b) av[1][b] = ap[3 * ST_RSF + 24 * (B0 + b)];            // s = 33: buffer 33 & 1
+            bv[1] = bp[(22 * 3) * 64];
+#pragma unroll
+            for (int s = 33; s < 77; ++s) {
+                if (s + 1 < 77) {
+                    const int kh = (s + 1) / 11, sp = (s + 1) % 11;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) av[(s + 1) & 1][b] = ap[kh * ST_RSF + 2 * sp + 24 * (B0 + b)];
+                    bv[(s + 1) & 1] = bp[(22 * kh + 2 * sp) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) t[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][b], bv[s & 1], (s == 33 || s == 66) ? zero : t[b], 0, 0, 0);
+                if (s == 65 || s == 76) {                                       // filter rows 3-5 / row 6 done
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        if (B0 + b == 0) add_tile_inplace(acc[0], t[b]);
+                        if (B0 + b == 1) add_tile_inplace(acc[1], t[b]);
+                        if (B0 + b == 2) add_tile_inplace(acc[2], t[b]);
+                        if (B0 + b == 3) add_tile_inplace(acc[3], t[b]);
+                        if (B0 + b == 4) add_tile_inplace(acc[4], t[b]);
+                        if (B0 + b == 5) add_tile_inplace(acc[5], t[b]);
+                        if (B0 + b == 6) add_tile_inplace(acc[6], t[b]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        later_chunks(std::integral_constant<int, 0>(), std::integral_constant<int, 3>());
+        later_chunks(std::integral_constant<int, 3>(), std::integral_constant<int, 2>());
+        later_chunks(std::integral_constant<int, 5>(), std::integral_constant<int, 2>());
 
         // ---- epilogue: bias + ReLU, 3x3 / stride 2 max.  acc[b][4 gg + 2 r + c] = convolution row 8 t + 2 gg + r, column 112 cb + 28 cg + 4 b + 2 h + c
         float own[7][4], rgt[7][4];
