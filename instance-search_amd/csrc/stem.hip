@@ -44,7 +44,9 @@ constexpr int ST_ROWCHUNKS = ST_RSF / 4;       // 16-B chunks per staged row: 17
 
 struct StemGeom { int H, W, Hc, Wc, Hp, Wp, steps, bands; };
 
-// a += t on the 16 accumulator registers of one MFMA tile, IN PLACE (as vector arithmetic hipcc allocated a third tile for the sum: 135 spills)
+// a += t on the 16 accumulator registers of one MFMA tile, IN PLACE: as vector arithmetic hipcc put the sums into fresh scattered register pairs
+// and turned the two old tiles into the next MFMA accumulators -- the file fragments and 135 VGPRs spill; the tied asm operand keeps the sum in
+// a's own registers (230 VGPRs, no spill).  The caller provides the MFMA -> VALU wait states.
 __device__ __forceinline__ void add_tile_inplace(f32x16& a, const f32x16& t) {
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -217,6 +219,10 @@ __global__ __launch_bounds__(512) void stem7x7_pool_kernel(const float* __restri
 #pragma unroll
                 for (int b = 0; b < NB; ++b) t[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s & 1][b], bv[s & 1], (s == 33 || s == 66) ? zero : t[b], 0, 0, 0);
                 if (s == 65 || s == 76) {                                       // filter rows 3-5 / row 6 done
+                    // the adds are inline asm: hipcc's hazard recognizer does not treat them as VALU reads of MFMA results, so the 18 wait states
+                    // a 16-pass MFMA needs before a VALU read of its destination are spelled out (the compiler emits s_nop 15 + s_nop 1 itself
+                    // in front of an ordinary v_pk_add_f32)
+                    asm volatile("s_nop 15\n\ts_nop 2" ::: "memory");
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
                         if (B0 + b == 0) add_tile_inplace(acc[0], t[b]);
