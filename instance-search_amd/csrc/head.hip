@@ -36,8 +36,14 @@ static int head_splits(int64_t K) {
 // read once instead of once per 64 rows; the tile shape only groups outputs, every output is the same chain in any of them.
 // ROWS: x is given as stored, (M, K) row-major (xT = x, Mrows = M): its tiles take the transposing LDS store of the weight tiles; rows past M read
 // zeros through the buffer descriptor.  Otherwise xT is (K, Mp), K-major, and goes to the LDS as it lies.  Same chain per output either way.
+#ifndef ISX_LB_HEADFWD
+#define ISX_LB_HEADFWD 2
+#endif
+#ifndef ISX_LB_SGD
+#define ISX_LB_SGD 3
+#endif
 template <int TM, int TN = 1, bool ROWS = false>
-__global__ __launch_bounds__(256) void head_fwd_gemm_kernel(const float* __restrict__ xT, int Mp, const float* __restrict__ Wn, int N, int K, int kt_per,
+__global__ __launch_bounds__(256, TM * TN >= 6 ? ISX_LB_HEADFWD : TM * TN >= 3 ? 3 : 4) void head_fwd_gemm_kernel(const float* __restrict__ xT, int Mp, const float* __restrict__ Wn, int N, int K, int kt_per,
                                                             float* __restrict__ part, int tiles_m, int Mrows = 0) {
     constexpr int BK = kHeadBK, BM = 64 * TM, BN = 64 * TN, LDA = ROWS ? BM + lds_pad(BK) : BM + 4, LDB = BN + lds_pad(BK);
     constexpr int CA = BM / 4, NA = ROWS ? BM * BK / 1024 : BK * CA / 256;
@@ -144,7 +150,7 @@ struct SgdParams { float lr, momentum, dampening, weight_decay; int nesterov, fi
 
 // TM: 128 (2) or 64 (1) rows of the weight per tile -- a shard of a sharded head can be as narrow as 64 output features; the tile only groups outputs
 template <int TM>
-__global__ __launch_bounds__(256) void head_sgd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t R, int N, int64_t K,
+__global__ __launch_bounds__(256, ISX_LB_SGD) void head_sgd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t R, int N, int64_t K,
                                                        float* __restrict__ w, float* __restrict__ mom, SgdParams sp, int tiles_k) {
     constexpr int TN = 2, BK = 32, BM = 64 * TM, BN = 128, LDA = BM + 4, LDB = BN + 4;
     constexpr int CA = BM / 4, CB = BN / 4, NA = BK * CA / 256, NB = BK * CB / 256;

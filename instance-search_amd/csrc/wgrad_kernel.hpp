@@ -27,8 +27,12 @@ __device__ __forceinline__ int64_t wgrad_src_row(const WgradGeom& g, int64_t p, 
 // FOLD > 0 (the descriptor head's input gradient, head.hip): the reduction is summed in two levels -- a chain per FOLD k-tiles, the chains added in
 // order into a second accumulator (gemm_tile.hpp) -- so that a run whose reduction is SHARDED across ranks (every rank a few of the chains,
 // isx_head_linear_dgrad_parts) lands on the same bits.  fold_kt: k-tiles per chain.
+// Workgroups per CU (round 5): without a bound hipcc spent 224 registers on the 128x128 shape and 293 on the folding 192x64 one (ONE wave per SIMD)
+#ifndef ISX_LB_WGRAD
+#define ISX_LB_WGRAD 3
+#endif
 template <int TM, int TN, bool FOLD = false>
-__global__ __launch_bounds__(256) void wgrad_gemm_kernel(const float* __restrict__ A, int64_t K, int N1, const float* __restrict__ Bm, int N2,
+__global__ __launch_bounds__(256, TM * TN == 1 ? 4 : FOLD ? 2 : ISX_LB_WGRAD) void wgrad_gemm_kernel(const float* __restrict__ A, int64_t K, int N1, const float* __restrict__ Bm, int N2,
                                                          WgradGeom g, int taps, float* __restrict__ C, int64_t ldc, int tiles_n, int kt_per,
                                                          int splits, float* __restrict__ colsum, int fold_kt = 0) {
     constexpr int BK = 32, BM = 64 * TM, BN = 64 * TN, LDA = BM + 4, LDB = BN + 4;       // +4: rows stay 16-B aligned for the float4 stores
