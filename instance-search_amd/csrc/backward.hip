@@ -23,14 +23,30 @@ namespace isx {
 
 int launch_gemm_masked(const float* A, int64_t M, const float* Bt, int64_t N, int D, float* C, const float* mask, const float* add, hipStream_t st);
 
-// number of pixel splits of a weight-gradient launch: enough workgroups to fill the chip (~2 per CU), at least 4 k-tiles each; a function of
-// the SHAPE only, so the summation tree of a micro-batch is the same whatever runs around it
+// Number of pixel splits of a weight-gradient launch -- a function of the SHAPE only, so the summation tree of a micro-batch is the same whatever
+// runs around it (a rank with one micro-batch and a process with eight land on the same bits).
+// Shapes the 128x128 tiles cover (round 5): the split is chosen for the launch the single-GPU step issues -- 8 micro-batches at once -- by a round
+// model: blocks = tiles x 8 x S run in ceil(blocks / 768) rounds (three resident workgroups per CU), a block costs its nk / S k-tiles plus ~6
+// k-tiles' worth of prologue and epilogue.  Round 4's rule (~1024 blocks per leaf) put every layer4 launch at 1.3-1.5 rounds: a quarter to a
+// third of each launch ran half empty (wgrad 3.3 ms per step for 311 GFLOP = 0.60 of the fp32 peak).
 static int wgrad_splits(int64_t K, int Cin, int Cout, int taps) {
+    const int64_t nk = (K + 31) / 32;
+    static const int64_t target = [] { const char* e = getenv("ISX_WGRAD_TARGET"); const long long v = e ? atoll(e) : 0; return (int64_t)(v >= 64 ? v : 0); }();   // A/B knob: > 0 = the rule of rounds 4-5a (blocks per leaf)
+    if (target == 0 && Cout % 128 == 0 && Cin % 128 == 0 && nk >= 8) {
+        const int64_t n128 = (int64_t)(Cout / 128) * (Cin / 128) * taps;
+        int best = 1;
+        double best_t = 1e300;
+        for (int s = 1; s <= 8 && nk / s >= 4; ++s) {
+            const int64_t rounds = (n128 * 8 * s + 767) / 768;
+            const double t = (double)rounds * ((double)nk / s + 6.0);
+            if (t < best_t) { best_t = t; best = s; }
+        }
+        return best;
+    }
     const bool big = Cout % 128 == 0 && Cin % 128 == 0 && (int64_t)(Cout / 128) * (Cin / 128) * taps >= 512;
     const int64_t tiles = (big ? (int64_t)(Cout / 128) * (Cin / 128) : (int64_t)(Cout / 64) * (Cin / 64)) * taps;
-    const int64_t nk = (K + 31) / 32;
-    static const int64_t target = [] { const char* e = getenv("ISX_WGRAD_TARGET"); const long long v = e ? atoll(e) : 0; return (int64_t)(v >= 64 ? v : 512); }();   // A/B knob; round 5: 1024 -> 512 workgroups per launch of ONE leaf (fewer, longer partial chains: step 24.8 -> 24.5 ms)
-    int64_t s = (target + tiles - 1) / tiles;
+    const int64_t tgt = target > 0 ? target : 512;
+    int64_t s = (tgt + tiles - 1) / tiles;
     if (s > nk / 4) s = nk / 4;
     if (s > 16) s = 16;
     return (int)(s < 1 ? 1 : s);

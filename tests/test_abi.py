@@ -48,7 +48,7 @@ def test_argument_validation_without_gpu():
     # round-4 entries: training kernels (backward.hip, head.hip)
     assert lib.isx_conv_wgrad_nhwc(None, None, 4, 1, 7, 7, 100, 64, 1, 1, None, None, None) == -1 and b"multiples of 64" in lib.isx_last_error()
     assert lib.isx_conv_wgrad_nhwc(None, None, 5, 2, 7, 7, 64, 64, 1, 1, None, None, None) == -1 and b"multiple of leaves" in lib.isx_last_error()
-    assert lib.isx_conv_wgrad_splits(1176, 512, 2048, 1) == 2 and lib.isx_conv_wgrad_splits(1176, 512, 512, 9) == 1 and lib.isx_conv_wgrad_splits(10, 100, 64, 1) == 0
+    assert lib.isx_conv_wgrad_splits(1176, 512, 2048, 1) == 3 and lib.isx_conv_wgrad_splits(1176, 512, 512, 9) == 2 and lib.isx_conv_wgrad_splits(10, 100, 64, 1) == 0
     assert lib.isx_conv3x3_s2_col2im_nhwc(None, 1, 14, 14, 30, None, None, None) == -1 and b"Cin % 4" in lib.isx_last_error()
     assert lib.isx_conv1x1_dgrad_nhwc(None, 0, 64, None, 64, None, None, None, None) == 0
     assert lib.isx_bn_fold_backward(None, None, 1, 1, None, None, None, None, 64, 64, 5, 0, 0, None, None, None, None) == -1 and b"taps" in lib.isx_last_error()
