@@ -154,13 +154,15 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
 
     // outer loop: chunks of the two-level sum (one pass when CHUNK == 0); inner loop: the staged k-tiles of a chunk (gemm_tile.hpp); the first
     // k-tile of a chunk starts its chains with C = 0
+    f32x16 (*totp)[TN] = nullptr;
+    if constexpr (CHUNK != 0) totp = tot;
     auto body = [&](int kt, auto zero_c) {
         const bool more = (kt + 1 < nk);
         if (more) {
             load_a();
             load_tile<true, BN, BK>(Wt, N, D, n0, (kt + 1) * BK, rb);
         }
-        mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc);
+        mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc, totp);
         __syncthreads();
         if (more) {
             store_tile<BM, BK>(As, ra);
@@ -173,10 +175,11 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
     } else {
         for (int kt = 0; kt < nk;) {
             const int kend = kt + CHUNK / BK < nk ? kt + CHUNK / BK : nk;
-            body(kt++, std::true_type());
+            body(kt++, std::true_type());                      // (interleaved fold: adds the PREVIOUS chunk's chain in front of its C = 0 MFMAs)
             for (; kt < kend; ++kt) body(kt, std::false_type());
-            add_chunk<TM, TN>(tot, acc);
+            if (!(PINNED && ISX_FOLD_INTERLEAVE)) add_chunk<TM, TN>(tot, acc);
         }
+        if (PINNED && ISX_FOLD_INTERLEAVE) add_chunk<TM, TN>(tot, acc);       // the last chunk
     }
     take_tot();
 }

@@ -93,13 +93,15 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
 
     // outer loop: chunks of the two-level sum (one pass when CHUNK == 0); inner loop: the staged k-tiles of a chunk.  The FIRST k-tile of a chunk is
     // a second copy of the body whose first MFMAs take C = 0 (no zeroing pass), the chain is added to tot behind the chunk's last barrier.
+    f32x16 (*totp)[TN] = nullptr;
+    if constexpr (CHUNK != 0) totp = tot;
     auto body = [&](int kt, auto zero_c) {
         const bool more = (kt + 1 < nk);
         if (more) {
             load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
             load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
         }
-        mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc);
+        mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc, totp);
         __syncthreads();
         if (more) {
             store_tile<BM, BK>(As, ra);
@@ -112,10 +114,11 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
     } else {
         for (int kt = 0; kt < nk;) {
             const int kend = kt + CHUNK / BK < nk ? kt + CHUNK / BK : nk;
-            body(kt++, std::true_type());
+            body(kt++, std::true_type());                      // (interleaved fold: adds the PREVIOUS chunk's chain in front of its C = 0 MFMAs)
             for (; kt < kend; ++kt) body(kt, std::false_type());
-            add_chunk<TM, TN>(tot, acc);
+            if (!(PINNED && ISX_FOLD_INTERLEAVE)) add_chunk<TM, TN>(tot, acc);
         }
+        if (PINNED && ISX_FOLD_INTERLEAVE) add_chunk<TM, TN>(tot, acc);       // the last chunk
     }
     if constexpr (CHUNK != 0) {
 #pragma unroll

@@ -294,8 +294,24 @@ __device__ __forceinline__ KtilePtrs<BK> pin_ktile_ptrs(const float* a_base, con
     return p;
 }
 // the k loop of mfma_ktile's prefetch variant on pinned addresses
+// a += t on the 16 registers of one MFMA tile IN PLACE (tied asm operands: the sum stays in a's registers, hipcc cannot rename it into fresh ones)
+__device__ __forceinline__ void add_tile_inplace(f32x16& a, const f32x16& t) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        f32x2_t x = {a[2 * p], a[2 * p + 1]};
+        const f32x2_t y = {t[2 * p], t[2 * p + 1]};
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(y));
+        a[2 * p] = x[0];
+        a[2 * p + 1] = x[1];
+    }
+}
+
+// tot (ZERO_C only, ISX_FOLD_INTERLEAVE): the chain that ended with the previous k-tile is added to tot tile by tile right in front of the MFMA that
+// restarts that tile from C = 0 -- the adds of tile n + 1 issue while the MFMA of tile n runs.  (The MFMAs that produced acc are at least one
+// barrier old: no MFMA -> VALU wait states needed.)
 template <int TM, int TN, int BK, bool ZERO_C = false>
-__device__ __forceinline__ void mfma_ktile_pinned(const KtilePtrs<BK>& p, f32x16 (&acc)[TM][TN]) {
+__device__ __forceinline__ void mfma_ktile_pinned(const KtilePtrs<BK>& p, f32x16 (&acc)[TM][TN], f32x16 (*tot)[TN] = nullptr) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float a[2][TM], b[2][TN];
 #pragma unroll
@@ -314,7 +330,10 @@ __device__ __forceinline__ void mfma_ktile_pinned(const KtilePtrs<BK>& p, f32x16
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], (ZERO_C && kk == 0) ? zero : acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+                if (ZERO_C && kk == 0 && tot) add_tile_inplace(tot[i][j], acc[i][j]);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], (ZERO_C && kk == 0) ? zero : acc[i][j], 0, 0, 0);
+            }
     }
 }
 
@@ -341,9 +360,14 @@ __device__ __forceinline__ void fold_chunk(f32x16 (&tot)[TM][TN], f32x16 (&acc)[
     add_chunk<TM, TN>(tot, acc);
     zero_tiles(acc);
 }
+#ifndef ISX_FOLD_INTERLEAVE
+#define ISX_FOLD_INTERLEAVE 1
+#endif
+// returns true when the k-tile added the previous chunk's chain to tot itself (pinned 128x128 shape with ISX_FOLD_INTERLEAVE)
 template <int TM, int TN, int BK, int LDA, int LDB, bool PINNED, bool ZERO_C = false>
-__device__ __forceinline__ void mfma_ktile_sel(const float* __restrict__ a_base, const float* __restrict__ b_base, const KtilePtrs<BK>& pins, f32x16 (&acc)[TM][TN]) {
-    if constexpr (PINNED) mfma_ktile_pinned<TM, TN, BK, ZERO_C>(pins, acc);
+__device__ __forceinline__ void mfma_ktile_sel(const float* __restrict__ a_base, const float* __restrict__ b_base, const KtilePtrs<BK>& pins, f32x16 (&acc)[TM][TN],
+                                               f32x16 (*tot)[TN] = nullptr) {
+    if constexpr (PINNED) mfma_ktile_pinned<TM, TN, BK, ZERO_C>(pins, acc, ISX_FOLD_INTERLEAVE ? tot : nullptr);
     else mfma_ktile<TM, TN, BK, LDA, LDB, ZERO_C>(a_base, b_base, acc);
 }
 }  // namespace isx

@@ -44,20 +44,9 @@ constexpr int ST_ROWCHUNKS = ST_RSF / 4;       // 16-B chunks per staged row: 17
 
 struct StemGeom { int H, W, Hc, Wc, Hp, Wp, steps, bands; };
 
-// a += t on the 16 accumulator registers of one MFMA tile, IN PLACE: as vector arithmetic hipcc put the sums into fresh scattered register pairs
-// and turned the two old tiles into the next MFMA accumulators -- the file fragments and 135 VGPRs spill; the tied asm operand keeps the sum in
-// a's own registers (230 VGPRs, no spill).  The caller provides the MFMA -> VALU wait states.
-__device__ __forceinline__ void add_tile_inplace(f32x16& a, const f32x16& t) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        f32x2_t x = {a[2 * p], a[2 * p + 1]};
-        const f32x2_t y = {t[2 * p], t[2 * p + 1]};
-        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(y));
-        a[2 * p] = x[0];
-        a[2 * p + 1] = x[1];
-    }
-}
+// (add_tile_inplace, gemm_tile.hpp: a += t on the 16 registers of one MFMA tile IN PLACE.  As vector arithmetic hipcc put the sums into fresh scattered
+// register pairs and turned the two old tiles into the next MFMA accumulators -- the file fragments and 135 VGPRs spill; the tied asm operand keeps the sum
+// in its own registers: 230 VGPRs, no spill.  The caller provides the MFMA -> VALU wait states.)
 
 // NCB: column bands per image (1: images up to 224 wide, the tile covers the whole width).
 template <int NCB>
