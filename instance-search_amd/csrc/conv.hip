@@ -190,9 +190,9 @@ __device__ __forceinline__ void conv1x1_dual_tile(float* __restrict__ lds, const
             const int kend = kt + kConvChunk / BK < nk ? kt + kConvChunk / BK : nk;
             body(kt++, std::true_type());                      // (interleaved fold: adds the PREVIOUS chunk's chain in front of its C = 0 MFMAs)
             for (; kt < kend; ++kt) body(kt, std::false_type());
-            if (!(PINNED && ISX_FOLD_INTERLEAVE)) add_chunk<TM, TN>(tot, acc);
+            if (!((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2)) add_chunk<TM, TN>(tot, acc);
         }
-        if (PINNED && ISX_FOLD_INTERLEAVE) add_chunk<TM, TN>(tot, acc);       // the last chunk
+        if ((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2) add_chunk<TM, TN>(tot, acc);       // the last chunk
     }
     if constexpr (kConvChunk != 0) {
 #pragma unroll

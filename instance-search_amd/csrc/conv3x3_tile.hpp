@@ -108,6 +108,8 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
         // requested TWO k-tiles ahead, in two staging register sets (+16 VGPRs; the LDS stays single-staged).  An even k-tile count only (Cin a
         // multiple of 64); one trip of the loop = two k-tiles = ONE chunk of the two-level sum.
         static_assert(!AHEAD2 || CHUNK % (2 * BK) == 0, "a chunk is a whole number of trips of the two-ahead loop");
+        f32x16 (*totp2)[TN] = nullptr;
+        if constexpr (CHUNK != 0) totp2 = tot;
         float4 ra1[NA], ra2[NA], rb2[BN * BK / 1024];
         auto stage = [&](float4 (&qa)[NA], float4 (&qb)[BN * BK / 1024], int kt) {
             load_a();
@@ -126,7 +128,8 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
         // undo the prefetch); those of the last trip point past the last tap / weight column -- range-checked buffer loads, values never used.
         for (int kt = 0; kt < nk; kt += 2) {
             stage(ra2, rb2, kt + 2);
-            if (CHUNK != 0 && (kt * BK) % (CHUNK ? CHUNK : 1) == 0) mfma_ktile<TM, TN, BK, LDA, LDB, CHUNK != 0>(a_base, b_base, acc);      // chunk start: C = 0
+            if (CHUNK != 0 && (kt * BK) % (CHUNK ? CHUNK : 1) == 0)      // chunk start: C = 0 (interleaved fold: the previous chunk's chain is added in front of it)
+                mfma_ktile<TM, TN, BK, LDA, LDB, CHUNK != 0>(a_base, b_base, acc, ISX_FOLD_INTERLEAVE >= 2 ? totp2 : nullptr);
             else mfma_ktile<TM, TN, BK, LDA, LDB>(a_base, b_base, acc);
             __syncthreads();
             store_tile<BM, BK>(As, ra1);
@@ -140,9 +143,12 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
                 store_tile<BN, BK>(Bs, rb2);
                 __syncthreads();
             }
-            if constexpr (CHUNK == 2 * BK) add_chunk<TM, TN>(tot, acc);
-            else if constexpr (CHUNK != 0) { if (((kt + 2) * BK) % CHUNK == 0 || kt + 2 >= nk) add_chunk<TM, TN>(tot, acc); }
+            if constexpr (ISX_FOLD_INTERLEAVE < 2) {
+                if constexpr (CHUNK == 2 * BK) add_chunk<TM, TN>(tot, acc);
+                else if constexpr (CHUNK != 0) { if (((kt + 2) * BK) % CHUNK == 0 || kt + 2 >= nk) add_chunk<TM, TN>(tot, acc); }
+            }
         }
+        if constexpr (ISX_FOLD_INTERLEAVE >= 2 && CHUNK != 0) add_chunk<TM, TN>(tot, acc);      // the last chunk
         take_tot();
         return;
     }
@@ -177,9 +183,9 @@ __device__ __forceinline__ void conv3x3_mainloop(float* __restrict__ lds, const 
             const int kend = kt + CHUNK / BK < nk ? kt + CHUNK / BK : nk;
             body(kt++, std::true_type());                      // (interleaved fold: adds the PREVIOUS chunk's chain in front of its C = 0 MFMAs)
             for (; kt < kend; ++kt) body(kt, std::false_type());
-            if (!(PINNED && ISX_FOLD_INTERLEAVE)) add_chunk<TM, TN>(tot, acc);
+            if (!((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2)) add_chunk<TM, TN>(tot, acc);
         }
-        if (PINNED && ISX_FOLD_INTERLEAVE) add_chunk<TM, TN>(tot, acc);       // the last chunk
+        if ((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2) add_chunk<TM, TN>(tot, acc);       // the last chunk
     }
     take_tot();
 }

@@ -116,9 +116,9 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
             const int kend = kt + CHUNK / BK < nk ? kt + CHUNK / BK : nk;
             body(kt++, std::true_type());                      // (interleaved fold: adds the PREVIOUS chunk's chain in front of its C = 0 MFMAs)
             for (; kt < kend; ++kt) body(kt, std::false_type());
-            if (!(PINNED && ISX_FOLD_INTERLEAVE)) add_chunk<TM, TN>(tot, acc);
+            if (!((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2)) add_chunk<TM, TN>(tot, acc);
         }
-        if (PINNED && ISX_FOLD_INTERLEAVE) add_chunk<TM, TN>(tot, acc);       // the last chunk
+        if ((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2) add_chunk<TM, TN>(tot, acc);       // the last chunk
     }
     if constexpr (CHUNK != 0) {
 #pragma unroll

@@ -201,12 +201,25 @@ __device__ __forceinline__ void add_chunk(f32x16 (&tot)[TM][TN], const f32x16 (&
         for (int j = 0; j < TN; ++j) tot[i][j] = tot[i][j] + acc[i][j];
 }
 
+// a += t on the 16 registers of one MFMA tile IN PLACE (tied asm operands: the sum stays in a's registers, hipcc cannot rename it into fresh ones)
+__device__ __forceinline__ void add_tile_inplace(f32x16& a, const f32x16& t) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        f32x2_t x = {a[2 * p], a[2 * p + 1]};
+        const f32x2_t y = {t[2 * p], t[2 * p + 1]};
+        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(y));
+        a[2 * p] = x[0];
+        a[2 * p + 1] = x[1];
+    }
+}
+
 // MFMAs of one staged k-tile.  Small tiles (TM * TN <= 2) have too few MFMAs per k-step to hide an LDS round trip
 // behind: the operand reads of HALF a k-tile are issued back to back, then the MFMAs (counted lgkmcnt(n) waits instead
 // of a drain per step; +4 % on the trunk's 1x1 convolutions).  a_base / b_base: this lane's first operand element.
 // ZERO_C: the first k-step starts new chains (C = 0 as an inline constant; the old contents of acc are dead): chunk start of the two-level sum.
 template <int TM, int TN, int BK, int LDA, int LDB, bool ZERO_C = false>
-__device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, const float* __restrict__ b_base, f32x16 (&acc)[TM][TN]) {
+__device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, const float* __restrict__ b_base, f32x16 (&acc)[TM][TN], f32x16 (*tot)[TN] = nullptr) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (TM * TN <= 2 && !ISX_SIMPLE_KLOOP) {
 #pragma unroll
@@ -224,8 +237,10 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, con
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j) {
+                        if (ZERO_C && h == 0 && kk == 0 && tot) add_tile_inplace(tot[i][j], acc[i][j]);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i], bf[kk][j], (ZERO_C && h == 0 && kk == 0) ? zero : acc[i][j], 0, 0, 0);
+                    }
         }
     } else if (ISX_KLOOP_PREFETCH) {
         // register prefetch one k-step ahead: the operand reads of step kk + 1 are issued BEFORE the MFMAs of step kk, so a wave
@@ -247,8 +262,10 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, con
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
+                for (int j = 0; j < TN; ++j) {
+                    if (ZERO_C && kk == 0 && tot) add_tile_inplace(tot[i][j], acc[i][j]);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], (ZERO_C && kk == 0) ? zero : acc[i][j], 0, 0, 0);
+                }
         }
     } else {
 #pragma unroll
@@ -261,7 +278,10 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ a_base, con
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], (ZERO_C && kk == 0) ? zero : acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if (ZERO_C && kk == 0 && tot) add_tile_inplace(tot[i][j], acc[i][j]);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], (ZERO_C && kk == 0) ? zero : acc[i][j], 0, 0, 0);
+                }
         }
     }
 }
@@ -294,19 +314,6 @@ __device__ __forceinline__ KtilePtrs<BK> pin_ktile_ptrs(const float* a_base, con
     return p;
 }
 // the k loop of mfma_ktile's prefetch variant on pinned addresses
-// a += t on the 16 registers of one MFMA tile IN PLACE (tied asm operands: the sum stays in a's registers, hipcc cannot rename it into fresh ones)
-__device__ __forceinline__ void add_tile_inplace(f32x16& a, const f32x16& t) {
-    typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        f32x2_t x = {a[2 * p], a[2 * p + 1]};
-        const f32x2_t y = {t[2 * p], t[2 * p + 1]};
-        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(x) : "v"(y));
-        a[2 * p] = x[0];
-        a[2 * p + 1] = x[1];
-    }
-}
-
 // tot (ZERO_C only, ISX_FOLD_INTERLEAVE): the chain that ended with the previous k-tile is added to tot tile by tile right in front of the MFMA that
 // restarts that tile from C = 0 -- the adds of tile n + 1 issue while the MFMA of tile n runs.  (The MFMAs that produced acc are at least one
 // barrier old: no MFMA -> VALU wait states needed.)
@@ -368,6 +375,6 @@ template <int TM, int TN, int BK, int LDA, int LDB, bool PINNED, bool ZERO_C = f
 __device__ __forceinline__ void mfma_ktile_sel(const float* __restrict__ a_base, const float* __restrict__ b_base, const KtilePtrs<BK>& pins, f32x16 (&acc)[TM][TN],
                                                f32x16 (*tot)[TN] = nullptr) {
     if constexpr (PINNED) mfma_ktile_pinned<TM, TN, BK, ZERO_C>(pins, acc, ISX_FOLD_INTERLEAVE ? tot : nullptr);
-    else mfma_ktile<TM, TN, BK, LDA, LDB, ZERO_C>(a_base, b_base, acc);
+    else mfma_ktile<TM, TN, BK, LDA, LDB, ZERO_C>(a_base, b_base, acc, ISX_FOLD_INTERLEAVE >= 2 ? tot : nullptr);
 }
 }  // namespace isx
