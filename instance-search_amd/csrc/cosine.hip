@@ -134,6 +134,15 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
                                       half, thr);
         return;
     }
+    if (EPI == 2 && TM * TN == 4 && ISX_EPI_LDS) {
+        // 128x128 convolution tiles: float4 epilogue through a wave-private LDS transpose (gemm_tile.hpp) when the shapes allow 16-B accesses
+        const float* res = reinterpret_cast<const float*>(gflag);
+        if ((N & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)C | (uintptr_t)(res ? res : C) | (uintptr_t)thr) & 15) == 0) {        // uniform
+            conv_epilogue_lds<TM, TN>(acc, lds + (threadIdx.x >> 6) * (32 * TM) * (32 * TN + 4), C, res, thr, ngrp, m0, M, n0, N, ldc, BM, wm_u * (32 * TM),
+                                      wn_u * (32 * TN), lane);
+            return;
+        }
+    }
     if (EPI == 2) {
         // Convolution epilogue through BUFFER instructions: a wave-uniform descriptor of the tile's rows (clipped at row M by the
         // hardware), one 32-bit lane offset per 32x32 MFMA tile (a column >= N gets an offset outside the descriptor: its loads return
@@ -230,7 +239,8 @@ __global__ __launch_bounds__(256, EPI != 2 ? 1 : TM * TN == 4 ? ISX_WG_PER_CU_12
                                                           float* __restrict__ C, int64_t ldc, TileMap tm,
                                                           const float* __restrict__ thr, uint8_t* __restrict__ gflag,
                                                           int ngrp) {
-    __shared__ float lds[BK * (64 * TM + 64 * TN + 2 * lds_pad(BK))];
+    constexpr int kStage = BK * (64 * TM + 64 * TN + 2 * lds_pad(BK)), kEpi = (EPI == 2 && TM * TN == 4 && ISX_EPI_LDS) ? epilogue_lds_floats<TM, TN>() : 0;
+    __shared__ float lds[kStage > kEpi ? kStage : kEpi];
     int tile_m, tile_n;
     tile_of_block(tm, tile_m, tile_n);
     const int64_t m0 = (int64_t)tile_m * (64 * TM), n0 = (int64_t)tile_n * (64 * TN);
@@ -245,7 +255,7 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_tail_kernel(const float* __restrict__ Q, int64_t M, const float* __restrict__ G, int64_t N, int D,
                                                               float* __restrict__ C, int64_t ldc, TileMap tm_big, TileMap tm_small, int64_t m_split,
                                                               const float* __restrict__ bias, uint8_t* __restrict__ res, int relu) {
-    constexpr int kBig = 16 * (128 + 128 + 2 * lds_pad(16));
+    constexpr int kBig0 = 16 * (128 + 128 + 2 * lds_pad(16)), kEpi = ISX_EPI_LDS ? epilogue_lds_floats<2, 2>() : 0, kBig = kBig0 > kEpi ? kBig0 : kEpi;
     __shared__ float lds[kBig > kTailLdsFloats ? kBig : kTailLdsFloats];
     const int nbig = tm_big.tiles_m * tm_big.tiles_n;                 // a multiple of 8: a block's XCD is the same in both numberings
     int tile_m, tile_n;

@@ -175,6 +175,51 @@ __device__ __forceinline__ void conv_epilogue_buffers(const f32x16 (&acc)[TM][TN
     }
 }
 
+// Convolution epilogue through the LDS (round 5): the C layout of the 32x32 MFMA gives a lane ONE column and 16 scattered rows -- 4-byte stores,
+// a wave instruction covers 2 rows x 128 B.  Here every wave parks its TM x TN tiles in a wave-private LDS region as a row-major (32 TM) x
+// (32 TN) image and reads it back as float4 along the rows: residual loads and stores are 16 B per lane, a wave instruction covers 64 / (8 TN)
+// rows x 128 TN B -- a quarter of the memory instructions, twice the contiguous run.  The residual is requested before the transpose.
+// wl: this wave's (32 TM) x (32 TN + 4) floats (the +4 keeps rows 16-B aligned and the transposed reads conflict-light); needs N % 4 == 0,
+// ldc % 4 == 0 and 16-B aligned C / res (the caller checks); same arithmetic per element as conv_epilogue_buffers: y = act(acc + bias (+ res)).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue_lds(const f32x16 (&acc)[TM][TN], float* __restrict__ wl, float* __restrict__ C, const float* __restrict__ res,
+                                                  const float* __restrict__ bias, int relu, int64_t m0, int64_t M, int64_t n0, int64_t N, int64_t ldc, int BM,
+                                                  int row0, int col0, int lane) {
+    constexpr int LDW = 32 * TN + 4, LPR = 8 * TN, RPI = 64 / LPR, NIT = 32 * TM / RPI;       // lanes per row, rows per instruction, instructions
+    const int l31 = lane & 31, half = lane >> 5;
+    const int r4 = lane / LPR, c4 = lane % LPR;
+    const auto rc = conv_tile_rsrc(C, m0, M, ldc, BM);
+    const auto rr = conv_tile_rsrc(res ? res : C, m0, M, ldc, BM);
+    const int64_t col = n0 + col0 + 4 * c4;
+    const unsigned lo = col < N ? (unsigned)(((row0 + r4) * ldc + col) * 4) : 0x80000000u;
+    float4 rv[NIT];
+    if (res) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            rv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rr, lo, (unsigned)(it * RPI * ldc * 4), 0));
+    }
+    const float4 b4 = (bias && col < N) ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) wl[(i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half) * LDW + j * 32 + l31] = acc[i][j][e];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        float4 v = *reinterpret_cast<const float4*>(wl + (it * RPI + r4) * LDW + 4 * c4);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        if (res) { v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w; }
+        if (relu) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rc, lo, (unsigned)(it * RPI * ldc * 4), 0);
+    }
+}
+template <int TM, int TN>
+constexpr int epilogue_lds_floats() { return 4 * (32 * TM) * (32 * TN + 4); }
+#ifndef ISX_EPI_LDS
+#define ISX_EPI_LDS 0        // A/B (round 5): float4 epilogue through an LDS transpose: bit-identical, NO gain (1x1 lab 10.96 vs 10.91 ms) -- store width is not what limits the short-K layers
+#endif
+
 // ---- two-level accumulation of the trunk convolutions (round 5) -----------------------------------------------------------------
 // A convolution output is NOT one fp32 chain over the whole reduction any more: the flattened reduction (kh, kw, ci) is cut into chunks of
 // ISX_CONV_CHUNK terms; inside a chunk the k-ordered fma chain of the matrix core starts from +0, and the chunk sums are added, in order, into
