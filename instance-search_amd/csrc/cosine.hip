@@ -268,6 +268,97 @@ __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_tail_kernel(co
     }
 }
 
+// ---- PERSISTENT 128x128 tiles for the 1x1 convolutions (round 5) ----------------------------------------------------------------------------------
+// A short-K layer (K = 128 ... 512: 8 ... 32 k-tiles) pays the fill of its load pipeline once per TILE: the first k-tile's operands take an
+// HBM / L2 round trip (~2 us) before the first MFMA can issue, a quarter of a K = 128 tile's matrix time, and two workgroups per CU cannot
+// hide it for each other (128 -> 512 + residual at 28x28: 0.62 of its own roofline, neither HBM- nor MFMA-bound).  Here 512 workgroups
+// (two per CU) each walk tiles b, b + G, b + 2 G, ... of the same XCD-aware order, and the operands of the NEXT tile's first k-tile are
+// requested before the current tile's epilogue: they land while the epilogue's loads and stores are in flight.  The staging registers are
+// free at that point, so the prefetch costs none.  Same arithmetic per output element as cosine_gemm_tile<..., EPI 2>.
+// MEASURED: bit-identical and 4 % slower than one workgroup per tile (see launch_gemm_any): kept as an A/B (ISX_CONV_PERSIST=1), not dispatched.
+template <bool ALIGNED>
+__global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_persist_kernel(const float* __restrict__ Q, int64_t M, const float* __restrict__ G, int64_t N, int D,
+                                                                                float* __restrict__ C, int64_t ldc, TileMap tm, int ntiles, TileMap tm_small,
+                                                                                int64_t m_split, const float* __restrict__ bias, const float* __restrict__ res,
+                                                                                int relu) {
+    constexpr int TM = 2, TN = 2, BK = 16, BM = 128, BN = 128, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK), CHUNK = kConvChunk;
+    __shared__ float lds[BK * (LDA + LDB)];
+    float* As = lds;
+    float* Bs = lds + BK * LDA;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
+    const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
+    const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
+    constexpr bool PINNED = CHUNK != 0 && ISX_PIN_KTILE;
+    KtilePtrs<BK> pins;
+    if constexpr (PINNED) pins = pin_ktile_ptrs<BK, LDA, LDB>(a_base, b_base);
+    const int nk = (D + BK - 1) / BK;
+
+    float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
+    int t = (int)blockIdx.x;
+    int tile_m = 0, tile_n = 0;
+    if (t < ntiles) {
+        tile_of_block(tm, tile_m, tile_n, t, ntiles);
+        load_tile<ALIGNED, BM, BK>(Q, M, D, (int64_t)tile_m * BM, 0, ra);
+        load_tile<ALIGNED, BN, BK>(G, N, D, (int64_t)tile_n * BN, 0, rb);
+    }
+    for (; t < ntiles; t += (int)gridDim.x) {
+        const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
+        f32x16 acc[TM][TN], tot[CHUNK ? TM : 1][CHUNK ? TN : 1];
+        zero_tiles(acc);
+        zero_tiles(tot);
+        store_tile<BM, BK>(As, ra);
+        store_tile<BN, BK>(Bs, rb);
+        __syncthreads();
+        f32x16 (*totp)[TN] = nullptr;
+        if constexpr (CHUNK != 0) totp = tot;
+        auto body = [&](int kt, auto zero_c) {
+            const bool more = (kt + 1 < nk);
+            if (more) {
+                load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
+                load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
+            }
+            mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc, totp);
+            __syncthreads();
+            if (more) {
+                store_tile<BM, BK>(As, ra);
+                store_tile<BN, BK>(Bs, rb);
+                __syncthreads();
+            }
+        };
+        if constexpr (CHUNK == 0) {
+            for (int kt = 0; kt < nk; ++kt) body(kt, std::false_type());
+        } else {
+            for (int kt = 0; kt < nk;) {
+                const int kend = kt + CHUNK / BK < nk ? kt + CHUNK / BK : nk;
+                body(kt++, std::true_type());
+                for (; kt < kend; ++kt) body(kt, std::false_type());
+                if (!((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2)) add_chunk<TM, TN>(tot, acc);
+            }
+            if ((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2) add_chunk<TM, TN>(tot, acc);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];
+        }
+        // the next tile's first operands: on their way while this tile's epilogue runs (every wave has left the LDS: the loop ended on a barrier)
+        const int tn = t + (int)gridDim.x;
+        if (tn < ntiles) {
+            tile_of_block(tm, tile_m, tile_n, tn, ntiles);
+            load_tile<ALIGNED, BM, BK>(Q, M, D, (int64_t)tile_m * BM, 0, ra);
+            load_tile<ALIGNED, BN, BK>(G, N, D, (int64_t)tile_n * BN, 0, rb);
+        }
+        conv_epilogue_buffers<TM, TN>(acc, C, res, bias, relu, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31, half);
+    }
+    // rows past the last whole round of 128x128 tiles: 64x64 tiles (conv1x1_tail_kernel's scheme), spread over the same workgroups
+    const int nsmall = tm_small.tiles_m * tm_small.tiles_n;
+    for (int ts = (int)blockIdx.x; ts < nsmall; ts += (int)gridDim.x) {
+        tile_of_block(tm_small, tile_m, tile_n, ts, nsmall);
+        cosine_gemm_tile<ALIGNED, 1, 1, 2, 32>(lds, Q, M, G, N, D, C, ldc, m_split + (int64_t)tile_m * 64, (int64_t)tile_n * 64, bias, (uint8_t*)res, relu);
+    }
+}
+
 // rows covered by whole rounds of 128x128 tiles when the rest of the grid is a partial round (0: no split)
 std::atomic<int> g_tail_split{1};
 int64_t gemm_tail_split_rows(int64_t M, int64_t N, int64_t slots) {
@@ -372,6 +463,24 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
             ISX_CHECK_LAUNCH("cosine_gemm");
             return ISX_OK;
         }
+    }
+    // A/B (round 5), OFF by default: persistent workgroups with the next tile's first operands prefetched across the epilogue are
+    // 4 % SLOWER on the ten 1x1 shapes of the lab (11.37 vs 10.90 ms; 128 -> 512 + residual 1.10 vs 1.07): the hardware dispatcher's dynamic
+    // placement of one workgroup per tile beats the static walk, and the pipeline fill of a tile is not what the short-K layers wait for.
+    static const bool use_persist = [] { const char* e = getenv("ISX_CONV_PERSIST"); return e && e[0] == '1'; }();
+    if (epi == 2 && best == 0 && use_persist && (g_force_cfg < 0 || g_force_cfg == 0)) {
+        TileMap tmap, small;
+        tmap.m_active = small.m_active = nullptr;
+        tmap.tiles_m = (int)((split > 0 ? split : M + 127) / 128); tmap.tiles_n = (int)((N + 127) / 128);
+        small.tiles_m = split > 0 ? (int)((M - split + 63) / 64) : 0; small.tiles_n = (int)((N + 63) / 64);
+        const int ntiles = tmap.tiles_m * tmap.tiles_n;
+        const int slots = 256 * ISX_WG_PER_CU_128;
+        const int want = ntiles + small.tiles_m * small.tiles_n;
+        const dim3 grid((unsigned)(want < slots ? want : slots)), block(256);
+        if (aligned) hipLaunchKernelGGL((conv1x1_persist_kernel<true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tmap, ntiles, small, split, thr, (const float*)gmax, relu);
+        else hipLaunchKernelGGL((conv1x1_persist_kernel<false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tmap, ntiles, small, split, thr, (const float*)gmax, relu);
+        ISX_CHECK_LAUNCH("conv1x1_persist");
+        return ISX_OK;
     }
     if (best == 0 && split > 0) {
         TileMap big, small;
