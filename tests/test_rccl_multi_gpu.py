@@ -58,6 +58,12 @@ def test_rccl_sharded_search_and_grad_allreduce(tmp_path):
     if "tree" in r[0]:
         for k in range(world):
             assert torch.equal(r[k]["tree"], r[0]["tree_ref"]), k                # TreeExchange over RCCL == the single-process tree sum, bit for bit
+    if "shard_ref" in r[0]:
+        y_ref, dx_ref, w_ref = r[0]["shard_ref"]                                # the head sharded by output features == one GPU's unsharded kernels
+        for k in range(world):
+            n = r[k]["shard_y"].size(0)
+            assert torch.equal(r[k]["shard_y"], y_ref[k * n:(k + 1) * n]) and torch.equal(r[k]["shard_dx"], dx_ref[k * n:(k + 1) * n]), k
+            assert torch.equal(r[k]["shard_w"], w_ref), k
             assert torch.equal(r[k]["rows_dw"], r[k]["rows_ref"]), k             # head weight gradient from all-gathered rows == the one-process GEMM
     assert float(r[0]["flat"].abs().sum()) > 0
 
