@@ -22,6 +22,43 @@ class TinyNet(nn.Module):
         return y / (y.pow(2).sum(1, keepdim=True) + 1e-10).sqrt()
 
 
+def shard_head_case(rank, world, dev, res):
+    from isx import dp, ops
+    # ---- the descriptor head sharded by output features (isx/shard_head.py): all-gathers of rows / column slices, all-to-all of the input
+    #      gradient's group chains, per-shard fused gradient + SGD, sync of the weight -- over RCCL, against one GPU's unsharded kernels ----
+    from isx import shard_head
+    if dp.is_power_of_two(world) and shard_head.GROUPS % world == 0:
+        from isx._lib import check, lib
+        g3 = torch.Generator().manual_seed(123)
+        n_out, K, Rr = 256, 1280, 6
+        W0, b0 = torch.randn(n_out, K, generator=g3) * 0.01, torch.randn(n_out, generator=g3)
+        x_all, dy_all = torch.randn(Rr * world, K, generator=g3).to(dev), torch.randn(Rr * world, n_out, generator=g3).to(dev)
+        kw = dict(lr=1e-2, momentum=0.9, weight_decay=5e-4)
+        w, bias = torch.nn.Parameter(W0.clone().to(dev)), torch.nn.Parameter(b0.clone().to(dev))
+        opt = torch.optim.SGD([w], **kw)
+        sh = shard_head.HeadShard(w, bias)
+        rows = slice(Rr * rank, Rr * rank + Rr)
+        for step in range(2):                                   # the second step runs on momentum buffers and on the synced weight
+            sh.begin_step(1)
+            y, ctx = sh.forward(x_all[rows], [rank])
+            dx = sh.backward(ctx, dy_all[rows])
+            sh.finish(opt)
+            sh.sync()
+        res["shard_y"], res["shard_dx"], res["shard_w"] = y.cpu(), dx.cpu(), w.detach().cpu()
+        if rank == 0:
+            wr = torch.nn.Parameter(W0.clone().to(dev))
+            optr = torch.optim.SGD([wr], **kw)
+            for step in range(2):
+                y_ref = ops.head_linear(x_all, wr.detach(), b0.to(dev))
+                M = x_all.size(0)
+                Mp = (M + 63) // 64 * 64
+                dyT = dy_all.new_zeros((n_out, Mp)); dyT[:, :M] = dy_all.t()
+                dx_ref = torch.empty((Mp, K), device=dev)
+                check(lib().isx_head_linear_dgrad(dyT.data_ptr(), Mp, n_out, wr.data_ptr(), K, dx_ref.data_ptr(), torch.cuda.current_stream().cuda_stream), "dgrad")
+                assert dp.fused_sgd_from_rows(optr, wr, dy_all, x_all)
+            res["shard_ref"] = (y_ref.cpu(), dx_ref[:M].cpu(), wr.detach().cpu())
+
+
 def main():
     out = sys.argv[1]
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
@@ -31,6 +68,10 @@ def main():
     from isx import ops, retrieval as R
     from isx.dp import GradAllReducer, broadcast_module_state
     res = {}
+    if os.environ.get("ISX_WORKER_CASE") == "shard_head":                       # one-rank rehearsal of the last section on a one-GPU box
+        shard_head_case(rank, world, dev, res)
+        torch.save(res, "%s.%d" % (out, rank))
+        return dist.destroy_process_group()
     # ---- sharded gallery search: torch.distributed (RCCL) exchange and libisx's own RCCL communicator ----
     g = torch.Generator().manual_seed(0)
     N, D, k, M = 40007, 256, 100, 300
@@ -105,39 +146,7 @@ def main():
         sink.finish()
         res["rows_dw"] = w.grad.cpu()
         res["rows_ref"] = dp.weight_gradient_from_rows(dyr, xr).cpu()
-    # ---- the descriptor head sharded by output features (isx/shard_head.py): all-gathers of rows / column slices, all-to-all of the input
-    #      gradient's group chains, per-shard fused gradient + SGD, sync of the weight -- over RCCL, against one GPU's unsharded kernels ----
-    from isx import shard_head
-    if dp.is_power_of_two(world) and shard_head.GROUPS % world == 0:
-        from isx._lib import check, lib
-        g3 = torch.Generator().manual_seed(123)
-        n_out, K, Rr = 256, 1280, 6
-        W0, b0 = torch.randn(n_out, K, generator=g3) * 0.01, torch.randn(n_out, generator=g3)
-        x_all, dy_all = torch.randn(Rr * world, K, generator=g3).to(dev), torch.randn(Rr * world, n_out, generator=g3).to(dev)
-        kw = dict(lr=1e-2, momentum=0.9, weight_decay=5e-4)
-        w, bias = torch.nn.Parameter(W0.clone().to(dev)), torch.nn.Parameter(b0.clone().to(dev))
-        opt = torch.optim.SGD([w], **kw)
-        sh = shard_head.HeadShard(w, bias)
-        rows = slice(Rr * rank, Rr * rank + Rr)
-        for step in range(2):                                   # the second step runs on momentum buffers and on the synced weight
-            sh.begin_step(1)
-            y, ctx = sh.forward(x_all[rows], [rank])
-            dx = sh.backward(ctx, dy_all[rows])
-            sh.finish(opt)
-            sh.sync()
-        res["shard_y"], res["shard_dx"], res["shard_w"] = y.cpu(), dx.cpu(), w.detach().cpu()
-        if rank == 0:
-            wr = torch.nn.Parameter(W0.clone().to(dev))
-            optr = torch.optim.SGD([wr], **kw)
-            for step in range(2):
-                y_ref = ops.head_linear(x_all, wr.detach(), b0.to(dev))
-                M = x_all.size(0)
-                Mp = (M + 63) // 64 * 64
-                dyT = dy_all.new_zeros((n_out, Mp)); dyT[:, :M] = dy_all.t()
-                dx_ref = torch.empty((Mp, K), device=dev)
-                check(lib().isx_head_linear_dgrad(dyT.data_ptr(), Mp, n_out, wr.data_ptr(), K, dx_ref.data_ptr(), torch.cuda.current_stream().cuda_stream), "dgrad")
-                assert dp.fused_sgd_from_rows(optr, wr, dy_all, x_all)
-            res["shard_ref"] = (y_ref.cpu(), dx_ref[:M].cpu(), wr.detach().cpu())
+    shard_head_case(rank, world, dev, res)
     torch.save(res, "%s.%d" % (out, rank))
     dist.barrier()
     torch.cuda.synchronize()

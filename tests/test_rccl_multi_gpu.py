@@ -80,3 +80,17 @@ def test_bench_two_gpus_bare_command_line():
     d = json.loads(lines[1])
     assert "isx_shard_topk_allgather" in d["exchange"]["implementation"] and d["exchange"]["overlap_identical"] is True
     assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 2 and d["value"] > 0
+
+
+def test_shard_head_worker_one_rank(tmp_path):
+    """The sharded-head section of the worker on ONE rank (an RCCL group of one): keeps that code exercised on a one-GPU box."""
+    if _n_gpus() < 1:
+        pytest.skip("no GPU")
+    out = str(tmp_path / "r")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rccl_worker.py"), out]
+    p = subprocess.run(cmd, env=dict(_env(), ISX_WORKER_CASE="shard_head"), cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    r = torch.load(out + ".0")
+    y_ref, dx_ref, w_ref = r["shard_ref"]
+    assert torch.equal(r["shard_y"], y_ref) and torch.equal(r["shard_dx"], dx_ref) and torch.equal(r["shard_w"], w_ref)
