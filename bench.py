@@ -756,13 +756,26 @@ def main():
             with ThreadPoolExecutor(max_workers=workers) as pool:
                 list(pool.map(write, range(n_files)))
             file_bytes = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp)) / float(n_files)
-            load = lambda f: C.to_raw_tensor(C.imread_rgb(f))
+            load = C.ImageLoader(raw=True)
             files = [os.path.join(tmp, "%05d.jpg" % (i % n_files)) for i in range(n)]
-            t0_ = time.perf_counter()
-            with ThreadPoolExecutor(max_workers=workers) as pool:
-                for _ in pool.map(load, files[:4096]):
-                    pass
-            decode_only = 4096 / (time.perf_counter() - t0_)
+            from train import _decode_farm as DF
+            farm = DF.decode_farm()
+            if farm is not None:                                   # decoder processes alone: files -> shared slots, nothing copied out
+                for t in farm.submit(files[:256], 224 * 224 * 3):
+                    t.tensor(); t.release()
+                t0_ = time.perf_counter()
+                pending = [farm.submit(files[a:a + 512], 224 * 224 * 3) for a in range(0, 4096, 512)]
+                for tickets in pending:
+                    for t in tickets:
+                        t.tensor(); t.release()
+                decode_only = 4096 / (time.perf_counter() - t0_)
+                workers = farm.n
+            else:
+                t0_ = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=workers) as pool:
+                    for _ in pool.map(load, files[:4096]):
+                        pass
+                decode_only = 4096 / (time.perf_counter() - t0_)
             first = load(files[0])
             data = [(TC.LazyImage(f, load, first.shape, first.dtype), "l%d" % (i % 100), f) for i, f in enumerate(files)]
             P = cf.P
@@ -789,9 +802,10 @@ def main():
         rate = n / t_pipe
         ips = world * B * args.steps / dt                      # the headline rate of this run (inputs resident in HBM)
         return {"images": n, "files": n_files, "format": "JPEG 224x224 quality 90, %.0f KB per file, PIL decode" % (file_bytes / 1e3), "cores": workers,
+                "decoders": "processes (train/_decode_farm.py)" if farm is not None else "threads",
                 "images_per_s": rate, "decode_only_images_per_s": decode_only, "decode_bound": bool(rate < 0.9 * ips),
                 "fraction_of_resident_rate": rate / ips, "descriptors_identical_to_decode_first": same,
-                "path": "test._common.load_sets(lazy) form: LazyImage -> decode pool (3 batches ahead) -> BatchStager pinned staging -> copy stream -> trunk"}
+                "path": "test._common.load_sets(lazy) form: LazyImage -> decoder processes (3 batches ahead, shared slots) -> BatchStager pinned staging -> copy stream -> trunk"}
 
     if args.ingest_images > 0 and rank == 0 and args.backbone_dtype == "f32" and not args.no_fold_bn:
         try:

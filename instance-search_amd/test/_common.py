@@ -56,6 +56,22 @@ def to_raw_tensor(img):
     return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
 
 
+class ImageLoader(object):
+    """file name -> image tensor: the raw (H,W,3) uint8 pixels (raw=True, normalised later on the GPU) or the normalised (3,H,W) float tensor of
+    the reference's ToTensor + Normalize.  `farm_kind` tells the decoders of train/_decode_farm.py that the file is read as plain 8-bit RGB, so
+    the read may happen in a decoder process and `from_u8` finish it here."""
+    farm_kind = "rgb_u8"
+
+    def __init__(self, mean=None, std=None, raw=False):
+        self.mean, self.std, self.raw = mean, std, bool(raw)
+
+    def from_u8(self, u8):
+        return u8 if self.raw else to_normalised_tensor(u8.numpy(), self.mean, self.std)
+
+    def __call__(self, fname):
+        return self.from_u8(to_raw_tensor(imread_rgb(fname)))
+
+
 def load_sets(dataset_full, labels, raw=False, lazy=None):
     """(test_set, test_train_set) as lists of (normalised tensor, label, path); fills `labels`
     with the sorted label set of the reference (gallery) images; queries whose label is
@@ -79,9 +95,9 @@ def load_sets(dataset_full, labels, raw=False, lazy=None):
     if raw:
         from train import _common as TC
         TC.RAW_INGEST["mean"], TC.RAW_INGEST["std"] = list(mean), list(std)
-        load = lambda f: to_raw_tensor(imread_rgb(f))
+        load = ImageLoader(raw=True)
     else:
-        load = lambda f: to_normalised_tensor(imread_rgb(f), mean, std)
+        load = ImageLoader(mean, std)
     if lazy is None:
         lazy = raw and os.environ.get("ISX_LAZY_INGEST", "1") != "0"
     if lazy and ref_files:
@@ -95,15 +111,29 @@ def load_sets(dataset_full, labels, raw=False, lazy=None):
     return qry, ref
 
 
+FARM_MIN_FILES = int(os.environ.get("ISX_DECODE_FARM_MIN", "64"))
+
+
 def _decode_all(load, files):
-    """[load(f) for f in files], file order kept, decoded on a pool of threads (PIL's decoders release the GIL): the reference reads its
-    folders one image at a time (test/classif_finetune_test.py:62-73), which is what a GPU test run then waits for.  ISX_DECODE_THREADS=1
-    restores the sequential read."""
-    import os
+    """[load(f) for f in files], file order kept.  The reference reads its folders one image at a time on the main thread
+    (test/classif_finetune_test.py:62-73), which is what a GPU test run then waits for; here the files of an ImageLoader go to the decoder
+    processes of train/_decode_farm.py (a thread pool does not scale: the decode of a small JPEG is mostly Python under the GIL) and only the
+    float conversion of the non-raw form runs on threads.  ISX_DECODE_PROCS=0 keeps everything on threads, ISX_DECODE_THREADS=1 sequential."""
+    files = list(files)
     workers = int(os.environ.get("ISX_DECODE_THREADS", "0")) or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
     if workers <= 1 or len(files) < 2 * workers:
         return [load(f) for f in files]
     from concurrent.futures import ThreadPoolExecutor
+    if getattr(load, "farm_kind", None) == "rgb_u8" and len(files) >= FARM_MIN_FILES:
+        from train import _decode_farm as DF
+        if DF.decode_farm() is not None:
+            first = to_raw_tensor(imread_rgb(files[0]))
+            slot = max(1 << 20, 2 * first.numel())            # ragged folders: a file larger than the slot is decoded in this process (Ticket.tensor)
+            u8 = DF.decode_files(files, slot)
+            if load.raw:
+                return u8
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                return list(pool.map(load.from_u8, u8))
     with ThreadPoolExecutor(max_workers=workers) as pool:
         return list(pool.map(load, files))
 

@@ -34,7 +34,7 @@ def normalise_u8_batch(x_u8, device):
 # Lazy ingest: the reference decodes a whole folder into a Python list before the first launch
 # (test/classif_finetune_test.py:62-73, utils/image.py:211-214); a 1 M-image gallery is 150 GB of decoded pixels -- more than the host has -- and
 # the GPU waits for the last file before it sees the first.  A folder dataset can instead carry LazyImage entries: the usual (image, label, path)
-# tuples whose image is decoded when a batch needs it, on a pool of threads (PIL's decoders release the GIL), a bounded number of batches ahead
+# tuples whose image is decoded when a batch needs it, by a farm of decoder processes (train/_decode_farm.py), a bounded number of batches ahead
 # of the trunk (BatchStager) and dropped once stacked into the pinned staging buffer.  Labels and paths are plain as ever.
 _DECODE_POOL = None
 
@@ -53,30 +53,63 @@ def _decode_pool():
 
 class LazyImage(object):
     """Stands where the image tensor of a (image, label, path) tuple stands; `shape` / `dtype` are those of the decoded image (all images of a
-    lazy set share them -- the reference's datasets are pre-sized, train/global_p.py image_sizes), `get()` returns the tensor."""
+    lazy set share them -- the reference's datasets are pre-sized, train/global_p.py image_sizes), `get()` returns the tensor.
+    A loader that reads plain 8-bit RGB (`load.farm_kind == "rgb_u8"`, test/_common.ImageLoader) is served by the decoder PROCESSES of
+    train/_decode_farm.py -- get() is then a view of a shared slot, valid until release(); any other loader runs on the thread pool."""
     __slots__ = ("path", "load", "shape", "dtype", "_fut")
     is_cuda = False
 
     def __init__(self, path, load, shape, dtype):
         self.path, self.load, self.shape, self.dtype, self._fut = path, load, tuple(shape), dtype, None
 
-    def _decode(self):
-        t = self.load(self.path)
+    def _check(self, t):
         if tuple(t.shape) != self.shape or t.dtype != self.dtype:
             raise RuntimeError("lazy ingest needs same-sized images: %s is %s %s, the set's first image %s %s (ISX_LAZY_INGEST=0 decodes ragged folders up front)"
                                % (self.path, tuple(t.shape), t.dtype, self.shape, self.dtype))
         return t
 
+    def _decode(self):
+        return self._check(self.load(self.path))
+
+    def farmed(self):
+        return getattr(self.load, "farm_kind", None) == "rgb_u8" and getattr(self.load, "raw", False) and self.dtype == torch.uint8
+
     def prefetch(self):
         if self._fut is None:
-            self._fut = _decode_pool().submit(self._decode)
+            prefetch_all([self])
+
+    def shared(self):
+        """True when get() returns a view of a decoder slot (to be copied out before release())."""
+        return self._fut is not None and not hasattr(self._fut, "cancel")
 
     def get(self):
         self.prefetch()
-        return self._fut.result()
+        return self._check(self._fut.result()) if self.shared() else self._fut.result()
 
     def release(self):
+        if self._fut is not None and self.shared():
+            self._fut.release()
         self._fut = None
+
+
+def prefetch_all(ims):
+    """Hand every not-yet-requested LazyImage of `ims` to the decoders: one submission to the process farm for the plain RGB loaders (chunks of
+    files per worker), the thread pool for the rest."""
+    todo = [im for im in ims if isinstance(im, LazyImage) and im._fut is None]
+    farmed = [im for im in todo if im.farmed()]
+    if farmed:
+        from ._decode_farm import decode_farm
+        farm = decode_farm()
+        if farm is not None:
+            by_bytes = {}
+            for im in farmed:
+                by_bytes.setdefault(im.shape[0] * im.shape[1] * im.shape[2], []).append(im)
+            for nbytes, group in by_bytes.items():
+                for im, t in zip(group, farm.submit([im.path for im in group], nbytes)):
+                    im._fut = t
+    for im in todo:
+        if im._fut is None:
+            im._fut = _decode_pool().submit(im._decode)
 
 
 def is_lazy(dataset):
@@ -87,10 +120,14 @@ def resolve_images(ims):
     """Tensors of a list of images, LazyImage entries decoded (in parallel) and released."""
     if not any(isinstance(im, LazyImage) for im in ims):
         return ims
+    prefetch_all(ims)
+    out = []
     for im in ims:
         if isinstance(im, LazyImage):
-            im.prefetch()
-    out = [im.get() if isinstance(im, LazyImage) else im for im in ims]
+            t = im.get()
+            out.append(t.clone() if im.shared() else t)          # a decoder slot is recycled after release()
+        else:
+            out.append(im)
     for im in ims:
         if isinstance(im, LazyImage):
             im.release()
@@ -255,14 +292,14 @@ class BatchStager(object):
         if self.lazy:
             # decode-ahead: the files of this batch and of the next two are with the decoder threads before this call blocks on the first image --
             # batch i + 2 is being decoded while batch i + 1 is stacked / copied and the trunk runs batch i; at most three batches are decoded in RAM
-            for im, _, _ in self.dataset[start:start + 3 * self.bs]:
-                im.prefetch()
+            prefetch_all([im for im, _, _ in self.dataset[start:start + 3 * self.bs]])
             lazy_chunk, chunk = chunk, [im.get() for im in chunk]
-            for im in lazy_chunk:
-                im.release()
         if self.copied[slot] is not None:
             self.copied[slot].synchronize()                      # the pinned buffer is free once its previous copy has left it
         _parallel_stack(chunk, self.host[slot])
+        if self.lazy:
+            for im in lazy_chunk:
+                im.release()                                     # decoder slots go back once their pixels are in the pinned buffer
         with torch.cuda.stream(self.copy_stream):
             if self.consumed[slot] is not None:
                 self.copy_stream.wait_event(self.consumed[slot])  # the device buffer is free once its previous readers have run
