@@ -103,6 +103,24 @@ def test_suffix_engine_matches_float64_autograd(which, B):
         assert _rel(p.grad, 2 * g0) <= 1e-6
 
 
+def test_post_accumulate_hooks_fire_for_gradients_accumulated_in_place():
+    """A parameter that already holds a .grad gets its new gradient added in place by isx_bn_fold_backward, past autograd's AccumulateGrad node;
+    the hooks registered behind that node (dp.GradAllReducer's bucket counters, the all-reduce gradient exchange) still run, once per backward."""
+    from isx.suffix import SuffixEngine
+    seq, cin, hw = _blocks("layer4")
+    eng = SuffixEngine(list(seq))
+    x = torch.relu(torch.randn(2, cin, hw, hw, device="cuda")).contiguous(memory_format=torch.channels_last)
+    seen = []
+    params = [p for p in seq.parameters() if p.requires_grad]
+    for p in params:
+        p.register_post_accumulate_grad_hook(lambda q: seen.append(id(q)))
+    eng(x).sum().backward()                                  # first backward: fresh tensors handed to autograd, its own AccumulateGrad calls the hooks
+    assert sorted(seen) == sorted(id(p) for p in params)
+    del seen[:]
+    eng(x).sum().backward()                                  # second: in place
+    assert sorted(seen) == sorted(id(p) for p in params)
+
+
 def test_suffix_engine_follows_the_optimizer():
     """The folded weights are derived per step from the parameters' version counters: after an optimizer step the engine computes with the new
     weights (same output as the plain modules), and a BatchNorm put into training mode makes it inapplicable."""
