@@ -123,6 +123,10 @@ def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, op
         lab_ids = torch.tensor([labels.index(lab) for lab, _, _, _ in batch], dtype=torch.int64)
         return [a, p, ng], [move_device(lab_ids, P.cuda_device)]
 
+    # same items -> same batch, whenever it is built: the negatives were drawn in create_epoch and nothing is augmented, so the training step may
+    # build the batches of the next mini-batches ahead of their turn (utils/train_general._Stepper._precompute_ahead)
+    create_batch.deterministic = trans is None
+
     def create_loss(out, labels_list):
         return criterion(*out), None
 

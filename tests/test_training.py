@@ -501,7 +501,8 @@ def test_untrained_blocks_follow_the_reference_table():
     assert first_trainable(frozen.features) == len(frozen.features)
 
 
-def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch, micro, mined, replay, batched=True, feature_dim=32, prefix_cache=False):
+def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch, micro, mined, replay, batched=True, feature_dim=32, prefix_cache=False,
+                            prefix_ahead=None, calls=None):
     """One run of train.siamese_descriptor.main on the reference configuration (ResNet-50, untrained_blocks from the table).  `mined`:
     list receiving the mined negatives per epoch; `replay`: a previous run's list to use instead of mining."""
     import copy
@@ -527,6 +528,11 @@ def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch,
         P.untrained_blocks = None                                  # the reference's table: 15 for ResNet-50
         P.train_suffix_batched = batched
         P.train_prefix_cache = prefix_cache
+        if prefix_ahead is not None:
+            P.train_prefix_ahead = prefix_ahead
+        if calls is not None:                                      # how many images each prefix launch of the run carried
+            real_prefix = ms._SplitTrunk.prefix
+            ms._SplitTrunk.prefix = lambda self_, features, x: (calls.append(int(x.size(0))) or real_prefix(self_, features, x))
         assert P.untrained_blocks == 15
         torch.manual_seed(0); random.seed(0)
         init = {k: v.detach().clone() for k, v in sd.get_siamese_net().state_dict().items()}
@@ -540,6 +546,8 @@ def _train_reference_config(split_trunk, suffix_engine, epochs, n_images, batch,
     finally:
         ms.SPLIT_TRUNK, ms.SUFFIX_ENGINE = old
         sd.mine_epoch_negatives = real_mine
+        if calls is not None:
+            ms._SplitTrunk.prefix = real_prefix
         sd.P.__dict__.clear(); sd.P.__dict__.update(saved)
 
 
@@ -651,6 +659,24 @@ def test_prefix_feature_cache_trains_the_same_bits():
     two epochs on the reference configuration end in the SAME state dict, bit for bit: the kernels are batch-invariant."""
     _, a = _train_reference_config(True, True, 2, 32, 16, 4, [], None)
     _, b = _train_reference_config(True, True, 2, 32, 16, 4, [], None, prefix_cache=True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.gpu
+def test_prefix_look_ahead_trains_the_same_bits():
+    """P.train_prefix_ahead: the frozen prefix of three consecutive mini-batches in ONE launch (the features of an image depend neither on its
+    batch nor on the optimizer steps in between) against every step launching its own -- the same state dict after two epochs, bit for bit; the
+    launches did carry 3 x 48 images (a trailing block of two carries 96, a single step launches its own 48)."""
+    from utils.dataset import get_pos_couples, synthetic_image_set
+    steps = sum(len(v) for v in get_pos_couples(synthetic_image_set(32, 4, seed=1, structure=0.5)).values()) // 16
+    assert steps >= 4
+    own, ahead = [], []
+    _, a = _train_reference_config(True, True, 2, 32, 16, 4, [], None, prefix_ahead=1, calls=own)
+    _, b = _train_reference_config(True, True, 2, 32, 16, 4, [], None, prefix_ahead=3, calls=ahead)
+    assert own.count(48) == 2 * steps and 144 not in own
+    rest = steps % 3
+    assert ahead.count(144) == 2 * (steps // 3) and ahead.count(96) == (2 if rest == 2 else 0) and ahead.count(48) == (2 if rest == 1 else 0)
     for k in a:
         assert torch.equal(a[k], b[k]), k
 

@@ -67,6 +67,8 @@ def run_config(name, args, world, rank, local):
     P.untrained_blocks = -1 if name == "frozen" else None          # None: the reference's table
     P.train_prefix_cache = name.endswith("_cached")
     P.train_fused_head_sgd = not args.no_fused_sgd
+    if args.prefix_ahead is not None:
+        P.train_prefix_ahead = args.prefix_ahead
     tr = synthetic_image_set(args.images, args.labels, seed=1)
     te = synthetic_image_set(64, args.labels, seed=2)
     n_couples = sum(len(v) for v in get_pos_couples(tr).values())
@@ -121,7 +123,7 @@ def run_config(name, args, world, rank, local):
                         "ms_per_step": step_ms, "achieved": flop["total"] / (step_ms * 1e-3) / 1e12, "frac": flop["total"] / (step_ms * 1e-3) / 157.3e12,
                         "counts": "forward of the frozen convolutions, forward + input gradient + weight gradient of the trained ones and of the head's "
                                   "Linear, %d images per step; the epoch's embedding pass and mining are outside ms_per_step" % (3 * P.train_batch_size)},
-           "exchange": dict(dp.STATS)}
+           "prefix_ahead": int(getattr(P, "train_prefix_ahead", 1)), "exchange": dict(dp.STATS)}
     if P.train_prefix_cache:
         out["prefix_cache"] = cache_stats
         out["roofline"]["note"] = "the FLOP count is the reference configuration's (prefix recomputed at every use); with the table most of the frozen-prefix term is not executed"
@@ -142,6 +144,7 @@ def main():
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--configs", default="reference,frozen")
     ap.add_argument("--no-fused-sgd", action="store_true", help="A/B: the head weight through a dW tensor and torch's optimizer (round 4)")
+    ap.add_argument("--prefix-ahead", type=int, default=None, help="P.train_prefix_ahead (default: the parameter file's, 4); 1 = every step launches its own prefix")
     ap.add_argument("--phases", action="store_true", help="synchronise and time the phases of the training step (diagnostic: the totals are slower)")
     args = ap.parse_args()
     import torch.distributed as dist
