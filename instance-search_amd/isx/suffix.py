@@ -188,13 +188,6 @@ class SuffixEngine(object):
         check(lib().isx_bn_fold_backward(dwp.data_ptr(), db.data_ptr(), 1, S, f.conv.weight.data_ptr(), f.scale.data_ptr(), f.mean.data_ptr(),
                                          f.istd.data_ptr(), f.cout, f.cin, f.taps, 1, 0, outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), _stream()),
               "isx_bn_fold_backward")
-        # a gradient accumulated in place never passes autograd's AccumulateGrad node, so the hooks that run behind it (dp.GradAllReducer's
-        # bucket counters in train_grad_exchange = "allreduce" mode, any user hook) are called here, once the kernel that completes it is enqueued
-        for p, handed_back in zip(params, grads[-3:]):
-            hooks = getattr(p, "_post_accumulate_grad_hooks", None)
-            if handed_back is None and hooks:
-                for hook in list(hooks.values()):
-                    hook(p)
 
     # ---- forward / backward of the whole suffix -------------------------------------------------------------------------------------
     def forward(self, x_nchw):

@@ -81,7 +81,7 @@ class Params(object):
         self.train_epoch_switch = 2          # semi-hard negatives before this epoch, hard ones after
         self.save_dir = None
         self.train_seed = 0
-        self.train_prefix_ahead = 4          # frozen trunk prefix of this many consecutive mini-batches in one launch (1: every step launches its own); same bits
+        self.train_prefix_ahead = 8          # frozen trunk prefix of this many consecutive mini-batches in one launch (1: every step launches its own); same bits
         self.train_prefix_cache = False      # frozen trunk prefix: look the features of resident training images up in an HBM table instead of recomputing them every step (same bits)
         self.train_head_shard = True         # data parallel: the descriptor head's Linear sharded by output features across the ranks (isx/shard_head.py)
         self.train_fused_head_sgd = True     # descriptor head: weight gradient + SGD update as one kernel (isx_head_sgd_step); False: torch's optimizer on a dW tensor

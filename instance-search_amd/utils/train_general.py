@@ -256,13 +256,13 @@ class _Stepper(object):
         self._epoch_set, self._ahead = dataset, None
 
     def _precompute_ahead(self, start, n, n_leaves, batch_args):
-        """Frozen trunk prefix for SEVERAL consecutive mini-batches in one launch (P.train_prefix_ahead of them, default 4).  The prefix of an
+        """Frozen trunk prefix for SEVERAL consecutive mini-batches in one launch (P.train_prefix_ahead of them, default 8).  The prefix of an
         image depends neither on the batch it rides in nor -- being frozen -- on the optimizer steps in between, so the features a step reads are
         bit for bit the ones its own launch would produce; 192 images fill the chip to 0.67 of the fp32 peak on these layers, 768 to 0.8.  Only
         when the training script declares its batch construction deterministic (`create_batch.deterministic`: no random augmentation, negatives
         drawn per epoch) -- the mini-batches further down the list are built ahead of their turn."""
         P = self.P
-        G = int(getattr(P, 'train_prefix_ahead', 4))
+        G = int(getattr(P, 'train_prefix_ahead', 8))
         ds = getattr(self, '_epoch_set', None)
         if (G < 2 or ds is None or start is None or n_leaves < 1 or not getattr(self.make_batch, 'deterministic', False)
                 or getattr(P, 'train_prefix_cache', False) or not getattr(P, 'train_trunk_per_minibatch', True)

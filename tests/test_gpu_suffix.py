@@ -104,8 +104,9 @@ def test_suffix_engine_matches_float64_autograd(which, B):
 
 
 def test_post_accumulate_hooks_fire_for_gradients_accumulated_in_place():
-    """A parameter that already holds a .grad gets its new gradient added in place by isx_bn_fold_backward, past autograd's AccumulateGrad node;
-    the hooks registered behind that node (dp.GradAllReducer's bucket counters, the all-reduce gradient exchange) still run, once per backward."""
+    """A parameter that already holds a .grad gets its new gradient added in place by isx_bn_fold_backward and autograd is handed None for it;
+    the engine still visits the parameter's AccumulateGrad node, so the hooks registered behind it (dp.GradAllReducer's bucket counters in the
+    all-reduce gradient exchange) run exactly once per backward either way (round-4 ADVICE assumed they did not)."""
     from isx.suffix import SuffixEngine
     seq, cin, hw = _blocks("layer4")
     eng = SuffixEngine(list(seq))

@@ -144,7 +144,7 @@ def main():
     ap.add_argument("--backbone", default="resnet50")
     ap.add_argument("--configs", default="reference,frozen")
     ap.add_argument("--no-fused-sgd", action="store_true", help="A/B: the head weight through a dW tensor and torch's optimizer (round 4)")
-    ap.add_argument("--prefix-ahead", type=int, default=None, help="P.train_prefix_ahead (default: the parameter file's, 4); 1 = every step launches its own prefix")
+    ap.add_argument("--prefix-ahead", type=int, default=None, help="P.train_prefix_ahead (default: the parameter file's, 8); 1 = every step launches its own prefix")
     ap.add_argument("--phases", action="store_true", help="synchronise and time the phases of the training step (diagnostic: the totals are slower)")
     args = ap.parse_args()
     import torch.distributed as dist
