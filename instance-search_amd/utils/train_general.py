@@ -34,9 +34,9 @@ def output_stats(train_type, P, test_print, test_net, net, testset_tuple, epoch,
     """Running-loss line every P.train_loss_int mini-batches; evaluation every P.train_test_int (or at
     the end of the epoch when that is <= 0)."""
     every = P.train_loss_int
-    running_loss += loss
+    running_loss = running_loss + loss              # `loss` may be a device scalar (_Stepper.step): summed where it lives, in float64
     if batch_count % every == every - 1:
-        log(P, '[{0:d}, {1:5d}] loss: {2:.5f}'.format(epoch + 1, batch_count + 1, running_loss / every))
+        log(P, '[{0:d}, {1:5d}] loss: {2:.5f}'.format(epoch + 1, batch_count + 1, float(running_loss) / every))
         running_loss = 0.0
     t = P.train_test_int
     if (t > 0 and batch_count % t == t - 1) or (t <= 0 and is_final):
@@ -351,7 +351,9 @@ class _Stepper(object):
             loss = t
         with _phase("optimizer"):
             optimizer.step()
-        loss = float(loss)                            # the one read-back of the step (after the optimizer has been enqueued)
+        # the loss stays a tensor (float64 scalar, on the device of the step): output_stats adds it to the running loss there and reads that back
+        # when a line is printed (every P.train_loss_int steps) -- a read-back per step would leave the GPU idle while the host prepares the next
+        loss = loss.reshape(())
         if self.world > 1:
             # BatchNorm in training mode (P.train_bn): each rank's running statistics saw only its slice -- average them so that the
             # replicas stay one model (same mining, same evaluation, a checkpoint that is every rank's)
