@@ -831,7 +831,7 @@ def main():
             import bench_train
             import io
             import contextlib
-            targs = _ap.Namespace(images=512, labels=64, epochs=5, backbone="resnet50", configs="reference,frozen", phases=False, no_fused_sgd=False)
+            targs = bench_train.make_parser().parse_args(["--images", "512", "--labels", "64", "--epochs", "5", "--backbone", "resnet50"])   # the tool's own defaults
             res_t = {}
             from train import siamese_descriptor as _sd
             saved_p = dict(_sd.P.__dict__)
@@ -850,6 +850,8 @@ def main():
                                "reference_config_with_prefix_cache_triplets_per_s": res_t["reference_cached"]["triplets_per_s"],
                                "prefix_cache": "P.train_prefix_cache (off in the two figures above): frozen-prefix features of the resident training images looked up in an "
                                                "HBM table instead of recomputed at every use; bit-identical training, not the reference's work per step",
+                               "prefix_look_ahead": "P.train_prefix_ahead = %d: the frozen prefix of that many consecutive mini-batches runs as one launch (every image still "
+                                                    "computed at every use; bit-identical to a launch per step)" % res_t["reference"].get("prefix_ahead", 1),
                                "statistic": res_t["reference"]["statistic"],
                                "reference_config_triplets_per_s_min_max": res_t["reference"]["triplets_per_s_min_max"],
                                "frozen_trunk_triplets_per_s_min_max": res_t["frozen"]["triplets_per_s_min_max"],

@@ -136,7 +136,7 @@ def run_config(name, args, world, rank, local):
     return out
 
 
-def main():
+def make_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--images", type=int, default=512)
     ap.add_argument("--labels", type=int, default=64)
@@ -146,7 +146,11 @@ def main():
     ap.add_argument("--no-fused-sgd", action="store_true", help="A/B: the head weight through a dW tensor and torch's optimizer (round 4)")
     ap.add_argument("--prefix-ahead", type=int, default=None, help="P.train_prefix_ahead (default: the parameter file's, 8); 1 = every step launches its own prefix")
     ap.add_argument("--phases", action="store_true", help="synchronise and time the phases of the training step (diagnostic: the totals are slower)")
-    args = ap.parse_args()
+    return ap
+
+
+def main():
+    args = make_parser().parse_args()
     import torch.distributed as dist
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     # debugging aid for boxes with ONE GPU (as in bench.py): ISX_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 over gloo, so that the
