@@ -262,7 +262,10 @@ class _Stepper(object):
         when the training script declares its batch construction deterministic (`create_batch.deterministic`: no random augmentation, negatives
         drawn per epoch) -- the mini-batches further down the list are built ahead of their turn."""
         P = self.P
+        # P.train_prefix_ahead counts mini-batches of ONE process; a rank of a P-rank run holds 1/P of each, so it looks P times further ahead:
+        # the launch carries the same number of images whatever the world size (each rank decides for itself: no collective is involved)
         G = int(getattr(P, 'train_prefix_ahead', 8))
+        G = G * self.world if G > 1 else G
         ds = getattr(self, '_epoch_set', None)
         if (G < 2 or ds is None or start is None or n_leaves < 1 or not getattr(self.make_batch, 'deterministic', False)
                 or getattr(P, 'train_prefix_cache', False) or not getattr(P, 'train_trunk_per_minibatch', True)
