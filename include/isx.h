@@ -427,6 +427,12 @@ int isx_head_sgd_step(const float* dy, const float* x, int64_t R, int N, int64_t
  * gradients), rows added in order.  x: (leaves * R, C); out: (leaves, C). */
 int isx_colsum_leaves(const float* x, int leaves, int R, int64_t C, float* out, isx_stream_t stream);
 
+/* out[c] = the sum of rows[0 .. L)[c] in the canonical TREE order of the data-parallel training step (isx/dp.py: a node is its left subtree
+ * plus its right subtree, split at L / 2 -- the order in which the per-micro-batch gradients of reference utils/train_general.py:51-74 are
+ * added, chosen so that 1, 2, 4, 8 ranks produce the same bits).  rows: L rows of n floats, `stride` floats apart; out may be rows' row 0.
+ * 1 <= L <= 16.  One pass over the L rows instead of L - 1 add passes. */
+int isx_tree_sum_rows(const float* rows, int L, int64_t stride, int64_t n, float* out, isx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -257,9 +257,54 @@ __global__ __launch_bounds__(256) void colsum_leaves_kernel(const float* __restr
     out[(int64_t)leaf * C + c] = s;
 }
 
+// Canonical tree sum of L rows (isx/dp.py tree_sum: sum(lo, hi) = sum(lo, mid) + sum(mid, hi), mid = lo + (hi - lo) / 2), all adds in registers.
+template <int N> struct TreeSum {
+    template <typename T> static __device__ __forceinline__ T of(const T* v) { return TreeSum<N / 2>::of(v) + TreeSum<N - N / 2>::of(v + N / 2); }
+};
+template <> struct TreeSum<1> {
+    template <typename T> static __device__ __forceinline__ T of(const T* v) { return v[0]; }
+};
+
+template <int L, typename T>
+__global__ __launch_bounds__(256) void tree_sum_rows_kernel(const T* __restrict__ rows, int64_t stride, int64_t n, T* __restrict__ out) {
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < n; c += (int64_t)gridDim.x * 256) {
+        T v[L];
+#pragma unroll
+        for (int l = 0; l < L; ++l) v[l] = rows[(int64_t)l * stride + c];
+        out[c] = TreeSum<L>::of(v);
+    }
+}
+
+__device__ __forceinline__ float4 operator+(const float4& a, const float4& b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int L>
+static void launch_tree_sum(const float* rows, int64_t stride, int64_t n, float* out, hipStream_t st) {
+    const bool vec = n % 4 == 0 && stride % 4 == 0 && (((uintptr_t)rows | (uintptr_t)out) % 16) == 0;
+    const int64_t items = vec ? n / 4 : n;
+    const unsigned grid = (unsigned)((items + 255) / 256 < 8192 ? (items + 255) / 256 : 8192);
+    if (vec)
+        hipLaunchKernelGGL((tree_sum_rows_kernel<L, float4>), dim3(grid), dim3(256), 0, st, (const float4*)rows, stride / 4, items, (float4*)out);
+    else
+        hipLaunchKernelGGL((tree_sum_rows_kernel<L, float>), dim3(grid), dim3(256), 0, st, rows, stride, items, out);
+}
+
 }  // namespace isx
 
 using namespace isx;
+
+ISX_API int isx_tree_sum_rows(const float* rows, int L, int64_t stride, int64_t n, float* out, isx_stream_t stream) {
+    ISX_REQUIRE(L >= 1 && L <= 16 && n >= 0 && stride >= 0, "isx_tree_sum_rows: bad shape L=%d stride=%lld n=%lld (1 <= L <= 16)", L, (long long)stride, (long long)n);
+    if (n == 0) return ISX_OK;
+    ISX_REQUIRE(rows && out && (L == 1 || stride >= n), "isx_tree_sum_rows: null pointer or overlapping rows");
+    hipStream_t st = (hipStream_t)stream;
+    switch (L) {
+#define ISX_TS(l) case l: launch_tree_sum<l>(rows, stride, n, out, st); break;
+        ISX_TS(1) ISX_TS(2) ISX_TS(3) ISX_TS(4) ISX_TS(5) ISX_TS(6) ISX_TS(7) ISX_TS(8) ISX_TS(9) ISX_TS(10) ISX_TS(11) ISX_TS(12) ISX_TS(13) ISX_TS(14) ISX_TS(15) ISX_TS(16)
+#undef ISX_TS
+    }
+    ISX_CHECK_LAUNCH("isx_tree_sum_rows");
+    return ISX_OK;
+}
 
 // Splits of the K dimension isx_head_linear_fwd uses (host arithmetic; sizes the workspace: splits * Mp * N floats).
 ISX_API int isx_head_linear_splits(int64_t K) { return K > 0 ? head_splits(K) : 0; }

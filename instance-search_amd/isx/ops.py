@@ -611,6 +611,19 @@ def masked_sums(sim, qlab, glab):
     return out
 
 
+def tree_sum_rows(rows, out=None):
+    """Sum of the rows of a (L, n) fp32 device tensor in the canonical tree order of isx/dp.py (tree_sum), one kernel (isx_tree_sum_rows);
+    L <= 16.  `out`: an (n,) tensor to write (may be rows[0])."""
+    rows = _f32(rows, "rows")
+    L, n = rows.shape
+    if rows.stride(1) != 1:
+        raise _lib.IsxError("tree_sum_rows: rows must be contiguous along the last dimension")
+    if out is None:
+        out = torch.empty((n,), device=rows.device, dtype=torch.float32)
+    check(lib().isx_tree_sum_rows(rows.data_ptr(), int(L), int(rows.stride(0)) if L > 1 else int(n), int(n), out.data_ptr(), _stream()), "isx_tree_sum_rows")
+    return out
+
+
 DBA_MAX_GROUP = 1024
 
 

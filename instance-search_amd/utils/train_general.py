@@ -330,7 +330,12 @@ class _Stepper(object):
                     losses = [l for p in parts for l in p[1]]
                 else:
                     flat_all, losses = self._leaves_batched(eng, head, mine, offsets, n, pre, sink)
-                self.flat.put(dp.tree_sum(lo, hi, lambda i: flat_all[i - lo]))
+                if flat_all.is_cuda and 1 <= hi - lo <= 16:
+                    from isx import ops
+                    self.flat.attach_all()
+                    ops.tree_sum_rows(flat_all, out=self.flat.flat)       # the same tree, one pass over the leaves' rows instead of L - 1 add passes
+                else:
+                    self.flat.put(dp.tree_sum(lo, hi, lambda i: flat_all[i - lo]))
                 if self.exchange is not None:
                     self.exchange.allreduce_(self.flat.flat)
             elif self.mode == 'tree':

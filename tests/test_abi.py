@@ -57,6 +57,7 @@ def test_argument_validation_without_gpu():
     assert lib.isx_head_linear_fwd(None, 24, 60, 100352, None, 2048, None, None, None, 0, None) == -1 and b"Mp % 64" in lib.isx_last_error()
     assert lib.isx_head_linear_dgrad(None, 64, 2048, None, 100, None, None) == -1 and b"K % 64" in lib.isx_last_error()
     assert lib.isx_colsum_leaves(None, 0, 24, 2048, None, None) == 0 and lib.isx_l2norm_rows_bwd(None, None, 0, 16, 1e-10, None, None) == 0
+    assert lib.isx_tree_sum_rows(None, 17, 8, 8, None, None) == -1 and b"1 <= L <= 16" in lib.isx_last_error() and lib.isx_tree_sum_rows(None, 4, 8, 0, None, None) == 0
     # empty problems are no-ops
     assert lib.isx_l2norm_rows(None, 0, 16, 1e-10, None, None) == 0
     assert lib.isx_cosine_sim(None, 0, None, 0, 8, None, None) == 0

@@ -185,3 +185,25 @@ def test_fused_sgd_declines_what_the_kernel_does_not_cover():
     assert not dp.fused_sgd_from_rows(torch.optim.SGD([w], lr=0.1), w, torch.zeros(4, 100, device="cuda"), torch.zeros(4, 64, device="cuda"))
     w2 = torch.nn.Parameter(torch.zeros(128, 128, device="cuda"))
     assert not dp.fused_sgd_from_rows(torch.optim.Adam([w2], lr=0.1), w2, torch.zeros(4, 128, device="cuda"), torch.zeros(4, 128, device="cuda"))
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 5, 8, 13, 16])
+def test_tree_sum_rows_is_the_canonical_tree(L):
+    """isx_tree_sum_rows == isx/dp.tree_sum on the same rows, bit for bit (float4 and scalar launches, strided rows, in place into row 0)."""
+    from isx import dp, ops
+    g = torch.Generator().manual_seed(L)
+    for n, pad in ((4096 + 8, 0), (1001, 3)):
+        buf = (torch.randn(L, n + pad, generator=g) * torch.logspace(-3, 3, L).view(L, 1)).cuda()
+        rows = buf[:, :n]
+        want = dp.tree_sum(0, L, lambda i: rows[i].clone())
+        got = ops.tree_sum_rows(rows) if pad == 0 else torch.empty(n, device="cuda")
+        if pad:
+            from isx._lib import check, lib
+            check(lib().isx_tree_sum_rows(rows.data_ptr(), L, rows.stride(0), n, got.data_ptr(), torch.cuda.current_stream().cuda_stream), "x")
+        assert torch.equal(got, want)
+        cpu = dp.tree_sum(0, L, lambda i: rows[i].cpu().clone())                   # and the CPU's fp32 adds in the same order
+        assert torch.equal(got.cpu(), cpu)
+    rows = torch.randn(L, 512, generator=g).cuda()
+    want = dp.tree_sum(0, L, lambda i: rows[i].clone())
+    ops.tree_sum_rows(rows, out=rows[0])
+    assert torch.equal(rows[0], want)
