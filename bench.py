@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-overlap-exchange", action="store_true",
                     help="N > 1: keep the search stage of a step (query all-gather, GEMM, top-k, result exchange) on the main stream "
                          "(default: on a second stream behind the next step's trunk)")
+    ap.add_argument("--slab-rows", type=int, default=131072, help="rows of the descriptor-slab round trip (GPU -> file -> GPU, isx/slab.py); 0 skips it")
     ap.add_argument("--decode-images", type=int, default=16384, help="images of the decode-inclusive ingest leg (JPEG files -> descriptors); 0 skips it")
     ap.add_argument("--ingest-images", type=int, default=65536,
                     help="images of the non-resident streaming-ingest side measurement (0 = skip); host memory: 4096 distinct uint8 images, the rest views")
@@ -300,6 +301,9 @@ def compact_line(full, detail_file=None):
     dg = full.get("ingest_decode")
     if isinstance(dg, dict):
         line["ingest_decode"] = _pick(dg, ("error", "images", "cores", "images_per_s", "decode_only_images_per_s", "decode_bound", "descriptors_identical_to_decode_first"))
+    sl = full.get("slab_roundtrip")
+    if isinstance(sl, dict):
+        line["slab_roundtrip"] = _pick(sl, ("error", "rows", "write_GB_per_s", "read_GB_per_s", "identical", "search_identical"))
     tr = full.get("training")
     if isinstance(tr, dict):
         line["training"] = _pick(tr, ("error", "reference_config_triplets_per_s", "frozen_trunk_triplets_per_s", "reference_over_frozen", "reference_config", "statistic",
@@ -323,7 +327,7 @@ def compact_line(full, detail_file=None):
     for key in ("value", "ms_per_step", "dist_per_s"):          # the contract's scalars keep their digits
         if key in full:
             line[key] = full[key]
-    for victim in ("families", "training", "ingest_decode", "ingest_streaming", "exchange", "extraction_regions", "retrieval_shard", "roofline_step"):      # never expected: a safety net
+    for victim in ("families", "slab_roundtrip", "training", "ingest_decode", "ingest_streaming", "exchange", "extraction_regions", "retrieval_shard", "roofline_step"):      # never expected: a safety net
         if len(json.dumps(line)) <= MAX_LINE_BYTES:
             break
         line.pop(victim, None)
@@ -813,6 +817,45 @@ def main():
         except Exception as e:
             ingest_result = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
+    def slab_bench():
+        """Next-scope row f2: a gallery slab GPU -> file (SlabWriter: row blocks through one pinned buffer) -> GPU (mmap -> pinned staging -> HBM),
+        and a search against the re-read gallery.  The rates are the box's file system's as much as the code's; the bits must be the same."""
+        import tempfile
+        from isx import slab as _slab
+        n = args.slab_rows
+        g_ = torch.Generator(device=dev).manual_seed(11)
+        desc = ops.l2norm_rows(torch.randn((n, D), device=dev, generator=g_))
+        lab = (torch.arange(n, dtype=torch.int32) % 1000)
+        tmp = tempfile.mkdtemp(prefix="isx_slab_")
+        path = os.path.join(tmp, "gallery.slab")
+        try:
+            torch.cuda.synchronize(); t0_ = time.perf_counter()
+            _slab.save_slab(path, desc, lab)
+            t_w = time.perf_counter() - t0_
+            t0_ = time.perf_counter()
+            back = retrieval.ShardedGallery.from_slab(path, dev)
+            torch.cuda.synchronize()
+            t_r = time.perf_counter() - t0_
+            same = bool(torch.equal(back.shard, desc))
+            q = desc[:256].clone()
+            s1, i1 = retrieval.ShardedGallery(desc, idx_base=0).search(q, k)
+            s2, i2 = back.search(q, k)
+            same_search = bool(torch.equal(i1, i2) and torch.equal(s1, s2))
+            nbytes = os.path.getsize(path)
+        finally:
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+        return {"rows": n, "dim": D, "file_bytes": nbytes, "write_GB_per_s": nbytes / t_w / 1e9, "read_GB_per_s": nbytes / t_r / 1e9, "identical": same,
+                "search_identical": same_search, "where": tempfile.gettempdir(),
+                "path": "isx.slab.save_slab (SlabWriter, streamed from HBM) -> isx.retrieval.ShardedGallery.from_slab (mmap -> pinned -> HBM)"}
+
+    slab_result = None
+    if args.slab_rows > 0 and rank == 0 and world == 1:
+        try:
+            slab_result = slab_bench()
+        except Exception as e:
+            slab_result = {"error": "%s: %s" % (type(e).__name__, e)}
+
     ingest_decode_result = None
     if args.decode_images > 0 and rank == 0 and args.backbone_dtype == "f32" and not args.no_fold_bn:
         try:
@@ -983,6 +1026,8 @@ def main():
             line["ingest_streaming"] = ingest_result
         if ingest_decode_result is not None:
             line["ingest_decode"] = ingest_decode_result
+        if slab_result is not None:
+            line["slab_roundtrip"] = slab_result
         if training_result is not None:
             line["training"] = training_result
         if world > 1:

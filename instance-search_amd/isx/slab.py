@@ -35,53 +35,74 @@ class SlabWriter(object):
     def __init__(self, path, rows, dim, has_labels=False, normalised=True):
         self.path, self.tmp, self.N, self.D = path, path + ".tmp", int(rows), int(dim)
         self.label_off = DATA_OFFSET + ((self.N * self.D * 4 + 4095) // 4096) * 4096 if has_labels else 0
-        self.f = open(self.tmp, "wb")
-        self.f.write(_HDR.pack(MAGIC, self.N, self.D, 1 if normalised else 0, self.label_off))
-        self.f.seek(DATA_OFFSET)
+        self.fd = os.open(self.tmp, os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+        os.pwrite(self.fd, _HDR.pack(MAGIC, self.N, self.D, 1 if normalised else 0, self.label_off), 0)
         self.written = 0
-        self._pin = None
+
+    def _write(self, host, rows):
+        """`rows` rows of the contiguous fp32 host tensor `host` behind the rows written so far (positional writes, READ_THREADS side by side)."""
+        _pio(self.fd, host, DATA_OFFSET + self.written * self.D * 4, rows * self.D * 4, write=True)
+        self.written += rows
 
     def append(self, block):
         """block: (n, D) fp32 rows that follow the rows written so far (torch tensor on any device, or ndarray)."""
-        if isinstance(block, torch.Tensor):
-            block = block.detach()
-            if block.dim() != 2 or block.size(1) != self.D or block.dtype != torch.float32:
-                raise ValueError("slab rows must be (n, %d) float32, got %s %s" % (self.D, tuple(block.shape), block.dtype))
-            for r0 in range(0, block.size(0), CHUNK_ROWS):
-                piece = block[r0:r0 + CHUNK_ROWS]
-                if piece.is_cuda:
-                    if self._pin is None or self._pin.size(0) < piece.size(0):
-                        self._pin = torch.empty((min(CHUNK_ROWS, max(piece.size(0), 1)), self.D), dtype=torch.float32).pin_memory()
-                    host = self._pin[:piece.size(0)]
-                    host.copy_(piece)
-                else:
-                    host = piece.contiguous()
-                host.numpy().tofile(self.f)
-                self.written += piece.size(0)
-        else:
+        if not isinstance(block, torch.Tensor):
             a = np.ascontiguousarray(block, dtype=np.float32)
             if a.ndim != 2 or a.shape[1] != self.D:
                 raise ValueError("slab rows must be (n, %d), got %s" % (self.D, a.shape))
-            a.tofile(self.f)
-            self.written += a.shape[0]
-        if self.written > self.N:
-            raise ValueError("more rows appended (%d) than the slab was opened for (%d)" % (self.written, self.N))
+            block = torch.from_numpy(a)
+        block = block.detach()
+        if block.dim() != 2 or block.size(1) != self.D or block.dtype != torch.float32:
+            raise ValueError("slab rows must be (n, %d) float32, got %s %s" % (self.D, tuple(block.shape), block.dtype))
+        if self.written + block.size(0) > self.N:
+            raise ValueError("more rows appended (%d) than the slab was opened for (%d)" % (self.written + block.size(0), self.N))
+        if not block.is_cuda:
+            if block.size(0):
+                self._write(block.contiguous(), block.size(0))
+            return
+        # from the GPU: pieces of READ_CHUNK_BYTES through the two pinned staging buffers -- the device-to-host copy of piece c + 1 runs
+        # while piece c goes to the file
+        rows_per = max(1, READ_CHUNK_BYTES // (self.D * 4))
+        stage = _read_stage(rows_per * self.D)
+        with torch.cuda.device(block.device):
+            starts = list(range(0, block.size(0), rows_per))
+            done = [None, None]
+
+            def fetch(c):
+                r0 = starts[c]
+                piece = block[r0:r0 + rows_per]
+                stage[c & 1][: piece.numel()].view(piece.size(0), self.D).copy_(piece, non_blocking=True)
+                done[c & 1] = torch.cuda.Event()
+                done[c & 1].record()
+                return piece.size(0)
+
+            sizes = {}
+            if starts:
+                sizes[0] = fetch(0)
+            for c in range(len(starts)):
+                done[c & 1].synchronize()
+                if c + 1 < len(starts):
+                    sizes[c + 1] = fetch(c + 1)
+                self._write(stage[c & 1], sizes[c])
 
     def close(self, labels=None):
         if self.written != self.N:
-            self.f.close()
+            os.close(self.fd)
             os.unlink(self.tmp)
             raise ValueError("slab opened for %d rows, %d appended" % (self.N, self.written))
-        if self.label_off:
-            lab = labels.detach().cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
-            lab = np.ascontiguousarray(lab, dtype=np.int32)
-            if lab.shape != (self.N,):
-                raise ValueError("labels must have shape (%d,)" % self.N)
-            self.f.seek(self.label_off)
-            lab.tofile(self.f)
-        elif labels is not None:
-            raise ValueError("the slab was opened without labels")
-        self.f.close()
+        try:
+            if self.label_off:
+                lab = labels.detach().cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
+                lab = np.ascontiguousarray(lab, dtype=np.int32)
+                if lab.shape != (self.N,):
+                    raise ValueError("labels must have shape (%d,)" % self.N)
+                os.pwrite(self.fd, lab.tobytes(), self.label_off)
+            elif labels is not None:
+                raise ValueError("the slab was opened without labels")
+            else:
+                os.ftruncate(self.fd, DATA_OFFSET + self.N * self.D * 4)        # an empty slab still has its header page
+        finally:
+            os.close(self.fd)
         os.replace(self.tmp, self.path)
 
 
@@ -115,6 +136,48 @@ def load_gallery(path, device="cpu", rows=None):
     return desc, ref_set, names
 
 
+READ_CHUNK_BYTES = 64 << 20      # pinned staging pieces of a GPU load (two of them, kept for the process)
+READ_THREADS = 4
+_STAGE = []
+_READ_POOL = None
+
+
+def _read_stage(floats):
+    """Two pinned staging buffers of at least `floats` floats (allocated once: pinning 2 x 64 MB costs as much as reading 1 GB)."""
+    if not _STAGE or _STAGE[0].numel() < floats:
+        del _STAGE[:]
+        _STAGE.extend(torch.empty((floats,), dtype=torch.float32).pin_memory() for _ in range(2))
+    return _STAGE
+
+
+def _pio(fd, buf, offset, nbytes, write=False):
+    """nbytes between the file at `offset` and the contiguous host tensor `buf`: READ_THREADS positional reads (or writes) side by side (the
+    page cache <-> user copy of one thread runs at 4-7 GB/s; mmap adds a fault per 4 KB page on top)."""
+    global _READ_POOL
+    if nbytes <= 0:
+        return
+    view = memoryview(buf.numpy()).cast("B")
+    if _READ_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _READ_POOL = ThreadPoolExecutor(max_workers=READ_THREADS)
+    piece = -(-nbytes // READ_THREADS)
+    piece = (piece + 4095) // 4096 * 4096
+
+    def go(a):
+        b, at = min(a + piece, nbytes), a
+        while at < b:
+            k = os.pwritev(fd, [view[at:b]], offset + at) if write else os.preadv(fd, [view[at:b]], offset + at)
+            if k <= 0:
+                raise IOError("descriptor slab: short %s at byte %d" % ("write" if write else "read (the file is shorter than its header says)", offset + at))
+            at += k
+
+    list(_READ_POOL.map(go, range(0, nbytes, piece)))
+
+
+def _pread_into(fd, buf, offset, nbytes):
+    _pio(fd, buf, offset, nbytes)
+
+
 def slab_info(path):
     with open(path, "rb") as f:
         magic, N, D, flags, label_off = _HDR.unpack(f.read(_HDR.size))
@@ -139,18 +202,23 @@ def load_slab(path, device="cpu", rows=None):
     else:
         with torch.cuda.device(dev):                        # copies, events and the final sync all on the TARGET device's stream
             out = torch.empty((n, D), dtype=torch.float32, device=dev)
-            stage = [torch.empty((min(CHUNK_ROWS, max(n, 1)), D), dtype=torch.float32).pin_memory() for _ in range(2)]
+            rows_per = max(1, min(max(n, 1), READ_CHUNK_BYTES // (D * 4)))
+            stage = _read_stage(rows_per * D)
             events = [None, None]
             copy_stream = torch.cuda.current_stream(dev)
-            for c, r0 in enumerate(range(0, n, CHUNK_ROWS)):
-                r1 = min(r0 + CHUNK_ROWS, n)
-                b = c & 1
-                if events[b] is not None:
-                    events[b].synchronize()                 # the previous copy out of this buffer is done
-                stage[b][: r1 - r0].copy_(torch.from_numpy(np.ascontiguousarray(mm[r0:r1])))
-                out[r0:r1].copy_(stage[b][: r1 - r0], non_blocking=True)
-                events[b] = torch.cuda.Event()
-                events[b].record(copy_stream)
+            fd = os.open(path, os.O_RDONLY)
+            try:
+                for c, r0 in enumerate(range(0, n, rows_per)):
+                    r1 = min(r0 + rows_per, n)
+                    b = c & 1
+                    if events[b] is not None:
+                        events[b].synchronize()             # the previous copy out of this buffer is done
+                    _pread_into(fd, stage[b], DATA_OFFSET + (lo + r0) * D * 4, (r1 - r0) * D * 4)
+                    out[r0:r1].copy_(stage[b][: (r1 - r0) * D].view(r1 - r0, D), non_blocking=True)
+                    events[b] = torch.cuda.Event()
+                    events[b].record(copy_stream)
+            finally:
+                os.close(fd)
             torch.cuda.synchronize(dev)
     labels = None
     if info["has_labels"]:
