@@ -402,6 +402,24 @@ def scatter_rows(slab, indices, rows):
         slab.index_copy_(0, torch.tensor(indices, dtype=torch.int64, device=slab.device), rows.to(slab.dtype))
 
 
+_LABEL_IDS = {}
+
+
+def label_index(labels):
+    """label -> position in the run's label list (what the reference computes as `labels.index(lab)` per image -- train/classif_finetune.py:46,
+    train/siamese_descriptor.py:129: O(#labels) each, seconds per pass at 10 k labels); first occurrence wins, as with list.index.  Cached per
+    list object and length (the mains fill their `labels` list once, then keep it constant)."""
+    key = id(labels)
+    hit = _LABEL_IDS.get(key)
+    if hit is None or hit[0] != len(labels) or hit[1] is not labels:
+        ids = {}
+        for i, lab in enumerate(labels):
+            ids.setdefault(lab, i)
+        _LABEL_IDS.clear()                       # one list at a time is alive in a run
+        hit = _LABEL_IDS[key] = (len(labels), labels, ids)
+    return hit[2]
+
+
 def test_transform(P):
     return None if P.test_pre_proc else P.test_trans
 

@@ -7,7 +7,7 @@ import torch.nn as nn
 from model.custom_modules import l2_normalize_rows
 from model.siamese import TuneClassif
 from utils import fold_batches, move_device, tensor
-from ._common import BatchStager, base_model, device_batch_size, load_weights, make_resident, stage_batch, test_transform
+from ._common import BatchStager, base_model, device_batch_size, label_index, load_weights, make_resident, stage_batch, test_transform
 from .classif_finetune_p import P
 
 labels = []   # filled by the entry point once the reference set is listed, then constant
@@ -23,7 +23,8 @@ def test_classif_net(net, test_set):
         correct, total = acc
         with torch.no_grad():
             pred = net(stage_batch(batch, trans, P.cuda_device)).argmax(1).tolist()
-        correct += sum(1 for (_, lab, _), p in zip(batch, pred) if labels.index(lab) == p)
+        ids = label_index(labels)
+        correct += sum(1 for (_, lab, _), p in zip(batch, pred) if ids[lab] == p)
         return correct, total + len(batch)
 
     return fold_batches(run, (0, 0), test_set, device_batch_size(P, test_set))

@@ -6,7 +6,7 @@ import torch
 from model.custom_modules import l2_normalize_rows
 from model.siamese import TuneClassif, TuneClassifSub
 from utils import fold_batches, move_device, tensor
-from ._common import base_model, device_batch_size, fold_shape_buckets, load_weights, make_resident, scatter_rows, stage_batch, test_transform
+from ._common import base_model, device_batch_size, fold_shape_buckets, label_index, load_weights, make_resident, scatter_rows, stage_batch, test_transform
 from .classif_regions_p import P
 
 labels = []
@@ -38,7 +38,8 @@ def test_classif_net(net, test_set):
             pred = out.max(1)[0].flatten(1).argmax(1)
             flat = out.flatten(2)
             cls = flat[torch.arange(out.size(0)), :, pred].argmax(1).tolist()
-        correct += sum(1 for (_, lab, _), p in zip(batch, cls) if labels.index(lab) == p)
+        ids = label_index(labels)
+        correct += sum(1 for (_, lab, _), p in zip(batch, cls) if ids[lab] == p)
         return correct, total + len(batch)
 
     return fold_batches(run, (0, 0), test_set, 1)

@@ -13,7 +13,7 @@ from model.siamese import DescriptorNet, TuneClassif
 from model.custom_modules import TripletLoss
 from utils import (choose_rand_neg, choose_rand_neg_index, embeddings_device_dim, fold_batches, get_pos_couples, get_similarities, log, move_device,
                    tensor, test_print_descriptor, train_gen)
-from ._common import BatchStager, base_model, device_batch_size, load_weights, make_resident, stage_batch, stage_images, test_transform
+from ._common import BatchStager, base_model, device_batch_size, label_index, load_weights, make_resident, stage_batch, stage_images, test_transform
 from .siamese_descriptor_p import P
 
 labels = []
@@ -120,7 +120,8 @@ def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, op
         a = stage_images([prep(im1) for _, _, (im1, _), _ in batch], P.cuda_device)
         p = stage_images([prep(im2) for _, _, (_, im2), _ in batch], P.cuda_device)
         ng = stage_images([prep(train_set[k][0] if k >= 0 else choose_rand_neg(train_set, lab)) for lab, _, _, k in batch], P.cuda_device)
-        lab_ids = torch.tensor([labels.index(lab) for lab, _, _, _ in batch], dtype=torch.int64)
+        ids = label_index(labels)
+        lab_ids = torch.tensor([ids[lab] for lab, _, _, _ in batch], dtype=torch.int64)
         return [a, p, ng], [move_device(lab_ids, P.cuda_device)]
 
     # same items -> same batch, whenever it is built: the negatives were drawn in create_epoch and nothing is augmented, so the training step may

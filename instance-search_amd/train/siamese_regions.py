@@ -10,7 +10,7 @@ from model.siamese import RegionDescriptorNet, TuneClassifSub
 from model.custom_modules import TripletLoss
 from utils import (choose_rand_neg, choose_rand_neg_index, fold_batches, get_pos_couples, get_similarities, log, move_device, tensor,
                    test_print_descriptor, train_gen)
-from ._common import base_model, device_batch_size, fold_shape_buckets, load_weights, make_resident, scatter_rows, stage_batch, test_transform
+from ._common import base_model, device_batch_size, fold_shape_buckets, label_index, load_weights, make_resident, scatter_rows, stage_batch, test_transform
 from .siamese_descriptor import mine_epoch_negatives, shuffle_couples
 from .siamese_regions_p import P
 
@@ -60,7 +60,7 @@ def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, cr
         im3 = train_set[k][0] if k >= 0 else choose_rand_neg(train_set, lab)
         prep = (lambda im: im) if trans is None else trans
         mv = lambda im: move_device(prep(im).unsqueeze(0), P.cuda_device)
-        return [mv(im1), mv(im2), mv(im3)], [move_device(torch.tensor([labels.index(lab)], dtype=torch.int64), P.cuda_device)]
+        return [mv(im1), mv(im2), mv(im3)], [move_device(torch.tensor([label_index(labels)[lab]], dtype=torch.int64), P.cuda_device)]
 
     def create_loss(out, labels_list):
         # triplet loss on the descriptors + classification loss over the anchor's k windows (:139-150)
