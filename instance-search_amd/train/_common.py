@@ -125,7 +125,7 @@ def resolve_images(ims):
     for im in ims:
         if isinstance(im, LazyImage):
             t = im.get()
-            out.append(t.clone() if im.shared() else t)          # a decoder slot is recycled after release()
+            out.append(torch.from_numpy(t.numpy().copy()) if im.shared() else t)   # a decoder slot is recycled after release(); numpy's memcpy, not torch's OpenMP team
         else:
             out.append(im)
     for im in ims:

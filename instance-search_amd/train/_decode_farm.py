@@ -86,6 +86,13 @@ class Ticket(object):
     def result(self):
         return self.tensor()
 
+    def copy(self):
+        """The image as a tensor of its own (one memcpy on this thread).  Not tensor().clone(): torch copies 150 KB with its OpenMP team, and a
+        team of 16 that has to assemble while 14 decoder processes keep every core busy takes a scheduler quantum per copy -- 1 ms per image
+        measured on the MI355X box, 2.3 of the 4.6 s of an evaluation run on 22 000 files."""
+        t = self.tensor()
+        return torch.from_numpy(t.numpy().copy())
+
     def release(self):
         if not self._released:
             self._released = True
@@ -304,7 +311,7 @@ def decode_files(paths, slot_bytes, window=256, ahead=3):
                 nxt += window
             tickets = inflight[0]
             for t in tickets:
-                out.append(t.tensor().clone())
+                out.append(t.copy())
             for t in inflight.pop(0):
                 t.release()
     finally:
