@@ -367,31 +367,46 @@ def device_batch_size(P, dataset, shape=None):
     return bs * max(1, -(-_MIN_DEVICE_BATCH_PIXELS // max(bs * pixels, 1)))
 
 
-def fold_shape_buckets(f, dataset, batch_size):
+def fold_shape_buckets(f, dataset, batch_size, stage=None):
     """Call f(indices, items) on batches of SAME-SHAPED images: the dataset is bucketed by image shape (first-seen order,
     dataset order inside a bucket), every bucket cut into batches of `batch_size` -- an int, or a function of the bucket's image
     shape (device_batch_size per bucket: a small first image must not size the launches of the large ones).  The reference walks a
     ragged region dataset one image per step (train/classif_regions.py:107-132, model/siamese.py:184); bucketing keeps the backbone
     batched whatever the mix of sizes.  Per-image results are independent, so the order of evaluation does not matter; a launch the
-    device cannot hold (torch.cuda.OutOfMemoryError) is retried as two halves."""
+    device cannot hold (torch.cuda.OutOfMemoryError) is retried as two halves.
+    stage = (trans, device): f is called as f(indices, items, x) with x the batch already ON the device, staged by a BatchStager per bucket --
+    resident sets as row gathers, lazy / non-resident ones decoded ahead, stacked into reusable pinned buffers and copied on a copy stream while
+    the previous batch computes (staging batch by batch on the compute path -- decode, clone, stack, pin, copy -- was 1.4 ms per 448 x 448
+    image against 0.26 ms of kernels)."""
     buckets = {}
     for i, item in enumerate(dataset):
         buckets.setdefault((tuple(item[0].shape), item[0].dtype), []).append(i)
 
-    def run(ii):
+    def call(ii, items, x=None):
+        if stage is None:
+            f(ii, items)
+        else:
+            f(ii, items, stage_batch(items, stage[0], stage[1]) if x is None else x)
+
+    def run(ii, items, x=None):
         try:
-            f(ii, [dataset[j] for j in ii])
+            call(ii, items, x)
         except torch.cuda.OutOfMemoryError:
             if len(ii) == 1:
                 raise
+            del x
             torch.cuda.empty_cache()
-            run(ii[:len(ii) // 2])
-            run(ii[len(ii) // 2:])
+            h = len(ii) // 2
+            run(ii[:h], items[:h])
+            run(ii[h:], items[h:])
 
     for (shape, _), idx in buckets.items():
         bs = max(int(batch_size(shape) if callable(batch_size) else batch_size), 1)
+        sub = dataset if len(idx) == len(dataset) else [dataset[j] for j in idx]
+        stager = BatchStager(sub, bs, stage[0], stage[1]) if stage is not None else None
         for s in range(0, len(idx), bs):
-            run(idx[s:s + bs])
+            ii, items = idx[s:s + bs], sub[s:s + bs]
+            run(ii, items, stager.get(s, items) if stager is not None else None)
 
 
 def scatter_rows(slab, indices, rows):

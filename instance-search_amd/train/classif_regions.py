@@ -5,8 +5,8 @@ import torch
 
 from model.custom_modules import l2_normalize_rows
 from model.siamese import TuneClassif, TuneClassifSub
-from utils import fold_batches, move_device, tensor
-from ._common import base_model, device_batch_size, fold_shape_buckets, label_index, load_weights, make_resident, scatter_rows, stage_batch, test_transform
+from utils import move_device, tensor
+from ._common import base_model, device_batch_size, fold_shape_buckets, label_index, load_weights, make_resident, scatter_rows, test_transform
 from .classif_regions_p import P
 
 labels = []
@@ -28,21 +28,25 @@ def _best_location_descriptors(score_map):
 
 
 def test_classif_net(net, test_set):
+    """(correct, total): the prediction of an image is the class of its globally highest score over all locations.  The reference walks the set
+    one image at a time (:50, "batch size has to be 1 here": sizes may differ); an image's score map does not depend on the batch it rides in,
+    so same-shaped images share a launch here (fold_shape_buckets) -- 15 ms of host work per single-image pass otherwise."""
     trans = test_transform(P)
+    if trans is None:
+        make_resident(test_set, P.cuda_device)          # the queries are classified here AND embedded right after: uploaded once
+    ids = label_index(labels)
+    correct = [0]
 
-    def run(acc, i, is_final, batch):
-        correct, total = acc
+    def run(indices, batch, x):
         with torch.no_grad():
-            out = net(stage_batch(batch, trans, P.cuda_device))[0]
-            # prediction = class of the globally highest score over all locations
+            out = net(x)[0]
             pred = out.max(1)[0].flatten(1).argmax(1)
             flat = out.flatten(2)
-            cls = flat[torch.arange(out.size(0)), :, pred].argmax(1).tolist()
-        ids = label_index(labels)
-        correct += sum(1 for (_, lab, _), p in zip(batch, cls) if ids[lab] == p)
-        return correct, total + len(batch)
+            cls = flat[torch.arange(out.size(0), device=out.device), :, pred].argmax(1).tolist()
+        correct[0] += sum(1 for (_, lab, _), p in zip(batch, cls) if ids[lab] == p)
 
-    return fold_batches(run, (0, 0), test_set, 1)
+    fold_shape_buckets(run, test_set, lambda shape: device_batch_size(P, test_set, shape), stage=(trans, P.cuda_device))
+    return correct[0], len(test_set)
 
 
 def get_embeddings(net, dataset, device, out_size):
@@ -51,14 +55,14 @@ def get_embeddings(net, dataset, device, out_size):
         make_resident(dataset, P.cuda_device)
     slab = tensor(device, len(dataset), out_size)
 
-    def run(indices, batch):
+    def run(indices, batch, x):
         with torch.no_grad():
-            out = net(stage_batch(batch, trans, P.cuda_device))[0]
+            out = net(x)[0]
             scatter_rows(slab, indices, _best_location_descriptors(out))
 
     # the reference walks one image at a time (images may differ in size); here images are bucketed by shape and every
-    # bucket goes through in batches of P.test_batch_size
-    fold_shape_buckets(run, dataset, lambda shape: device_batch_size(P, dataset, shape))
+    # bucket goes through in batches of P.test_batch_size, staged ahead of the trunk (BatchStager)
+    fold_shape_buckets(run, dataset, lambda shape: device_batch_size(P, dataset, shape), stage=(trans, P.cuda_device))
     return slab
 
 

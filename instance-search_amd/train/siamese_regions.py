@@ -10,7 +10,7 @@ from model.siamese import RegionDescriptorNet, TuneClassifSub
 from model.custom_modules import TripletLoss
 from utils import (choose_rand_neg, choose_rand_neg_index, fold_batches, get_pos_couples, get_similarities, log, move_device, tensor,
                    test_print_descriptor, train_gen)
-from ._common import base_model, device_batch_size, fold_shape_buckets, label_index, load_weights, make_resident, scatter_rows, stage_batch, test_transform
+from ._common import base_model, device_batch_size, fold_shape_buckets, label_index, load_weights, make_resident, scatter_rows, test_transform
 from .siamese_descriptor import mine_epoch_negatives, shuffle_couples
 from .siamese_regions_p import P
 
@@ -23,12 +23,12 @@ def get_embeddings(net, dataset, device, out_size):
         make_resident(dataset, P.cuda_device)
     slab = tensor(device, len(dataset), out_size)
 
-    def run(indices, batch):
+    def run(indices, batch, x):
         with torch.no_grad():
-            scatter_rows(slab, indices, net(stage_batch(batch, trans, P.cuda_device)))
+            scatter_rows(slab, indices, net(x))
 
-    # one image per step in the reference; images bucketed by shape share a backbone pass here
-    fold_shape_buckets(run, dataset, lambda shape: device_batch_size(P, dataset, shape))
+    # one image per step in the reference; images bucketed by shape share a backbone pass here, staged ahead of the trunk (BatchStager)
+    fold_shape_buckets(run, dataset, lambda shape: device_batch_size(P, dataset, shape), stage=(trans, P.cuda_device))
     return slab
 
 

@@ -17,17 +17,19 @@ import torch  # noqa: E402
 from PIL import Image  # noqa: E402
 
 NG, NQ, NL = (int(os.environ.get(k, d)) for k, d in (("LAB_GALLERY", "20000"), ("LAB_QUERIES", "2000"), ("LAB_LABELS", "2000")))
+MAIN, SIZE = os.environ.get("LAB_MAIN", "classif_finetune"), int(os.environ.get("LAB_SIZE", "224"))   # LAB_MAIN=classif_regions LAB_SIZE=448: the region path
 tmp = tempfile.mkdtemp(prefix="isx_e2e_")
-root = os.path.join(tmp, "CLICIDE_video_224sq")
+root = os.path.join(tmp, "CLICIDE_video_224sq" if SIZE == 224 else "CLICIDE_video_448")
 os.makedirs(os.path.join(root, "test"))
 os.makedirs(os.path.join(tmp, "data"))
-open(os.path.join(tmp, "data", "CLICIDE_224sq_train_ms.txt"), "w").write("0.485 0.456 0.406\n0.229 0.224 0.225\n")
+for name in ("CLICIDE_224sq", "CLICIDE_448"):
+    open(os.path.join(tmp, "data", name + "_train_ms.txt"), "w").write("0.485 0.456 0.406\n0.229 0.224 0.225\n")
 
 
 def write(job):
     i, path = job
     low = np.random.default_rng(i % 4096).integers(0, 256, (8, 8, 3), dtype=np.uint8)
-    im = np.asarray(Image.fromarray(low).resize((224, 224), Image.BICUBIC), dtype=np.int16)
+    im = np.asarray(Image.fromarray(low).resize((SIZE, SIZE), Image.BICUBIC), dtype=np.int16)
     im = np.clip(im + np.random.default_rng(10 ** 6 + i).integers(-12, 13, im.shape), 0, 255).astype(np.uint8)
     Image.fromarray(im).save(path, quality=90)
 
@@ -40,14 +42,17 @@ with ProcessPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)))) as p
     list(pool.map(write, jobs, chunksize=64))
 print("wrote %d files in %.1f s" % (len(jobs), time.perf_counter() - t0), flush=True)
 os.chdir(tmp)
-from test import classif_finetune_test  # noqa: E402
+from test import classif_finetune_test, classif_regions_test  # noqa: E402
 try:
     for rep in range(2):                       # the second run is the one to read (kernels loaded, decoder processes started)
         pr = cProfile.Profile()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         pr.enable()
-        res = classif_finetune_test.main(root, "resnet50", "", 0, False, 64, 0)
+        if MAIN == "classif_regions":
+            res = classif_regions_test.main(root, "resnet50", "", 0, 0)
+        else:
+            res = classif_finetune_test.main(root, "resnet50", "", 0, False, 64, 0)
         pr.disable()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
