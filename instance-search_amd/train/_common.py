@@ -1,6 +1,7 @@
 """Shared pieces of the four per-approach modules: batch staging and net construction."""
 import os
 
+import numpy as np
 import torch
 
 from isx import backbones
@@ -146,28 +147,32 @@ _STACK_POOL = None
 
 
 def _parallel_stack(chunk, out):
-    """out[:len(chunk)] = stack(chunk): the copy is one memcpy per image, spread over a few threads (torch releases the GIL inside)."""
+    """out[:len(chunk)] = stack(chunk): one memcpy per image (numpy's copy loop: the GIL is released, no OpenMP team), spread over a few threads.
+    torch.stack moved the same bytes at 1.75 GB/s next to busy decoder processes (44 ms per 128 images of 448 x 448 x 3): its OpenMP team of
+    16 has to assemble on cores the decoders occupy."""
     global _STACK_POOL
     k = len(chunk)
     first = chunk[0]
-    if first.dtype == torch.uint8 and first.numel() % 8 == 0:
-        # decoded uint8 images (the raw ingest): torch's byte-wise copy loop moves ~1.9 GB/s (40 ms per 512 images of 224 x 224 x 3: more than
-        # the trunk needs for them); the same bytes viewed as int64 words go at memcpy speed (15 ms, per-tensor overhead included)
-        try:
-            torch.stack([im.reshape(-1).view(torch.int64) for im in chunk], 0, out=out[:k].view(k, -1).view(torch.int64))
-            return
-        except RuntimeError:
-            pass                                    # unaligned storage offset / non-contiguous image: the plain path below
-    workers = min(8, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    if workers <= 1 or k < 64:
+    if first.is_cuda or out.is_cuda or not first.is_contiguous() or any(im.shape != first.shape or im.dtype != first.dtype for im in chunk):
         torch.stack(chunk, 0, out=out[:k])
+        return
+    dst = out[:k].numpy()
+    srcs = [im.numpy() for im in chunk]
+    workers = min(4, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    if workers <= 1 or k < 8 or k * first.numel() * first.element_size() < (4 << 20):
+        for j, a in enumerate(srcs):
+            np.copyto(dst[j], a)
         return
     if _STACK_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
         _STACK_POOL = ThreadPoolExecutor(max_workers=workers)
     step = -(-k // workers)
-    futs = [_STACK_POOL.submit(torch.stack, chunk[j:j + step], 0, out=out[j:min(j + step, k)]) for j in range(0, k, step)]
-    for f in futs:
+
+    def part(j0):
+        for j in range(j0, min(j0 + step, k)):
+            np.copyto(dst[j], srcs[j])
+
+    for f in [_STACK_POOL.submit(part, j0) for j0 in range(0, k, step)]:
         f.result()
 
 
