@@ -42,7 +42,7 @@ with ProcessPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)))) as p
     list(pool.map(write, jobs, chunksize=64))
 print("wrote %d files in %.1f s" % (len(jobs), time.perf_counter() - t0), flush=True)
 os.chdir(tmp)
-from test import classif_finetune_test, classif_regions_test  # noqa: E402
+from test import classif_finetune_test, classif_regions_test, siamese_descriptor_test, siamese_regions_test  # noqa: E402
 try:
     for rep in range(2):                       # the second run is the one to read (kernels loaded, decoder processes started)
         pr = cProfile.Profile()
@@ -51,6 +51,10 @@ try:
         pr.enable()
         if MAIN == "classif_regions":
             res = classif_regions_test.main(root, "resnet50", "", 0, 0)
+        elif MAIN == "siamese_descriptor":
+            res = siamese_descriptor_test.main(root, "resnet50", "", 0, 2048, 64, 0)
+        elif MAIN == "siamese_regions":
+            res = siamese_regions_test.main(root, "resnet50", "", 0, 2048, 6, 0)
         else:
             res = classif_finetune_test.main(root, "resnet50", "", 0, False, 64, 0)
         pr.disable()
