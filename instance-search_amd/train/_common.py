@@ -422,6 +422,56 @@ def scatter_rows(slab, indices, rows):
         slab.index_copy_(0, torch.tensor(indices, dtype=torch.int64, device=slab.device), rows.to(slab.dtype))
 
 
+def load_training_sets(P, dataset_full, labels):
+    """(train_set, test_train_set, test_set) of a training run from the dataset folder (or `synthetic:` spec), as the reference's training mains
+    read them (train/siamese_descriptor.py:166-191): the images of `dataset_full` train AND serve as the gallery of the evaluations, those of
+    `<dataset_full>/test` whose label is known are the queries.  With images pre-processed once and nothing augmented (P.train_pre_proc, the
+    reference's setting: train_trans == test_trans) the training and the gallery set are the same tensors -- one list serves as both (the
+    reference keeps two copies).  The dataset-dependent fields of P (reference train/*_p.py:27-48) are filled from the dataset id.  On the GPU
+    the sets carry raw uint8 pixels (normalised on the device), decoded by the processes of train/_decode_farm.py."""
+    from test import _common as C
+    from .global_p import feature_sizes, image_sizes
+    dataset_id = C.dataset_id_of(dataset_full)
+    if not getattr(P, 'train_pre_proc', True) or getattr(P, 'train_trans', None) is not None:
+        raise NotImplementedError("training entry point: only pre-processed, un-augmented training sets (P.train_pre_proc = True, P.train_trans = None); "
+                                  "build augmented sets yourself and call main(train_set, test_train_set, test_set)")
+    del labels[:]
+    test_set, ref_set = C.load_sets(dataset_full, labels, raw=(P.cuda_device >= 0), lazy=False)
+    P.dataset_full, P.dataset_id = dataset_full, dataset_id
+    P.image_input_size = image_sizes[dataset_id]
+    P.num_classes = len(labels)
+    P.feature_size2d = feature_sizes[str(P.cnn_model).lower(), image_sizes[dataset_id]]
+    P.test_pre_proc = True
+    return ref_set, ref_set, test_set
+
+
+def training_cli(argv, P, run, what):
+    """`python -m train.<approach> --dataset=<folder | synthetic:...> [--model=] [--device=] [--epochs=] [--classif-model=] [--preload-net=]
+    [--save-dir=] [--feature-dim=] [--batch-size=] [--micro-batch=] [--lr=]`: the reference's training scripts take everything from their
+    *_p.py file (edit and run); the same fields can be given here instead."""
+    import getopt
+    import sys
+    spec = {'dataset': ('dataset_full', str), 'model': ('cnn_model', str), 'device': ('cuda_device', int), 'epochs': ('train_epochs', int),
+            'classif-model': ('classif_model', str), 'preload-net': ('preload_net', str), 'save-dir': ('save_dir', str),
+            'feature-dim': ('feature_dim', int), 'batch-size': ('train_batch_size', int), 'micro-batch': ('train_micro_batch', int),
+            'lr': ('train_lr', float), 'seed': ('train_seed', int)}
+    try:
+        opts, _ = getopt.getopt(argv, '', ['help'] + [k + '=' for k in spec])
+    except getopt.GetoptError as e:
+        print('%s\nusage: python -m %s %s' % (e, what, ' '.join('[--%s=]' % k for k in spec)))
+        sys.exit(2)
+    for opt, arg in opts:
+        if opt == '--help':
+            print('usage: python -m %s %s' % (what, ' '.join('[--%s=]' % k for k in spec)))
+            sys.exit()
+        field, typ = spec[opt[2:]]
+        setattr(P, field, typ(arg))
+    if not getattr(P, 'dataset_full', None):
+        print('no dataset: give --dataset=<folder> (or synthetic:<dataset id>[:n=..][:q=..][:labels=..]) or set P.dataset_full')
+        sys.exit(2)
+    return run()
+
+
 _LABEL_IDS = {}
 
 

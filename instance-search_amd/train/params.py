@@ -63,6 +63,9 @@ class Params(object):
         self.embeddings_cuda_size = 64 * 2 ** 30
         self.log_file = None
         # --- siamese training (train/siamese_descriptor_p.py:62-101 of the reference) ---
+        self.dataset_full = ''                 # a dataset folder (+ its `test` sub-folder) or a `synthetic:` spec: what `python -m train.<approach>` reads
+        self.test_upfront = True               # evaluate before training (reference train/siamese_descriptor_p.py:56)
+        self.train = True
         self.train_epochs = 20
         self.train_batch_size = 64
         self.train_micro_batch = 8

@@ -148,7 +148,22 @@ def main(train_set, test_train_set, test_set):
     optimizer = make_sgd((p for p in net.parameters() if p.requires_grad), P.train_lr, P.train_momentum, P.train_weight_decay)
     criterion = TripletLoss(P.triplet_margin, P.train_loss_avg)
     testset_tuple = (test_set, test_train_set)
-    score = test_print_descriptor(train_type, P, net, testset_tuple, get_embeddings)
+    score = test_print_descriptor(train_type, P, net, testset_tuple, get_embeddings) if getattr(P, 'test_upfront', True) else 0
+    if not getattr(P, 'train', True):
+        return net, score
     score = train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, optimizer, best_score=score)
     test_print_descriptor(train_type, P, net, testset_tuple, get_embeddings, best_score=len(test_set) + 1)
     return net, score
+
+
+def run(dataset_full=None):
+    """The reference's main() (:165-207): the sets come from P.dataset_full (a dataset folder with its `test` sub-folder, or a `synthetic:` spec),
+    then upfront test (P.test_upfront) -> training (P.train) -> final test, as main() above does on loaded sets."""
+    from ._common import load_training_sets
+    return main(*load_training_sets(P, dataset_full or P.dataset_full, labels))
+
+
+if __name__ == '__main__':
+    import sys
+    from ._common import training_cli
+    training_cli(sys.argv[1:], P, run, 'train.siamese_descriptor')

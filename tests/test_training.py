@@ -734,3 +734,35 @@ def test_region_training_runs_on_gpu(model, fs, size):
         assert any(p.grad is not None and float(p.grad.abs().sum()) > 0 for n, p in net.named_parameters() if n.startswith("features.") and p.requires_grad)
     finally:
         sr.P.__dict__.clear(); sr.P.__dict__.update(saved)
+
+
+def test_training_entry_point_reads_its_dataset_like_the_reference(monkeypatch, capsys):
+    """`run()` / `python -m train.siamese_descriptor`: the sets come from P.dataset_full (here a `synthetic:` spec), the dataset-dependent fields of P
+    are filled from the dataset id, P.test_upfront / P.train are honoured, and the command-line form sets the same fields."""
+    import copy
+    from train import _common as TC
+    from train import siamese_descriptor as sd
+    saved = copy.copy(sd.P.__dict__)
+    calls = []
+    monkeypatch.setattr(sd, "train_siam_triplets_pos_couples", lambda net, train_set, testset_tuple, *a, **k: calls.append((len(train_set), len(testset_tuple[0]))) or 7)
+    monkeypatch.setattr(sd, "test_print_descriptor", lambda *a, **k: calls.append("test") or 3)
+    monkeypatch.setattr(sd, "get_siamese_net", lambda: nn.Linear(2, 2))
+    try:
+        P = sd.P
+        P.cuda_device, P.cnn_model = -1, "alexnet"
+        net, score = sd.run("synthetic:CLICIDE_video_224sq:n=12:q=4:labels=3:size=32")
+        assert calls == ["test", (12, 4), "test"] and score == 7
+        assert P.num_classes == 3 and P.feature_size2d == (6, 6) and tuple(P.image_input_size) == (3, 224, 224) and sd.labels == sorted(sd.labels) and len(sd.labels) == 3
+        del calls[:]
+        P.test_upfront, P.train = False, False
+        net, score = sd.run("synthetic:CLICIDE_video_224sq:n=12:q=4:labels=3:size=32")
+        assert calls == [] and score == 0
+        P.test_upfront, P.train = True, True
+        TC.training_cli(["--dataset=synthetic:CLICIDE_video_224sq:n=8:q=4:labels=2:size=32", "--model=alexnet", "--device=-1", "--epochs=3", "--lr=0.5"], P, sd.run,
+                        "train.siamese_descriptor")
+        assert calls == ["test", (8, 4), "test"] and P.train_epochs == 3 and P.train_lr == 0.5 and P.dataset_full.startswith("synthetic:")
+        P.train_pre_proc = False
+        with pytest.raises(NotImplementedError):
+            sd.run()
+    finally:
+        sd.P.__dict__.clear(); sd.P.__dict__.update(saved)
