@@ -469,6 +469,23 @@ def training_cli(argv, P, run, what):
     if not getattr(P, 'dataset_full', None):
         print('no dataset: give --dataset=<folder> (or synthetic:<dataset id>[:n=..][:q=..][:labels=..]) or set P.dataset_full')
         sys.exit(2)
+    # data parallel: `python -m torch.distributed.run --nproc-per-node N -m train.<approach> ...` -- one rank per GPU (RCCL; gloo for CPU runs);
+    # utils.train_gen finds the process group and splits every mini-batch's micro-batches over the ranks (isx/dp.py)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        import torch.distributed as dist
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        if P.cuda_device >= 0:
+            P.cuda_device = local
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group('gloo')
+        try:
+            return run()
+        finally:
+            dist.barrier()
+            dist.destroy_process_group()
     return run()
 
 

@@ -766,3 +766,33 @@ def test_training_entry_point_reads_its_dataset_like_the_reference(monkeypatch, 
             sd.run()
     finally:
         sd.P.__dict__.clear(); sd.P.__dict__.update(saved)
+
+
+def test_training_entry_point_under_a_two_rank_launch(tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 <script calling train._common.training_cli>` (gloo, CPU): the command-line entry opens the
+    process group, train_gen splits the micro-batches over the two ranks, and both ranks end on the same weights as ONE process run from the same
+    command."""
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=os.path.join(ROOT, "instance-search_amd"), OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--dataset=synthetic:CLICIDE_video_224sq:n=6:q=2:labels=2:size=224", "--model=alexnet", "--device=-1", "--epochs=1", "--batch-size=4", "--micro-batch=2",
+            "--feature-dim=16", "--seed=3"]
+    drv = ("import os, sys, torch\n"
+           "from train import siamese_descriptor as sd\nfrom train import _common as TC\n"
+           "torch.manual_seed(0); torch.set_num_threads(1)\n"
+           "sd.P.test_upfront = False; sd.P.train_loss_int = 1000\n"
+           "net, _ = TC.training_cli(%r, sd.P, sd.run, 'train.siamese_descriptor')\n"
+           "torch.save({k: v.clone() for k, v in net.state_dict().items()}, %r + os.environ.get('RANK', 'single'))\n") % (args, str(tmp_path / "w."))
+    script = tmp_path / "drv.py"
+    script.write_text(drv)
+    one = subprocess.run([sys.executable, str(script)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(_free_port()), str(script)], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    a, b0, b1 = (torch.load(str(tmp_path / ("w." + r))) for r in ("single", "0", "1"))
+    for k in a:
+        assert torch.equal(b0[k], b1[k]), k
+        assert torch.equal(a[k], b0[k]), k
+    assert any("feature_reduc1" in k for k in a)
