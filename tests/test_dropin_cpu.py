@@ -439,6 +439,29 @@ def test_region_embeddings_bucket_ragged_images_by_shape():
     fold_shape_buckets(lambda ii, items: seen.append((ii, [tuple(t.shape) for t, _, _ in items])), ds, 3)
     assert [ii for ii, _ in seen] == [[0, 2, 5], [6, 8], [1, 3, 4], [7]]
     assert all(len(set(shapes)) == 1 for _, shapes in seen)
+    # stage = (trans, device): the batch arrives staged (here: CPU, a plain stack), same buckets, rows in dataset order; a launch the device cannot
+    # hold is retried as two halves with batches staged on the spot
+    staged, ooms = [], []
+
+    def f(ii, items, x):
+        if len(ii) == 3 and not ooms:
+            ooms.append(ii)
+            raise torch.cuda.OutOfMemoryError("simulated")
+        assert x.shape[0] == len(ii) == len(items) and all(torch.equal(x[k], items[k][0]) for k in range(len(ii)))
+        staged.append(ii)
+
+    fold_shape_buckets(f, ds, 3, stage=(None, -1))
+    assert ooms == [[0, 2, 5]] and staged == [[0], [2, 5], [6, 8], [1, 3, 4], [7]]
+    # test_classif_net walks the same buckets (the reference: one image per pass) and counts every image once
+    torch.manual_seed(0)
+    cr.P.cuda_device, cr.P.test_pre_proc, cr.P.test_batch_size = -1, True, 4
+    del cr.labels[:]
+    cr.labels.extend(sorted(set(l for _, l, _ in ds)))
+    sub0 = TuneClassifSub(backbones.alexnet(pretrained=True), 3, (6, 6)).eval()
+    c4, t4 = cr.test_classif_net(sub0, ds)
+    cr.P.test_batch_size = 1
+    c1, t1 = cr.test_classif_net(sub0, ds)
+    assert t4 == t1 == len(ds) and c4 == c1
     torch.manual_seed(0)
     sub = TuneClassifSub(backbones.alexnet(pretrained=True), 3, (6, 6)).eval()
     for P_ in (cr.P, sr.P):
