@@ -310,8 +310,32 @@ class _SplitRows(torch.autograd.Function):
         return torch.cat([g if g is not None else ref.new_zeros((n,) + rest) for g in grads], 0), None
 
 
+_SKIP_HEAD_INIT = [False]
+
+
+class head_weights_follow(object):
+    """`with head_weights_follow(bool(P.preload_net)):` around the construction of a siamese net whose state dict is loaded right after: the
+    822 MB descriptor head is allocated without its random initialisation (0.6 s of `uniform_` on the host per evaluation run; the reference
+    pays it too, model/siamese.py:110-114 + train/siamese_descriptor.py:158-160).  Without a file to load nothing changes."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = _SKIP_HEAD_INIT[0]
+        _SKIP_HEAD_INIT[0] = self.on
+        return self
+
+    def __exit__(self, *exc):
+        _SKIP_HEAD_INIT[0] = self.prev
+
+
 def _descriptor_head(in_features, out_features):
-    return nn.Sequential(NormalizeL2(), Shift(in_features), RowDeferredLinear(in_features, out_features))
+    if _SKIP_HEAD_INIT[0]:
+        lin = torch.nn.utils.skip_init(RowDeferredLinear, in_features, out_features)
+    else:
+        lin = RowDeferredLinear(in_features, out_features)
+    return nn.Sequential(NormalizeL2(), Shift(in_features), lin)
 
 
 def _apply_head(head, rows):

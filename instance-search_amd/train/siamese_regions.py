@@ -35,7 +35,9 @@ def get_embeddings(net, dataset, device, out_size):
 def get_siamese_net():
     class_net = TuneClassifSub(base_model(P), P.num_classes, P.feature_size2d, untrained=P.untrained_blocks)
     load_weights(class_net, P.classif_model)
-    net = RegionDescriptorNet(class_net, P.regions_k, P.feature_dim, P.feature_size2d, untrained=P.untrained_blocks)
+    from model.siamese import head_weights_follow
+    with head_weights_follow(bool(P.preload_net)):               # the state dict loaded below brings the head's weights
+        net = RegionDescriptorNet(class_net, P.regions_k, P.feature_dim, P.feature_size2d, untrained=P.untrained_blocks)
     return move_device(load_weights(net, P.preload_net), P.cuda_device)
 
 

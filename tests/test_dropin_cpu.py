@@ -603,3 +603,33 @@ def test_gallery_slab_cli_round_trip_on_the_cpu(tmp_path, capsys):
     assert r1 == r2 and "descriptors written to" in out and "descriptors read from" in out
     with pytest.raises(ValueError, match="another label set"):
         T.main("synthetic:CLICIDE_video_224sq:n=24:q=6:labels=5", "alexnet", "", -1, True, 8, 0, gallery_slab=f)
+
+
+def test_descriptor_head_skips_its_random_init_when_weights_follow(tmp_path):
+    """get_siamese_net with P.preload_net: the head is allocated without the 0.6 s random initialisation and then filled from the file -- the
+    loaded net equals the saved one; without a file the usual seeded init is untouched."""
+    import copy
+    from train import siamese_descriptor as sd
+    saved = copy.copy(sd.P.__dict__)
+    try:
+        P = sd.P
+        P.cuda_device, P.cnn_model, P.feature_size2d, P.feature_dim, P.num_classes, P.classif_model, P.preload_net = -1, "alexnet", (6, 6), 16, 3, "", ""
+        torch.manual_seed(0)
+        a = sd.get_siamese_net()
+        torch.manual_seed(0)
+        b = sd.get_siamese_net()
+        assert all(torch.equal(v, b.state_dict()[k]) for k, v in a.state_dict().items())            # seeded init unchanged
+        f = str(tmp_path / "w.pth.tar")
+        torch.save(a.state_dict(), f)
+        P.preload_net = f
+        calls = []
+        real = torch.nn.Linear.reset_parameters
+        torch.nn.Linear.reset_parameters = lambda self: calls.append((tuple(self.weight.shape), self.weight.device.type)) or real(self)
+        try:
+            c = sd.get_siamese_net()
+        finally:
+            torch.nn.Linear.reset_parameters = real
+        assert ((16, 256 * 6 * 6), "meta") in calls and ((16, 256 * 6 * 6), "cpu") not in calls    # the head's Linear was not initialised (skip_init: on the meta device only) ...
+        assert all(torch.equal(v, c.state_dict()[k]) for k, v in a.state_dict().items())            # ... and holds the file's weights
+    finally:
+        sd.P.__dict__.clear(); sd.P.__dict__.update(saved)
