@@ -519,8 +519,15 @@ def base_model(P, pretrained=True):
 
 
 def load_weights(net, fname):
+    """net.load_state_dict(torch.load(fname)) (reference train/siamese_descriptor.py:158-160).  Files in torch's zip format are memory-mapped (the
+    822 MB descriptor head is copied once, file -> parameter, not file -> RAM -> parameter); the legacy pickle files reference-era torch wrote
+    are read as before."""
     if fname:
-        net.load_state_dict(torch.load(fname, map_location='cpu'))
+        try:
+            state = torch.load(fname, map_location='cpu', mmap=True)
+        except (RuntimeError, ValueError, TypeError):
+            state = torch.load(fname, map_location='cpu')
+        net.load_state_dict(state)
     return net
 
 
