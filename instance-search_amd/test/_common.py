@@ -138,6 +138,99 @@ def _decode_all(load, files):
         return list(pool.map(load, files))
 
 
+# ---- data-parallel evaluation (SURVEY 8e): `python -m torch.distributed.run --nproc-per-node N -m test.<approach>_test ...` ------------------------
+# Extraction is embarrassingly parallel (images are independent): every rank extracts a contiguous 1/N of the queries and of the gallery, the
+# descriptor rows are all-gathered (1 M x 2048 fp32 = 8.2 GB: every GPU of the node holds the whole slab with room to spare), and the metrics are
+# split by QUERY rows -- P@1 and AP of a query need its whole score row, which each rank computes against the full gallery for its queries, with
+# the same kernels on the same values as one process would.  The counts are summed, the per-query APs gathered in query order and averaged as
+# the single-process run averages them: the printed lines are the same.  (Galleries beyond one GPU's memory: isx.retrieval.ShardedGallery,
+# top-k metrics -- bench.py's retrieval_shard leg.)
+def dp_world():
+    import torch.distributed as dist
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def dp_bounds(n, world, rank):
+    """[lo, hi): the contiguous slice of n items that belongs to `rank`."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def _dp_gather_rows(local, counts, device):
+    """All ranks' row blocks (rank r holds counts[r] rows) -> the whole (sum(counts), D) tensor on every rank, rows in rank order."""
+    import torch.distributed as dist
+    world, D, most = len(counts), local.size(1), max(counts)
+    pad = local.new_zeros((most, D))
+    pad[:local.size(0)].copy_(local)
+    if dist.get_backend() == 'nccl':
+        out = pad.new_empty((world * most, D))
+        dist.all_gather_into_tensor(out, pad)
+        parts = [out[r * most:r * most + counts[r]] for r in range(world)]
+    else:
+        host = pad.cpu()
+        bufs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(bufs, host)
+        parts = [bufs[r][:counts[r]].to(local.device) for r in range(world)]
+    return torch.cat(parts, 0)
+
+
+def dp_sync_net(net):
+    """Every rank evaluates rank 0's network: without a weights file the layers a wrapper adds (a new classifier, the descriptor head) are
+    random-initialised, differently on every rank."""
+    if dp_world()[1] > 1:
+        from isx.dp import broadcast_module_state
+        broadcast_module_state(net, src=0)
+    return net
+
+
+def dp_classify(test_classif_net, net, test_set):
+    """test_classif_net over the ranks: (correct, total) of the whole set on every rank."""
+    rank, world = dp_world()
+    if world == 1:
+        return test_classif_net(net, test_set)
+    import torch.distributed as dist
+    lo, hi = dp_bounds(len(test_set), world, rank)
+    c, t = test_classif_net(net, test_set[lo:hi]) if hi > lo else (0, 0)
+    dev = next(net.parameters()).device if dist.get_backend() == 'nccl' else 'cpu'
+    tot = torch.tensor([int(c), int(t)], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot)
+    return int(tot[0]), int(tot[1])
+
+
+def dp_embeddings(get_embeddings, net, dataset, device, out_size):
+    """get_embeddings over the ranks: each extracts its contiguous slice of `dataset`, every rank returns the whole (len(dataset), out_size) slab."""
+    rank, world = dp_world()
+    if world == 1:
+        return get_embeddings(net, dataset, device, out_size)
+    counts = [dp_bounds(len(dataset), world, r)[1] - dp_bounds(len(dataset), world, r)[0] for r in range(world)]
+    lo, hi = dp_bounds(len(dataset), world, rank)
+    if hi > lo:
+        local = get_embeddings(net, dataset[lo:hi], device, out_size)
+    else:
+        local = torch.zeros((0, out_size), device=('cuda:%d' % device if device >= 0 else 'cpu'))
+    return _dp_gather_rows(local, counts, device)
+
+
+def dp_metrics(test_embeddings, ref_embeddings, test_set, ref_set):
+    """retrieval_metrics with the QUERIES split over the ranks (each against the whole gallery); the dict of the whole query set on every rank."""
+    rank, world = dp_world()
+    if world == 1:
+        return retrieval_metrics(test_embeddings, ref_embeddings, test_set, ref_set)
+    import torch.distributed as dist
+    lo, hi = dp_bounds(len(test_set), world, rank)
+    if hi > lo:
+        m = retrieval_metrics(test_embeddings[lo:hi], ref_embeddings, test_set[lo:hi], ref_set)
+        mine = (int(m['correct']), list(m['aps']))
+    else:
+        mine = (0, [])
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    correct = sum(c for c, _ in parts)
+    aps = [a for _, ap in parts for a in ap]                # rank order = query order
+    valid = [a for a in aps if a == a]
+    M = len(test_set)
+    return {'prec1': float(correct) / M, 'correct': correct, 'total': M, 'mAP': sum(valid) / float(len(valid)) if valid else float('nan'), 'aps': aps}
+
+
 def gallery_embeddings(get_embeddings, net, ref_set, device, out_size, labels, save_slab=None, gallery_slab=None):
     """(gallery descriptors, gallery set) of an evaluation run.  Default: extracted, as the reference does on every run
     (test/classif_finetune_test.py:80-81).  --save-slab=<file>: the extracted slab is also written to disk (isx/slab.py: row blocks streamed from
@@ -153,9 +246,10 @@ def gallery_embeddings(get_embeddings, net, ref_set, device, out_size, labels, s
             raise ValueError('--gallery-slab: %s holds %d-d descriptors, this run computes %d-d ones' % (gallery_slab, desc.size(1), out_size))
         print('Gallery: {0} descriptors read from {1}'.format(desc.size(0), gallery_slab))
         return desc, slab_set
-    emb = get_embeddings(net, ref_set, device, out_size)
+    emb = dp_embeddings(get_embeddings, net, ref_set, device, out_size)
     if save_slab:
-        slab.save_gallery(save_slab, emb, ref_set, labels)
+        if dp_world()[0] == 0:                               # every rank holds the whole slab; one writes it
+            slab.save_gallery(save_slab, emb, ref_set, labels)
         print('Gallery: {0} descriptors written to {1}'.format(emb.size(0), save_slab))
     return emb, ref_set
 
@@ -165,7 +259,7 @@ def evaluate_retrieval(test_embeddings, ref_embeddings, test_set, ref_set, devic
     (prec1, mAP) pair of the plain pass (the reference returns nothing; the prints are the API)."""
     # sim = torch.mm(test_emb, ref_emb.t()) -> precision1 -> mean_avg_precision (reference test/classif_finetune_test.py:82-85),
     # evaluated in query-row blocks when the matrix exceeds utils.metrics.SIM_BUDGET_BYTES (same values, no 40 GB matrix)
-    m = retrieval_metrics(test_embeddings, ref_embeddings, test_set, ref_set)
+    m = dp_metrics(test_embeddings, ref_embeddings, test_set, ref_set)
     prec1, mAP = m['prec1'], m['mAP']
     print('Descriptor (TEST): {0} / {1} - acc: {2:.4f} - mAP:{3:.4f}'.format(m['correct'], m['total'], prec1, mAP))
     if dba == 0:
@@ -173,7 +267,7 @@ def evaluate_retrieval(test_embeddings, ref_embeddings, test_set, ref_set, devic
     from .instance_avg import instance_avg
     print('Testing using instance feature augmentation')
     dba_embeddings, dba_set = instance_avg(device, ref_embeddings, ref_set, labels, dba)
-    d = retrieval_metrics(test_embeddings, dba_embeddings, test_set, dba_set)
+    d = dp_metrics(test_embeddings, dba_embeddings, test_set, dba_set)
     print('Descriptor (TEST DBA k={4}): {0} / {1} - acc: {2:.4f} - mAP:{3:.4f}'.format(d['correct'], d['total'], d['prec1'], d['mAP'], dba))
     return prec1, mAP
 
@@ -214,15 +308,39 @@ def run_cli(argv, usage, spec, required, main, P):
     if 'dba' not in spec:
         values.pop('dba', None)
     device = values['device']
-    try:
-        if device >= 0:
-            with torch.cuda.device(device):
-                main(**values)
+    # data parallel: under `python -m torch.distributed.run --nproc-per-node N` every rank takes GPU LOCAL_RANK (RCCL; gloo for CPU runs, and with
+    # ISX_BENCH_ONE_DEVICE=1 -- a rehearsal on a one-GPU box: every rank on cuda:0); rank 0 prints
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    quiet = None
+    if world > 1:
+        import torch.distributed as dist
+        one_device = os.environ.get('ISX_BENCH_ONE_DEVICE', '0') == '1'
+        if device >= 0 and not one_device:
+            device = values['device'] = int(os.environ.get('LOCAL_RANK', '0'))
+            torch.cuda.set_device(device)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device))
         else:
-            main(**values)
+            dist.init_process_group('gloo')
+        if dist.get_rank() != 0:
+            quiet = open(os.devnull, 'w')
+    try:
+        import contextlib
+        with (contextlib.redirect_stdout(quiet) if quiet is not None else contextlib.nullcontext()):
+            if device >= 0:
+                with torch.cuda.device(device):
+                    return main(**values)
+            else:
+                return main(**values)
     except Exception:
         log_detail(P, None, traceback.format_exc())
         raise
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        if quiet is not None:
+            quiet.close()
 
 
 def usage_text(script, lines):

@@ -30,11 +30,11 @@ def main(dataset_full, model, weights, device, dba, save_slab=None, gallery_slab
     P.bn_model = ''
 
     print('Testing network on dataset with ID {0}'.format(dataset_id))
-    class_net = get_class_net()
+    class_net = C.dp_sync_net(get_class_net())
     prepare_for_inference(class_net, P)
-    c, t = test_classif_net(class_net, test_set)
+    c, t = C.dp_classify(test_classif_net, class_net, test_set)
     print('Classification (TEST): {0} / {1} - acc: {2:.4f}'.format(c, t, float(c) / t))
-    test_embeddings = get_embeddings(class_net, test_set, device, len(labels))
+    test_embeddings = C.dp_embeddings(get_embeddings, class_net, test_set, device, len(labels))
     ref_embeddings, test_train_set = C.gallery_embeddings(get_embeddings, class_net, test_train_set, device, len(labels), labels, save_slab, gallery_slab)
     return C.evaluate_retrieval(test_embeddings, ref_embeddings, test_set, test_train_set, device, labels, dba)
 

@@ -34,9 +34,9 @@ def main(dataset_full, model, weights, device, feature_dim, regions_k, dba, save
     P.regions_k = regions_k
 
     print('Testing network on dataset with ID {0}'.format(dataset_id))
-    net = get_siamese_net()
+    net = C.dp_sync_net(get_siamese_net())
     prepare_for_inference(net, P)
-    test_embeddings = get_embeddings(net, test_set, device, net.feature_size)
+    test_embeddings = C.dp_embeddings(get_embeddings, net, test_set, device, net.feature_size)
     ref_embeddings, test_train_set = C.gallery_embeddings(get_embeddings, net, test_train_set, device, net.feature_size, labels, save_slab, gallery_slab)
     return C.evaluate_retrieval(test_embeddings, ref_embeddings, test_set, test_train_set, device, labels, dba)
 

@@ -126,5 +126,5 @@ def retrieval_metrics(test_emb, ref_emb, test_set, ref_set, kth=1, budget_bytes=
                 sum_all += float(sim.double().sum())
         del sim
     valid = [a for a in aps if a == a]
-    return {"prec1": float(correct) / M, "correct": correct, "total": M, "max_sim": torch.cat(max_sims, 0), "max_label": max_label,
-            "mAP": sum(valid) / float(len(valid)), "sum_pos": sum_pos, "sum_all": sum_all, "blocks": len(blocks)}
+    return {"prec1": float(correct) / max(M, 1), "correct": correct, "total": M, "max_sim": torch.cat(max_sims, 0) if max_sims else None, "max_label": max_label,
+            "mAP": sum(valid) / float(len(valid)) if valid else float("nan"), "aps": aps, "sum_pos": sum_pos, "sum_all": sum_all, "blocks": len(blocks)}

@@ -4,11 +4,14 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -80,3 +83,25 @@ def test_shard_bounds_cover_rows():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+@pytest.mark.parametrize("main_args", [
+    ["test.classif_finetune_test", "--dataset=synthetic:CLICIDE_video_224sq:n=14:q=5:labels=3:size=224:struct=60", "--model=alexnet", "--device=-1", "--classify=False", "--batch=4", "--dba=2"],
+    ["test.siamese_descriptor_test", "--dataset=synthetic:CLICIDE_video_224sq:n=11:q=4:labels=3:size=224:struct=60", "--model=alexnet", "--device=-1", "--feature-dim=16", "--batch=4", "--dba=0"],
+])
+def test_evaluation_mains_under_a_two_rank_launch_print_the_single_process_lines(tmp_path, main_args):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m test.<approach>_test ...` (gloo, CPU): the ranks split queries and gallery, gather the
+    descriptor rows, split the metrics by query rows -- rank 0 prints what ONE process prints (same counts; mAP to the printed digits), the other
+    rank prints nothing."""
+    import subprocess
+    pkg = os.path.join(ROOT, "instance-search_amd")
+    env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(_free_port()), "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
+    assert pick(one.stdout) and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)

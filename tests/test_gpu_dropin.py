@@ -562,3 +562,29 @@ def test_streaming_ingest_matches_resident_path(monkeypatch):
         a, b = out[name, "resident"], out[name, "streamed"]
         assert torch.isfinite(a).all() and float((a.norm(dim=1) - 1).abs().max()) < 1e-5
         assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("main_args", [
+    ["test.classif_finetune_test", "--dataset=synthetic:CLICIDE_video_224sq:n=70:q=21:labels=5:size=224:struct=50", "--model=resnet50", "--device=0", "--classify=False", "--batch=16", "--dba=3"],
+    ["test.classif_regions_test", "--dataset=synthetic:CLICIDE_video_448:n=18:q=7:labels=3:size=288:struct=50", "--model=resnet50", "--device=0", "--dba=0"],
+])
+def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(main_args):
+    """SURVEY 8e through the reference's CLI surface: `torch.distributed.run --nproc-per-node 2 -m test.<approach>_test` (both ranks on the box's one
+    GPU over gloo: ISX_BENCH_ONE_DEVICE=1; RCCL replaces only the transport) splits queries and gallery over the ranks, gathers the descriptor rows
+    and splits the metrics by query rows -- and prints exactly what one process prints: the kernels give an image the same descriptor whatever
+    batch it rides in."""
+    import subprocess
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "instance-search_amd")
+    env = dict(os.environ, ISX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    one = subprocess.run([sys.executable, "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
+    assert len(pick(one.stdout)) >= 4 and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)
