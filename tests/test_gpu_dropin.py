@@ -1,5 +1,8 @@
 """The Python drop-in surface on the GPU: the HIP path is the one that runs, and it agrees with
 the CPU restatement at the kernel boundary (same feature map in -> same descriptors out)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
