@@ -74,9 +74,38 @@ def l2norm_shift_rows(x, shift=None, eps=EPS):
 _HEAD_WS = {}
 
 
-def head_linear_applicable(rows, weight):
+def head_linear_applicable(rows, weight, any_width=False):
+    """any_width: N need not be a multiple of 64 (head_linear_any pads the weight's rows)."""
     return (rows.is_cuda and rows.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous() and rows.dim() == 2
-            and weight.dim() == 2 and weight.size(1) % 32 == 0 and weight.size(0) % 64 == 0 and 192 * weight.size(1) * 4 < 2 ** 32 and rows.size(0) < 2 ** 24)
+            and weight.dim() == 2 and weight.size(1) % 32 == 0 and (any_width or weight.size(0) % 64 == 0) and 192 * weight.size(1) * 4 < 2 ** 32
+            and rows.size(0) < 2 ** 24)
+
+
+_PADDED = {}
+
+
+def head_linear_any(rows, weight, bias=None):
+    """head_linear for any number of output features: the weight's rows (and the bias) are padded with zeros to a multiple of 64 -- once per
+    version of the weight, the copy is kept -- and the padding columns dropped.  Every output element is its own chain over K, so the padding
+    changes no value.  For the classifier layers of TuneClassif (2048 -> 464 class scores, reference model/siamese.py:28-32): a row's scores do
+    not depend on the batch it is computed in, as with every other descriptor of the path."""
+    N = weight.size(0)
+    if N % 64 == 0:
+        return head_linear(rows, weight, bias)
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), None if bias is None else (bias.data_ptr(), bias._version))
+    hit = _PADDED.get(id(weight))
+    if hit is None or hit[0] != key:
+        Np = (N + 63) // 64 * 64
+        wp = weight.new_zeros((Np, weight.size(1)))
+        wp[:N].copy_(weight.detach())
+        bp = None
+        if bias is not None:
+            bp = bias.new_zeros((Np,))
+            bp[:N].copy_(bias.detach())
+        if len(_PADDED) >= 8:
+            _PADDED.clear()
+        hit = _PADDED[id(weight)] = (key, wp, bp)
+    return head_linear(rows, hit[1], hit[2])[:, :N].contiguous()
 
 
 def head_linear(rows, weight, bias=None):

@@ -99,6 +99,7 @@ class TuneClassif(nn.Module):
             first = self.classifier._modules[names[0]]
             self.classifier._modules[names[0]] = nn.Linear(first.in_features * factor, first.out_features)
             self.feature_reduc = nn.Sequential()
+        _rows_linears(self.classifier)
 
     def forward(self, x):
         x = self.features(x)
@@ -354,9 +355,26 @@ def _linear_rows(rows, weight, bias):
     from isx import ops
     if not rows.is_contiguous():
         rows = rows.contiguous()
-    if ops.head_linear_applicable(rows, weight):
-        return ops.head_linear(rows, weight.detach(), bias.detach() if bias is not None else None)
+    if ops.head_linear_applicable(rows, weight, any_width=True):
+        return ops.head_linear_any(rows, weight.detach(), bias.detach() if bias is not None else None)
     return F.linear(rows, weight, bias)
+
+
+class RowsLinear(nn.Linear):
+    """nn.Linear (same parameters and state-dict keys) whose GPU inference runs on libisx's row-invariant GEMM (_linear_rows): the classifier
+    layers of TuneClassif -- class scores used as descriptors (P.embeddings_classify, reference train/classif_finetune.py:87-90) and the
+    classification test do not depend on the batch size, nor on how a data-parallel run splits the set."""
+
+    def forward(self, x):
+        if x.dim() == 2 and _fast(x, self):
+            return _linear_rows(x, self.weight, self.bias)
+        return F.linear(x, self.weight, self.bias)
+
+
+def _rows_linears(classifier):
+    for m in classifier.modules():
+        if type(m) is nn.Linear:
+            m.__class__ = RowsLinear
 
 
 class DescriptorNet(nn.Module):

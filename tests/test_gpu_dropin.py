@@ -591,3 +591,34 @@ def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(ma
     assert two.returncode == 0, two.stderr[-2000:]
     pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
     assert len(pick(one.stdout)) >= 4 and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)
+
+
+def test_classifier_scores_do_not_depend_on_the_batch():
+    """TuneClassif's classifier on the GPU (class scores as descriptors, P.embeddings_classify; the classification test): libisx's row-invariant GEMM
+    with the weight's rows padded to a multiple of 64 -- batches of 1 / 7 / 33 give every image the same scores bit for bit, equal to float64 within
+    1e-5 of the largest score, for a ResNet head (2048 -> 464) and an AlexNet head (9216 -> 4096 -> 4096 -> 17)."""
+    from isx import backbones, ops
+    from model.siamese import RowsLinear, TuneClassif
+    torch.manual_seed(0)
+    for net, n_cls, size in ((backbones.resnet50(pretrained=True, seed=0), 464, 224), (backbones.alexnet(pretrained=True), 17, 224)):
+        m = TuneClassif(net, n_cls).cuda().eval()
+        lins = [l for l in m.classifier.modules() if isinstance(l, nn.Linear)]
+        assert lins and all(type(l) is RowsLinear for l in lins)
+        x = torch.randn(33, 3, size, size, device="cuda")
+        with torch.no_grad():
+            f = m.feature_reduc(m.features(x)).reshape(33, -1)
+            whole = m.classifier(f)
+            for bs in (1, 7):
+                parts = torch.cat([m.classifier(f[i:i + bs]) for i in range(0, 33, bs)], 0)
+                assert torch.equal(parts, whole), bs
+            ref = f.double()
+            for mod in m.classifier:
+                ref = torch.nn.functional.linear(ref, mod.weight.double(), mod.bias.double()) if isinstance(mod, nn.Linear) else (torch.relu(ref) if isinstance(mod, nn.ReLU) else ref)
+        assert whole.shape == (33, n_cls)
+        assert float((whole.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # the padded copy follows the weight
+    w = torch.randn(17, 64, device="cuda")
+    r = torch.randn(5, 64, device="cuda")
+    y0 = ops.head_linear_any(r, w)
+    w.mul_(2.0)
+    assert torch.equal(ops.head_linear_any(r, w), 2.0 * y0)
