@@ -567,19 +567,27 @@ def test_streaming_ingest_matches_resident_path(monkeypatch):
         assert torch.equal(a, b), name
 
 
-@pytest.mark.parametrize("main_args", [
-    ["test.classif_finetune_test", "--dataset=synthetic:CLICIDE_video_224sq:n=70:q=21:labels=5:size=224:struct=50", "--model=resnet50", "--device=0", "--classify=False", "--batch=16", "--dba=3"],
-    ["test.classif_regions_test", "--dataset=synthetic:CLICIDE_video_448:n=18:q=7:labels=3:size=288:struct=50", "--model=resnet50", "--device=0", "--dba=0"],
+@pytest.mark.parametrize("which,main_args", [
+    ("finetune", ["test.classif_finetune_test", "--dataset=synthetic:CLICIDE_video_224sq:n=70:q=21:labels=5:size=224:struct=50", "--model=resnet50", "--device=0", "--classify=True",
+                  "--batch=16", "--dba=3"]),
+    ("regions", ["test.classif_regions_test", "--dataset=synthetic:CLICIDE_video_448:n=18:q=7:labels=3:size=288:struct=50", "--model=resnet50", "--device=0", "--dba=0"]),
 ])
-def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(main_args):
+def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(tmp_path, which, main_args):
     """SURVEY 8e through the reference's CLI surface: `torch.distributed.run --nproc-per-node 2 -m test.<approach>_test` (both ranks on the box's one
     GPU over gloo: ISX_BENCH_ONE_DEVICE=1; RCCL replaces only the transport) splits queries and gallery over the ranks, gathers the descriptor rows
-    and splits the metrics by query rows -- and prints exactly what one process prints: the kernels give an image the same descriptor whatever
-    batch it rides in."""
+    and splits the metrics by query rows -- and prints exactly what one process prints from the same weights file: the kernels give an image the same
+    descriptor (class scores included) whatever batch it rides in."""
     import subprocess
     import socket
+    from isx import backbones
+    from model.siamese import TuneClassif, TuneClassifSub
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(root, "instance-search_amd")
+    torch.manual_seed(3)
+    net = TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5) if which == "finetune" else TuneClassifSub(backbones.resnet50(pretrained=True, seed=0), 3, (7, 7))
+    weights = str(tmp_path / "w.pth.tar")
+    torch.save(net.state_dict(), weights)
+    main_args = main_args + ["--weights=" + weights]
     env = dict(os.environ, ISX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
