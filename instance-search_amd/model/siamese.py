@@ -36,9 +36,10 @@ class BoxPool(nn.AvgPool2d):
     by libisx `isx_boxpool_s1` on the GPU."""
 
     def forward(self, x):
-        if _fast(x) and self.stride in (1, (1, 1)) and self.padding in (0, (0, 0)):
+        kh, kw = self.kernel_size if isinstance(self.kernel_size, tuple) else (self.kernel_size,) * 2
+        # stride 1, or a window that spans the whole map (one output: the stride is never used -- TuneClassif's AvgPool2d(7) on a 7 x 7 map)
+        if _fast(x) and x.dim() == 4 and (self.stride in (1, (1, 1)) or tuple(x.shape[2:]) == (kh, kw)) and self.padding in (0, (0, 0)) and not self.ceil_mode:
             from isx import ops
-            kh, kw = self.kernel_size if isinstance(self.kernel_size, tuple) else (self.kernel_size,) * 2
             if ops.boxpool_s1_applicable_nhwc(x):
                 return ops.boxpool_s1_nhwc(x, kh, kw)        # channels-last trunk output: pooled in place, stays channels-last
             return ops.boxpool_s1(x.float(), kh, kw)
@@ -100,6 +101,7 @@ class TuneClassif(nn.Module):
             self.classifier._modules[names[0]] = nn.Linear(first.in_features * factor, first.out_features)
             self.feature_reduc = nn.Sequential()
         _rows_linears(self.classifier)
+        _box_pools(self.feature_reduc)
 
     def forward(self, x):
         x = self.features(x)
@@ -375,6 +377,14 @@ def _rows_linears(classifier):
     for m in classifier.modules():
         if type(m) is nn.Linear:
             m.__class__ = RowsLinear
+
+
+def _box_pools(reduc):
+    """TuneClassif's spatial reduction (ResNet: AvgPool2d(7)) on libisx's box-pooling kernel: with the classifier on the row-invariant GEMM the
+    whole class-score path of an image is independent of its batch (MIOpen's pooling picks its kernel by batch size)."""
+    for m in reduc.modules():
+        if type(m) is nn.AvgPool2d:
+            m.__class__ = BoxPool
 
 
 class DescriptorNet(nn.Module):
