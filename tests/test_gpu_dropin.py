@@ -588,7 +588,9 @@ def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(tm
     weights = str(tmp_path / "w.pth.tar")
     torch.save(net.state_dict(), weights)
     main_args = main_args + ["--weights=" + weights]
-    env = dict(os.environ, ISX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # OMP_NUM_THREADS=1 for both runs: torch.distributed.run sets it for its workers, and the SYNTHETIC images (host arithmetic of
+    # utils.dataset.synthetic_image_set) differ in the last bit between thread counts -- the inputs, not the path, would differ
+    env = dict(os.environ, ISX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
