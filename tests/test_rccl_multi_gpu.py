@@ -94,3 +94,27 @@ def test_shard_head_worker_one_rank(tmp_path):
     r = torch.load(out + ".0")
     y_ref, dx_ref, w_ref = r["shard_ref"]
     assert torch.equal(r["shard_y"], y_ref) and torch.equal(r["shard_dx"], dx_ref) and torch.equal(r["shard_w"], w_ref)
+
+
+@needs2
+def test_evaluation_main_over_rccl_prints_the_single_process_lines(tmp_path):
+    """`torch.distributed.run --nproc-per-node N -m test.classif_finetune_test` with one rank per GPU over RCCL (class scores as descriptors): the
+    lines of one process, from the same weights file."""
+    sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
+    from isx import backbones
+    from model.siamese import TuneClassif
+    world = min(_n_gpus(), 4)
+    torch.manual_seed(3)
+    weights = str(tmp_path / "w.pth.tar")
+    torch.save(TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5).state_dict(), weights)
+    args = ["test.classif_finetune_test", "--dataset=synthetic:CLICIDE_video_224sq:n=70:q=21:labels=5:size=224:struct=50", "--model=resnet50", "--device=0",
+            "--classify=True", "--batch=16", "--dba=3", "--weights=" + weights]
+    env = dict(_env(), OMP_NUM_THREADS="1")
+    pkg = os.path.join(ROOT, "instance-search_amd")
+    one = subprocess.run([sys.executable, "-m"] + args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
+                           str(_free_port()), "-m"] + args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
+    assert many.returncode == 0, many.stderr[-2000:]
+    pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
+    assert len(pick(one.stdout)) >= 4 and pick(many.stdout) == pick(one.stdout), (one.stdout, many.stdout)
