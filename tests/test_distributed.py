@@ -95,6 +95,16 @@ def test_evaluation_mains_under_a_two_rank_launch_print_the_single_process_lines
     rank prints nothing."""
     import subprocess
     pkg = os.path.join(ROOT, "instance-search_amd")
+    # both runs evaluate ONE network from a weights file: layers without a file are random-initialised, and torch seeds every process differently
+    sys.path.insert(0, pkg)
+    from isx import backbones
+    from model.siamese import DescriptorNet, TuneClassif
+    torch.manual_seed(5)
+    cls = TuneClassif(backbones.alexnet(pretrained=True), 3)
+    net = cls if "classif_finetune" in main_args[0] else DescriptorNet(cls, 16, (6, 6))
+    weights = str(tmp_path / "w.pth.tar")
+    torch.save(net.state_dict(), weights)
+    main_args = main_args + ["--weights=" + weights]
     env = dict(os.environ, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
