@@ -162,6 +162,13 @@ class _ConvBiasAct(nn.Module):
             if residual is not None and residual.stride() != y.stride():
                 residual = residual.contiguous(memory_format=torch.channels_last if not y.is_contiguous() else torch.contiguous_format)
             return ops.bias_act_(y, self.bias, residual, self.relu)
+        if not torch.is_grad_enabled():
+            # CPU inference (the parity side of the GPU tests, CPU-only users): the epilogue in place on the convolution's own output -- the same
+            # fp32 adds in the same order, without three more passes' worth of fresh 100 MB tensors per layer
+            y.add_(self.bias.view(1, -1, 1, 1).to(y.dtype))
+            if residual is not None:
+                y.add_(residual)
+            return y.relu_() if self.relu else y
         y = y + self.bias.view(1, -1, 1, 1).to(y.dtype)
         if residual is not None:
             y = y + residual
