@@ -365,6 +365,8 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if torch.get_num_threads() > usable_cpus():                  # a box that shows 256 CPUs and owns 16: an OpenMP team of 128 is throttled into the ground
+        torch.set_num_threads(usable_cpus())
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

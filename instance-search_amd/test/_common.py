@@ -307,6 +307,8 @@ def run_cli(argv, usage, spec, required, main, P):
         sys.exit(2)
     if 'dba' not in spec:
         values.pop('dba', None)
+    from utils.general import cap_torch_threads
+    cap_torch_threads()
     device = values['device']
     # data parallel: under `python -m torch.distributed.run --nproc-per-node N` every rank takes GPU LOCAL_RANK (RCCL; gloo for CPU runs, and with
     # ISX_BENCH_ONE_DEVICE=1 -- a rehearsal on a one-GPU box: every rank on cuda:0); rank 0 prints

@@ -41,7 +41,8 @@ _DECODE_POOL = None
 
 
 def decode_workers():
-    return int(os.environ.get("ISX_DECODE_THREADS", "0")) or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+    from utils.general import usable_cpus
+    return int(os.environ.get("ISX_DECODE_THREADS", "0")) or min(16, usable_cpus())
 
 
 def _decode_pool():
@@ -469,6 +470,8 @@ def training_cli(argv, P, run, what):
     if not getattr(P, 'dataset_full', None):
         print('no dataset: give --dataset=<folder> (or synthetic:<dataset id>[:n=..][:q=..][:labels=..]) or set P.dataset_full')
         sys.exit(2)
+    from utils.general import cap_torch_threads
+    cap_torch_threads()
     # data parallel: `python -m torch.distributed.run --nproc-per-node N -m train.<approach> ...` -- one rank per GPU (RCCL; gloo for CPU runs);
     # utils.train_gen finds the process group and splits every mini-batch's micro-batches over the ranks (isx/dp.py)
     world = int(os.environ.get('WORLD_SIZE', '1'))

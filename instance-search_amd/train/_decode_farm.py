@@ -270,7 +270,8 @@ def farm_workers():
     v = os.environ.get("ISX_DECODE_PROCS")
     if v is not None and v != "":
         return max(0, int(v))
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+    from utils.general import usable_cpus
+    cores = min(16, usable_cpus())
     return max(1, cores - cores // 8)
 
 

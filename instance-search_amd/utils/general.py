@@ -84,6 +84,29 @@ def tensor(device, *sizes):
     return torch.empty(*sizes, dtype=torch.float32, device='cuda' if device >= 0 else 'cpu')
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a container can see 256 CPUs and own 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    for path in ('/sys/fs/cgroup/cpu.max',):
+        try:
+            quota, period = open(path).read().split()
+            if quota != 'max':
+                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cap_torch_threads():
+    """torch sizes its OpenMP team from the CPUs it SEES; under a cgroup quota (16 of 256 on the MI355X boxes) a team of 128 is throttled into
+    the ground -- elementwise host ops at 6 GB/s, every host-side pass of an evaluation run several times slower.  The entry points of this
+    package cap the team at what the process owns; a smaller explicit setting (OMP_NUM_THREADS, torch.set_num_threads) is left alone."""
+    n = usable_cpus()
+    if torch.get_num_threads() > n:
+        torch.set_num_threads(n)
+    return torch.get_num_threads()
+
+
 def is_main_process():
     """True on rank 0 of a torch.distributed job and in a plain single-process run: the one process that prints result
     lines, appends to the log file and writes checkpoints."""

@@ -14,6 +14,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU sides of the GPU tests (torch-CPU references, float64 arbiters) on a box that shows 256 CPUs and owns 16: see cap_torch_threads
+    try:
+        from utils.general import cap_torch_threads
+        cap_torch_threads()
+    except Exception:
+        pass
 
 
 def _has_gpu():

@@ -151,6 +151,8 @@ def make_parser():
 
 def main():
     args = make_parser().parse_args()
+    from utils.general import cap_torch_threads
+    cap_torch_threads()
     import torch.distributed as dist
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     # debugging aid for boxes with ONE GPU (as in bench.py): ISX_BENCH_ONE_DEVICE=1 maps every rank to cuda:0 over gloo, so that the
