@@ -108,6 +108,7 @@ class DecodeFarm(object):
         self.by_id = {}
         self.pending = {}                                 # request id -> _Chunk
         self.load = [0] * self.n                          # files outstanding per worker
+        self.dead = [False] * self.n                      # the worker's answer pipe closed: nothing more is handed to it
         self.next_id = 0
         self.closed = False
         self.pid = os.getpid()
@@ -150,6 +151,7 @@ class DecodeFarm(object):
                     ch.done.set()
         finally:                                           # the pipe closed: close() or the worker died -- nobody waits for ever
             with self.lock:
+                self.dead[i] = True
                 dead = [(r, c) for r, c in self.pending.items() if c.worker == i]
                 for r, _ in dead:
                     del self.pending[r]
@@ -189,7 +191,14 @@ class DecodeFarm(object):
         for seg in fresh:
             msg = b"A\t%d\t" % seg.sid + seg.path.encode("utf-8", "surrogateescape") + b"\n"
             for i in range(self.n):
-                self._send(i, msg)
+                try:
+                    self._send(i, msg)
+                except DecodeError:                        # a worker that has ended maps nothing: its share of the un-link count is given up
+                    with self.lock:
+                        self.dead[i] = True
+                        seg.unmapped_by -= 1
+                        if seg.unmapped_by == 0:
+                            seg.unlink()
         return out
 
     def _give_back(self, seg, slot):
@@ -220,7 +229,10 @@ class DecodeFarm(object):
                 by_seg.setdefault(places[j][0].sid, []).append(j)
             for sid, js in by_seg.items():
                 with self.lock:
-                    i = min(range(self.n), key=lambda w: self.load[w])
+                    alive = [w for w in range(self.n) if not self.dead[w]]
+                    if not alive:
+                        raise DecodeError("every decoder process has ended (exit codes %s)" % [p.poll() for p in self.procs])
+                    i = min(alive, key=lambda w: self.load[w])
                     rid = self.next_id
                     self.next_id += 1
                     ch = _Chunk(i, len(js))

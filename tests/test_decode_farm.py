@@ -89,9 +89,23 @@ def test_a_file_larger_than_the_slot_is_still_read(tmp_path, farm_env):
 
 
 def test_a_dead_decoder_fails_loudly(tmp_path, farm_env):
-    files = _write(tmp_path, 3)
+    """One decoder killed: what it held fails at the image, the others keep serving; all killed: a DecodeError, not a hang."""
+    import time
+    files = _write(tmp_path, 6)
     farm = farm_env.decode_farm()
-    for p in farm.procs:
+    assert all(t.tensor().shape == (40, 56, 3) for t in farm.submit(files, 40 * 56 * 3))
+    os.kill(farm.procs[0].pid, signal.SIGKILL)
+    farm.procs[0].wait()
+    for _ in range(100):
+        if farm.dead[0]:
+            break
+        time.sleep(0.05)
+    assert farm.dead[0]
+    tickets = farm.submit(files * 4, 40 * 56 * 3)                 # the two survivors take everything
+    assert all(t.chunk.worker != 0 and t.tensor().shape == (40, 56, 3) for t in tickets)
+    for t in tickets:
+        t.release()
+    for p in farm.procs[1:]:
         os.kill(p.pid, signal.SIGKILL)
         p.wait()
     with pytest.raises(farm_env.DecodeError):
