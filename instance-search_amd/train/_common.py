@@ -498,15 +498,15 @@ _LABEL_IDS = {}
 def label_index(labels):
     """label -> position in the run's label list (what the reference computes as `labels.index(lab)` per image -- train/classif_finetune.py:46,
     train/siamese_descriptor.py:129: O(#labels) each, seconds per pass at 10 k labels); first occurrence wins, as with list.index.  Cached per
-    list object and length (the mains fill their `labels` list once, then keep it constant)."""
+    list object and checked against a copy of its content (the mains refill the same list object on every run)."""
     key = id(labels)
     hit = _LABEL_IDS.get(key)
-    if hit is None or hit[0] != len(labels) or hit[1] is not labels:
+    if hit is None or hit[1] != labels:          # a list compare (identical objects: pointer compares) -- the mains refill the SAME list per run
         ids = {}
         for i, lab in enumerate(labels):
             ids.setdefault(lab, i)
         _LABEL_IDS.clear()                       # one list at a time is alive in a run
-        hit = _LABEL_IDS[key] = (len(labels), labels, ids)
+        hit = _LABEL_IDS[key] = (len(labels), list(labels), ids)
     return hit[2]
 
 
