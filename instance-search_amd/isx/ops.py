@@ -81,31 +81,30 @@ def head_linear_applicable(rows, weight, any_width=False):
             and rows.size(0) < 2 ** 24)
 
 
-_PADDED = {}
+def pad_rows_to_64(weight, bias=None):
+    """(weight, bias) with the weight's rows and the bias padded with zeros to a multiple of 64 outputs (head_linear's tile height)."""
+    N = weight.size(0)
+    Np = (N + 63) // 64 * 64
+    wp = weight.new_zeros((Np, weight.size(1)))
+    wp[:N].copy_(weight.detach())
+    bp = None
+    if bias is not None:
+        bp = bias.new_zeros((Np,))
+        bp[:N].copy_(bias.detach())
+    return wp, bp
 
 
-def head_linear_any(rows, weight, bias=None):
-    """head_linear for any number of output features: the weight's rows (and the bias) are padded with zeros to a multiple of 64 -- once per
-    version of the weight, the copy is kept -- and the padding columns dropped.  Every output element is its own chain over K, so the padding
-    changes no value.  For the classifier layers of TuneClassif (2048 -> 464 class scores, reference model/siamese.py:28-32): a row's scores do
-    not depend on the batch it is computed in, as with every other descriptor of the path."""
+def head_linear_any(rows, weight, bias=None, padded=None):
+    """head_linear for any number of output features: rows of zeros pad the weight (and the bias) to a multiple of 64, the padding columns are
+    dropped.  Every output element is its own chain over K, so the padding changes no value.  `padded`: the (weight, bias) pair of pad_rows_to_64,
+    kept by the caller next to its weight (model/siamese.RowsLinear caches it per version of the parameter); None: padded here, per call.
+    For the classifier layers of TuneClassif (2048 -> 464 class scores, reference model/siamese.py:28-32): a row's scores do not depend on the
+    batch it is computed in, as with every other descriptor of the path."""
     N = weight.size(0)
     if N % 64 == 0:
         return head_linear(rows, weight, bias)
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), None if bias is None else (bias.data_ptr(), bias._version))
-    hit = _PADDED.get(id(weight))
-    if hit is None or hit[0] != key:
-        Np = (N + 63) // 64 * 64
-        wp = weight.new_zeros((Np, weight.size(1)))
-        wp[:N].copy_(weight.detach())
-        bp = None
-        if bias is not None:
-            bp = bias.new_zeros((Np,))
-            bp[:N].copy_(bias.detach())
-        if len(_PADDED) >= 8:
-            _PADDED.clear()
-        hit = _PADDED[id(weight)] = (key, wp, bp)
-    return head_linear(rows, hit[1], hit[2])[:, :N].contiguous()
+    wp, bp = padded if padded is not None else pad_rows_to_64(weight, bias)
+    return head_linear(rows, wp, bp)[:, :N].contiguous()
 
 
 def head_linear(rows, weight, bias=None):

@@ -103,7 +103,7 @@ def _derived(owner, slot, sources, build):
 def invalidate_derived_weights(module):
     """Drop every cached re-layout of a weight (OHWI copies, concatenated / transposed projection weights) under `module`."""
     for m in module.modules():
-        for slot in ('_c_w_ohwi', '_c_w_cat', '_c_w3t', '_hwc'):
+        for slot in ('_c_w_ohwi', '_c_w_cat', '_c_w3t', '_hwc', '_c_pad64'):
             if slot in m.__dict__:
                 m.__dict__[slot] = None
 

@@ -350,7 +350,7 @@ def _apply_head(head, rows):
     return head(rows)
 
 
-def _linear_rows(rows, weight, bias):
+def _linear_rows(rows, weight, bias, owner=None):
     """The descriptor head's Linear on GPU rows outside autograd: libisx's split-K GEMM (isx_head_linear_fwd_rows) -- the kernel the training step
     runs, so the per-epoch mining pass, the evaluation and the training forward of the same weights produce the same bits, and a descriptor does
     not depend on the batch it was computed in.  Shapes the kernel does not cover (K % 32, N % 64) keep torch's GEMM."""
@@ -358,7 +358,11 @@ def _linear_rows(rows, weight, bias):
     if not rows.is_contiguous():
         rows = rows.contiguous()
     if ops.head_linear_applicable(rows, weight, any_width=True):
-        return ops.head_linear_any(rows, weight.detach(), bias.detach() if bias is not None else None)
+        padded = None
+        if weight.size(0) % 64 and owner is not None:           # the padded copy lives with the module and follows its parameters (nn_utils._derived)
+            from .nn_utils import _derived
+            padded = _derived(owner, '_c_pad64', (weight,) + ((bias,) if bias is not None else ()), lambda: ops.pad_rows_to_64(weight, bias))
+        return ops.head_linear_any(rows, weight.detach(), bias.detach() if bias is not None else None, padded)
     return F.linear(rows, weight, bias)
 
 
@@ -369,7 +373,7 @@ class RowsLinear(nn.Linear):
 
     def forward(self, x):
         if x.dim() == 2 and _fast(x, self):
-            return _linear_rows(x, self.weight, self.bias)
+            return _linear_rows(x, self.weight, self.bias, owner=self)
         return F.linear(x, self.weight, self.bias)
 
 

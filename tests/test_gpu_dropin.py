@@ -626,9 +626,11 @@ def test_classifier_scores_do_not_depend_on_the_batch():
                 ref = torch.nn.functional.linear(ref, mod.weight.double(), mod.bias.double()) if isinstance(mod, nn.Linear) else (torch.relu(ref) if isinstance(mod, nn.ReLU) else ref)
         assert whole.shape == (33, n_cls)
         assert float((whole.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
-    # the padded copy follows the weight
-    w = torch.randn(17, 64, device="cuda")
+    # the padded copy is kept with the module and follows its parameters
+    lin = RowsLinear(64, 17).cuda()
     r = torch.randn(5, 64, device="cuda")
-    y0 = ops.head_linear_any(r, w)
-    w.mul_(2.0)
-    assert torch.equal(ops.head_linear_any(r, w), 2.0 * y0)
+    with torch.no_grad():
+        y0 = lin(r)
+        assert "_c_pad64" in lin.__dict__ and torch.equal(y0, ops.head_linear_any(r, lin.weight.detach(), lin.bias.detach()))
+        lin.weight.mul_(2.0); lin.bias.mul_(2.0)
+        assert torch.equal(lin(r), 2.0 * y0)
