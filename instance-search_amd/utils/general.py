@@ -87,11 +87,16 @@ def tensor(device, *sizes):
 def usable_cpus():
     """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (a container can see 256 CPUs and own 16)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    for path in ('/sys/fs/cgroup/cpu.max',):
-        try:
-            quota, period = open(path).read().split()
-            if quota != 'max':
-                n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    try:                                                     # cgroup v2
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:                                                 # cgroup v1
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, int(float(quota) / period + 0.5)))
         except Exception:
             pass
     return max(1, n)

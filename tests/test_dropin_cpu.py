@@ -633,3 +633,64 @@ def test_descriptor_head_skips_its_random_init_when_weights_follow(tmp_path):
         assert all(torch.equal(v, c.state_dict()[k]) for k, v in a.state_dict().items())            # ... and holds the file's weights
     finally:
         sd.P.__dict__.clear(); sd.P.__dict__.update(saved)
+
+
+def test_thread_cap_follows_the_cpus_the_process_owns(monkeypatch):
+    """utils.general.cap_torch_threads: torch's team is cut to affinity ∩ cgroup quota (boxes that show 256 CPUs and own 16) and never raised."""
+    import builtins
+    from utils import general as G
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == '/sys/fs/cgroup/cpu.max':
+            import io
+            return io.StringIO("200000 100000\n")          # a quota of two CPUs
+        return real_open(path, *a, **k)
+
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.setattr(builtins, "open", fake_open)
+        assert G.usable_cpus() == min(2, len(os.sched_getaffinity(0)))
+        torch.set_num_threads(max(before, 4))
+        assert G.cap_torch_threads() == G.usable_cpus() == torch.get_num_threads()
+        torch.set_num_threads(1)
+        assert G.cap_torch_threads() == 1                    # a smaller explicit setting is left alone
+    finally:
+        monkeypatch.undo()
+        torch.set_num_threads(before)
+
+
+def test_training_entry_point_reads_a_folder_of_image_files(tmp_path, monkeypatch):
+    """train.siamese_descriptor.run on a dataset FOLDER (reference train/siamese_descriptor.py:166-191): the images of the folder are the training
+    set and the gallery, those of `test/` with a known label the queries; labels come from the file names, mean / std from the dataset's file."""
+    import copy
+    from PIL import Image
+    from train import siamese_descriptor as sd
+    root = tmp_path / "CLICIDE_video_224sq"
+    (root / "test").mkdir(parents=True)
+    (tmp_path / "data").mkdir()
+    (tmp_path / "data" / "CLICIDE_224sq_train_ms.txt").write_text("0.4 0.5 0.6\n0.2 0.3 0.25\n")
+    rng = np.random.default_rng(0)
+    for lab in ("a", "b", "c"):
+        for i in range(3):
+            Image.fromarray(rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)).save(root / ("%s-%d.png" % (lab, i)))
+    for lab in ("a", "c", "zz"):                               # "zz" is not a gallery label: dropped
+        Image.fromarray(rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)).save(root / "test" / ("%s-9.png" % lab))
+    monkeypatch.chdir(tmp_path)
+    saved = copy.copy(sd.P.__dict__)
+    seen = []
+    monkeypatch.setattr(sd, "train_siam_triplets_pos_couples", lambda net, train_set, testset_tuple, *a, **k: seen.append((train_set, testset_tuple)) or 1)
+    monkeypatch.setattr(sd, "test_print_descriptor", lambda *a, **k: 0)
+    monkeypatch.setattr(sd, "get_siamese_net", lambda: torch.nn.Linear(2, 2))
+    try:
+        sd.P.cuda_device, sd.P.cnn_model = -1, "alexnet"
+        sd.run(str(root))
+        train_set, (test_set, test_train_set) = seen[0]
+        assert len(train_set) == 9 and train_set is test_train_set and len(test_set) == 2 and sd.labels == ["a", "b", "c"]
+        im, lab, path = train_set[0]
+        assert im.shape == (3, 32, 32) and im.dtype == torch.float32 and path.endswith(".png")
+        raw = torch.from_numpy(np.asarray(Image.open(path).convert("RGB")).copy()).permute(2, 0, 1).float() / 255.0
+        want = (raw - torch.tensor([0.4, 0.5, 0.6]).view(3, 1, 1)) / torch.tensor([0.2, 0.3, 0.25]).view(3, 1, 1)
+        assert torch.allclose(im, want, atol=1e-6)
+    finally:
+        sd.P.__dict__.clear(); sd.P.__dict__.update(saved)
