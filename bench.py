@@ -871,7 +871,6 @@ def main():
     training_result = None
     if not args.no_train_bench and world == 1 and args.backbone_dtype == "f32":
         try:
-            import argparse as _ap
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_train
             import io

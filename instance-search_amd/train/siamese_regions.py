@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from model.siamese import RegionDescriptorNet, TuneClassifSub
 from model.custom_modules import TripletLoss
-from utils import (choose_rand_neg, choose_rand_neg_index, fold_batches, get_pos_couples, get_similarities, log, move_device, tensor,
+from utils import (choose_rand_neg, choose_rand_neg_index, get_pos_couples, get_similarities, log, move_device, tensor,
                    test_print_descriptor, train_gen)
 from ._common import base_model, device_batch_size, fold_shape_buckets, label_index, load_weights, make_resident, scatter_rows, test_transform
 from .siamese_descriptor import mine_epoch_negatives, shuffle_couples

@@ -61,6 +61,8 @@ try:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         print("run %d: %.2f s for %d gallery + %d query files (%.0f images/s end to end)  result %s" % (rep, dt, NG, NQ, (NG + NQ) / dt, res), flush=True)
+        if rep == 0 and os.environ.get("LAB_COLD"):          # LAB_COLD=1: profile of the FIRST run (code objects, decoder start, allocations)
+            break
     s = io.StringIO()
     pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(28)
     print(s.getvalue()[:6000])
