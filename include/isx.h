@@ -283,6 +283,25 @@ int isx_dba_groups(const float* emb, int64_t N, int D, const int32_t* order, con
 /* ---- multi-GPU (no reference counterpart: one torch.mm on one device,
  *      test/classif_finetune_test.py:82; BASELINE config 5 shards the gallery rows) --- */
 
+/* Average precision against a gallery SHARDED by rows (one shard per GPU): the reference walks the full ranked list of ONE score row
+ * (utils/metrics.py:25-45); the AP only depends on the ranks of the positives, and a rank is a count of gallery keys -- which adds over
+ * shards.  Three steps around two collectives; with one shard they are isx_average_precision_sim cut at its synchronisation points, and for any
+ * number of shards the float64 result is the same bits as the unsharded kernels' and the reference loop's.
+ *   isx_ap_shard_positives  sim: (M, N) this shard's score rows, idx_base: global index of its first gallery row, glab: (N) its labels ->
+ *                           keys: (M, cap) canonical keys (score, global index) of the shard's positives per query, 0 = empty slot, any order;
+ *                           count: (M) how many there were (more than cap: the query is over the cap).              [all-gather keys, sum counts]
+ *   isx_ap_shard_hist       keys_all: (M, W) the gathered keys of all shards (0 = empty) -> hist: (M, isx_ap_shard_max_positives()) int32: for
+ *                           every key x of this shard's rows at or above the smallest positive, bucket #{positives > x} += 1.   [all-reduce sum]
+ *   isx_ap_from_hist        hist summed over the shards (rows `ld` ints apart: the buckets past the largest n_lab need not travel), n_lab: (M)
+ *                           positives per query over all shards -> ap: (M) float64; NaN where the
+ *                           reference returns None (no positive left after kth - 1), -1.0 over isx_ap_shard_max_positives() positives.
+ * Global indices below 2^32. */
+int isx_ap_shard_max_positives(void);
+int isx_ap_shard_positives(const float* sim, int64_t M, int64_t N, int64_t idx_base, const int32_t* qlab, const int32_t* glab, int cap,
+                           uint64_t* keys, int32_t* count, isx_stream_t stream);
+int isx_ap_shard_hist(const float* sim, int64_t M, int64_t N, int64_t idx_base, const uint64_t* keys_all, int W, int32_t* hist, isx_stream_t stream);
+int isx_ap_from_hist(const int32_t* hist, int ld, const int32_t* n_lab, int64_t M, int kth, double* ap, isx_stream_t stream);
+
 /* Merge P per-shard canonical top-k lists (after the RCCL all-gather) into the global
  * top-k.  scores, idx: (P,M,k) with GLOBAL indices, (-inf,-1) padding allowed;
  * out: (M,k).  P*k <= 4096. */

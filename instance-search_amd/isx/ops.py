@@ -628,6 +628,44 @@ def average_precision_sim(sim, qlab, glab, kth=1):
     return ap
 
 
+def ap_shard_max_positives():
+    return int(lib().isx_ap_shard_max_positives())
+
+
+def ap_shard_positives(sim, idx_base, qlab, glab, cap=None):
+    """Step 1 of the sharded average precision (include/isx.h): (keys (M, cap) int64 bit patterns of the canonical uint64 keys, 0 = empty;
+    count (M,) int32) of this shard's positives per query.  sim: (M, Ns) scores against the shard's rows, idx_base: the shard's first global row."""
+    sim = _f32(sim, "sim")
+    M, N = sim.shape
+    cap = ap_shard_max_positives() if cap is None else int(cap)
+    qlab, glab = _typed(qlab, torch.int32, "qlab"), _typed(glab, torch.int32, "glab")
+    keys = torch.empty((M, cap), dtype=torch.int64, device=sim.device)
+    count = torch.empty((M,), dtype=torch.int32, device=sim.device)
+    check(lib().isx_ap_shard_positives(sim.data_ptr(), M, N, int(idx_base), qlab.data_ptr(), glab.data_ptr(), cap, keys.data_ptr(), count.data_ptr(), _stream()),
+          "isx_ap_shard_positives")
+    return keys, count
+
+
+def ap_shard_hist(sim, idx_base, keys_all):
+    """Step 2: this shard's bucket counts (M, ap_shard_max_positives()) int32 against the gathered keys of all shards (M, W)."""
+    sim = _f32(sim, "sim")
+    M, N = sim.shape
+    keys_all = _typed(keys_all, torch.int64, "keys_all")
+    assert keys_all.dim() == 2 and keys_all.size(0) == M
+    hist = torch.empty((M, ap_shard_max_positives()), dtype=torch.int32, device=sim.device)
+    check(lib().isx_ap_shard_hist(sim.data_ptr(), M, N, int(idx_base), keys_all.data_ptr(), int(keys_all.size(1)), hist.data_ptr(), _stream()), "isx_ap_shard_hist")
+    return hist
+
+
+def ap_from_hist(hist, n_lab, kth=1):
+    """Step 3: float64 AP per query from the histogram summed over the shards (M, ld) and the positives per query over all shards (M,)."""
+    hist, n_lab = _typed(hist, torch.int32, "hist"), _typed(n_lab, torch.int32, "n_lab")
+    M = hist.size(0)
+    ap = torch.empty((M,), dtype=torch.float64, device=hist.device)
+    check(lib().isx_ap_from_hist(hist.data_ptr(), int(hist.size(1)), n_lab.data_ptr(), M, int(kth), ap.data_ptr(), _stream()), "isx_ap_from_hist")
+    return ap
+
+
 def masked_sums(sim, qlab, glab):
     sim = _f32(sim, "sim")
     M, N = sim.shape

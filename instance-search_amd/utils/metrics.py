@@ -128,3 +128,135 @@ def retrieval_metrics(test_emb, ref_emb, test_set, ref_set, kth=1, budget_bytes=
     valid = [a for a in aps if a == a]
     return {"prec1": float(correct) / max(M, 1), "correct": correct, "total": M, "max_sim": torch.cat(max_sims, 0) if max_sims else None, "max_label": max_label,
             "mAP": sum(valid) / float(len(valid)) if valid else float("nan"), "aps": aps, "sum_pos": sum_pos, "sum_all": sum_all, "blocks": len(blocks)}
+
+
+# ---- average precision against a gallery sharded by rows -------------------------------------------------------------------------
+# The reference ranks ONE full score row per query (utils/metrics.py:25-45).  AP only depends on the ranks of the positives, and a rank is a count
+# of gallery keys, which adds over shards: three steps around two collectives (include/isx.h, isx_ap_shard_*).  GPU tensors run libisx's kernels;
+# CPU tensors (the reference's --device=-1 mode, the gloo tests) the numpy restatement below -- the same integers, the same float64 expressions.
+_AP_MAXP = 2048
+
+
+def _cpu_rank_keys(scores, gidx):
+    """Canonical ranking keys (larger = ranked earlier: score descending, global index ascending; -0.0 folded onto +0.0) as uint64."""
+    import numpy as np
+    s = np.array(scores, dtype=np.float32, copy=True)
+    s[s == 0.0] = 0.0
+    u = s.view(np.uint32)
+    ob = np.where(u & np.uint32(0x80000000), ~u, u | np.uint32(0x80000000)).astype(np.uint64)
+    return (ob << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - np.asarray(gidx, dtype=np.uint64))
+
+
+def ap_shard_positives(sim, idx_base, qlab, glab, cap=_AP_MAXP):
+    """(keys (M, cap) int64 bit patterns of the uint64 keys, 0 = empty; count (M,) int32): this shard's positives per query."""
+    if sim.is_cuda:
+        from isx import ops
+        return ops.ap_shard_positives(sim.float(), idx_base, qlab.to(sim.device), glab.to(sim.device), cap)
+    import numpy as np
+    s, q, g = sim.float().numpy(), qlab.numpy(), glab.numpy()
+    M = s.shape[0]
+    keys, count = np.zeros((M, cap), dtype=np.uint64), np.zeros((M,), dtype=np.int32)
+    for i in range(M):
+        j = np.nonzero(g == q[i])[0]
+        count[i] = len(j)
+        k = _cpu_rank_keys(s[i, j], idx_base + j)[:cap]
+        keys[i, :len(k)] = k
+    return torch.from_numpy(keys.view(np.int64)), torch.from_numpy(count)
+
+
+def ap_shard_hist(sim, idx_base, keys_all):
+    """This shard's bucket counts (M, 2048) int32 against the gathered keys of all shards (M, W)."""
+    if sim.is_cuda:
+        from isx import ops
+        return ops.ap_shard_hist(sim.float(), idx_base, keys_all.to(sim.device))
+    import numpy as np
+    s, ka = sim.float().numpy(), keys_all.numpy().view(np.uint64)
+    M, N = s.shape
+    hist = np.zeros((M, _AP_MAXP), dtype=np.int32)
+    gidx = idx_base + np.arange(N)
+    for i in range(M):
+        pk = np.sort(ka[i][ka[i] != 0])                          # ascending
+        if len(pk) == 0 or len(pk) > _AP_MAXP:
+            continue
+        x = _cpu_rank_keys(s[i], gidx)
+        x = x[x >= pk[0]]
+        b = len(pk) - np.searchsorted(pk, x, side='right')       # #{positives > x}
+        hist[i, :len(pk)] = np.bincount(b, minlength=len(pk))[:len(pk)]
+    return torch.from_numpy(hist)
+
+
+def ap_from_hist(hist, n_lab, kth=1):
+    """float64 AP per query from the histogram summed over the shards; NaN without a (remaining) positive, -1 over 2048 positives."""
+    if hist.is_cuda:
+        from isx import ops
+        return ops.ap_from_hist(hist, n_lab.to(hist.device), kth)
+    import numpy as np
+    h, nl = hist.numpy(), n_lab.numpy()
+    out = np.empty((h.shape[0],), dtype=np.float64)
+    for r in range(h.shape[0]):
+        n_lab_r = int(nl[r])
+        n_pos = n_lab_r - (kth - 1)
+        if n_pos <= 0:
+            out[r] = float('nan')
+            continue
+        if n_lab_r > _AP_MAXP or n_lab_r > h.shape[1]:
+            out[r] = -1.0
+            continue
+        dn, ap, before, hh = float(n_pos), 0.0, 0, 0
+        for i in range(n_lab_r):
+            before += int(h[r, i])
+            rp = before - 1
+            if rp < kth - 1:
+                continue
+            hcur, hh = hh, hh + 1
+            j = rp - (kth - 1)
+            recall, old_recall = float(hcur + 1) / dn, float(hcur) / dn
+            precision = float(hcur + 1) / (float(j) + 1.0)
+            old_precision = 1.0 if j == 0 else float(hcur) / float(j)
+            ap += (recall - old_recall) * ((old_precision + precision) / 2.0)
+        out[r] = ap
+    return torch.from_numpy(out)
+
+
+def sharded_average_precisions(test_emb, shard_emb, idx_base, qlab, glab_shard, kth=1, group=None, budget_bytes=None):
+    """AP (float64, (M,)) of every query against a gallery whose rows are sharded over the ranks of `group`: `shard_emb` are this rank's rows
+    (global rows idx_base ...), `glab_shard` their labels, `test_emb` / `qlab` the replicated queries.  The same values on every rank, and the
+    same float64 bits as the unsharded evaluation.  Query rows go block by block (the (block, shard) score matrix within budget_bytes)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    M, Ns = test_emb.size(0), shard_emb.size(0)
+    dev = test_emb.device
+    on_wire = (lambda t: t) if world == 1 or dist.get_backend(group) == 'nccl' else (lambda t: t.cpu())
+    out = []
+    ns_max = Ns
+    if world > 1:                                                # the query blocks must be the same on every rank: sized by the LARGEST shard
+        t = on_wire(torch.tensor([Ns], dtype=torch.int64, device=dev))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        ns_max = int(t)
+    for r0, r1 in row_blocks(M, max(ns_max, 1), budget_bytes):
+        from .train_siamese import similarity_matrix
+        sim = similarity_matrix(test_emb[r0:r1], shard_emb) if Ns else test_emb.new_zeros((r1 - r0, 0))
+        keys, count = ap_shard_positives(sim, idx_base, qlab[r0:r1], glab_shard, _AP_MAXP)
+        if world > 1:
+            cap = on_wire(count.max().reshape(1).to(torch.int64)) if count.numel() else torch.zeros(1, dtype=torch.int64)
+            dist.all_reduce(cap, op=dist.ReduceOp.MAX, group=group)
+            cap = max(1, min(int(cap), _AP_MAXP))
+            mine = on_wire(keys[:, :cap].contiguous())
+            parts = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(parts, mine, group=group)
+            keys_all = torch.cat(parts, 1).to(dev)
+            n_lab = on_wire(count.clone())
+            dist.all_reduce(n_lab, group=group)
+            n_lab = n_lab.to(dev)
+        else:
+            keys_all, n_lab = keys, count
+        hist = ap_shard_hist(sim, idx_base, keys_all)
+        ld = max(1, min(int(n_lab.max()) if n_lab.numel() else 1, _AP_MAXP))
+        hist = hist[:, :ld].contiguous()                         # the buckets past the largest number of positives are zero: they need not travel
+        if world > 1:
+            h = on_wire(hist)
+            dist.all_reduce(h, group=group)
+            hist = h.to(dev)
+        out.append(ap_from_hist(hist, n_lab, kth).cpu())
+        del sim
+    return torch.cat(out, 0) if out else torch.zeros((0,), dtype=torch.float64)
