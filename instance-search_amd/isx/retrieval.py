@@ -246,6 +246,14 @@ class ShardedGallery(object):
                 self._fb_event.record(torch.cuda.current_stream(self.shard.device))
         return out
 
+    def average_precisions(self, Q, qlab, glab_local, kth=1, budget_bytes=None):
+        """float64 average precision of every (replicated) query against the WHOLE sharded gallery (reference utils/metrics.py:25-45 on one full
+        score row): the ranks of the positives are counts that add over the shards (include/isx.h isx_ap_shard_*; one all-gather of the
+        positives' keys, one all-reduce of their rank histograms) -- the bits of the unsharded evaluation, on every rank.
+        qlab: (M,) int32 query labels, glab_local: (rows of this shard,) int32."""
+        from utils.metrics import sharded_average_precisions
+        return sharded_average_precisions(Q, self.shard, self.idx_base, qlab, glab_local, kth, self.group, budget_bytes)
+
     def search(self, Q, k):
         """Global canonical top-k for the (replicated) query block Q: (scores (M,k), idx (M,k))."""
         s, i = self.local_search(Q, k)

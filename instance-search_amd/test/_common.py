@@ -231,6 +231,46 @@ def dp_metrics(test_embeddings, ref_embeddings, test_set, ref_set):
     return {'prec1': float(correct) / M, 'correct': correct, 'total': M, 'mAP': sum(valid) / float(len(valid)) if valid else float('nan'), 'aps': aps}
 
 
+class GalleryShard(object):
+    """This rank's contiguous rows of a gallery that is NOT gathered (ISX_EVAL_SHARDED=1, or a slab beyond SHARD_GALLERY_BYTES): `rows` are the
+    descriptors of gallery items [lo, lo + len(rows)) of `total`."""
+
+    def __init__(self, rows, lo, total):
+        self.rows, self.lo, self.total = rows, int(lo), int(total)
+
+    def size(self, dim=None):
+        shape = (self.total, self.rows.size(1))
+        return shape if dim is None else shape[dim]
+
+
+SHARD_GALLERY_BYTES = 64 << 30           # a gallery slab beyond this stays sharded over the ranks (one MI355X holds 288 GB: 1 M x 2048 fp32 is 8.2 GB)
+
+
+def _keep_sharded(n_rows, out_size):
+    mode = os.environ.get('ISX_EVAL_SHARDED', 'auto')
+    if dp_world()[1] == 1 or mode == '0':
+        return False
+    return mode == '1' or n_rows * out_size * 4 > SHARD_GALLERY_BYTES
+
+
+def dp_metrics_sharded(test_embeddings, shard, test_set, ref_set, kth=1):
+    """P@1 and mAP against a gallery that stays sharded by rows: the kth-best gallery item of every query through the sharded search (per-shard
+    top-k, all-gather, canonical merge: isx.retrieval.ShardedGallery), the average precisions through the sharded rank counts
+    (utils.metrics.sharded_average_precisions) -- the values of the unsharded evaluation, no rank ever holds the whole slab or a whole score row."""
+    from isx.retrieval import ShardedGallery
+    from utils.metrics import _label_ids, sharded_average_precisions
+    qlab, glab = _label_ids(test_set, ref_set)
+    M = len(test_set)
+    _, idx = ShardedGallery(shard.rows, idx_base=shard.lo).search(test_embeddings, kth)
+    best = idx[:, kth - 1].cpu().tolist()
+    correct = sum(1 for i, j in enumerate(best) if ref_set[j][1] == test_set[i][1])
+    aps = sharded_average_precisions(test_embeddings, shard.rows, shard.lo, qlab, glab[shard.lo:shard.lo + shard.rows.size(0)], kth).tolist()
+    if any(a == -1.0 for a in aps):
+        raise NotImplementedError('a query has more than 2048 positives: the sharded average precision does not cover it (gather the gallery: ISX_EVAL_SHARDED=0)')
+    valid = [a for a in aps if a == a]
+    return {'prec1': float(correct) / M, 'correct': correct, 'total': M, 'mAP': sum(valid) / float(len(valid)) if valid else float('nan'), 'aps': aps}
+
+
 def gallery_embeddings(get_embeddings, net, ref_set, device, out_size, labels, save_slab=None, gallery_slab=None):
     """(gallery descriptors, gallery set) of an evaluation run.  Default: extracted, as the reference does on every run
     (test/classif_finetune_test.py:80-81).  --save-slab=<file>: the extracted slab is also written to disk (isx/slab.py: row blocks streamed from
@@ -246,6 +286,11 @@ def gallery_embeddings(get_embeddings, net, ref_set, device, out_size, labels, s
             raise ValueError('--gallery-slab: %s holds %d-d descriptors, this run computes %d-d ones' % (gallery_slab, desc.size(1), out_size))
         print('Gallery: {0} descriptors read from {1}'.format(desc.size(0), gallery_slab))
         return desc, slab_set
+    if _keep_sharded(len(ref_set), out_size) and not save_slab:
+        rank, world = dp_world()
+        lo, hi = dp_bounds(len(ref_set), world, rank)
+        local = get_embeddings(net, ref_set[lo:hi], device, out_size) if hi > lo else torch.zeros((0, out_size), device=('cuda:%d' % device if device >= 0 else 'cpu'))
+        return GalleryShard(local, lo, len(ref_set)), ref_set
     emb = dp_embeddings(get_embeddings, net, ref_set, device, out_size)
     if save_slab:
         if dp_world()[0] == 0:                               # every rank holds the whole slab; one writes it
@@ -259,7 +304,12 @@ def evaluate_retrieval(test_embeddings, ref_embeddings, test_set, ref_set, devic
     (prec1, mAP) pair of the plain pass (the reference returns nothing; the prints are the API)."""
     # sim = torch.mm(test_emb, ref_emb.t()) -> precision1 -> mean_avg_precision (reference test/classif_finetune_test.py:82-85),
     # evaluated in query-row blocks when the matrix exceeds utils.metrics.SIM_BUDGET_BYTES (same values, no 40 GB matrix)
-    m = dp_metrics(test_embeddings, ref_embeddings, test_set, ref_set)
+    if isinstance(ref_embeddings, GalleryShard):
+        if dba != 0:
+            raise NotImplementedError('DBA needs the whole gallery on one device: run with ISX_EVAL_SHARDED=0')
+        m = dp_metrics_sharded(test_embeddings, ref_embeddings, test_set, ref_set)
+    else:
+        m = dp_metrics(test_embeddings, ref_embeddings, test_set, ref_set)
     prec1, mAP = m['prec1'], m['mAP']
     print('Descriptor (TEST): {0} / {1} - acc: {2:.4f} - mAP:{3:.4f}'.format(m['correct'], m['total'], prec1, mAP))
     if dba == 0:

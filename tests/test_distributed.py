@@ -89,7 +89,8 @@ def test_shard_bounds_cover_rows():
     ["test.classif_finetune_test", "--dataset=synthetic:CLICIDE_video_224sq:n=14:q=5:labels=3:size=224:struct=60", "--model=alexnet", "--device=-1", "--classify=False", "--batch=4", "--dba=2"],
     ["test.siamese_descriptor_test", "--dataset=synthetic:CLICIDE_video_224sq:n=11:q=4:labels=3:size=224:struct=60", "--model=alexnet", "--device=-1", "--feature-dim=16", "--batch=4", "--dba=0"],
 ])
-def test_evaluation_mains_under_a_two_rank_launch_print_the_single_process_lines(tmp_path, main_args):
+@pytest.mark.parametrize("sharded", ["0", "1"])
+def test_evaluation_mains_under_a_two_rank_launch_print_the_single_process_lines(tmp_path, main_args, sharded):
     """`python -m torch.distributed.run --nproc-per-node 2 -m test.<approach>_test ...` (gloo, CPU): the ranks split queries and gallery, gather the
     descriptor rows, split the metrics by query rows -- rank 0 prints what ONE process prints (same counts; mAP to the printed digits), the other
     rank prints nothing."""
@@ -110,8 +111,12 @@ def test_evaluation_mains_under_a_two_rank_launch_print_the_single_process_lines
         env.pop(k, None)
     one = subprocess.run([sys.executable, "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
+    if sharded == "1":                                           # the gallery stays sharded by rows: sharded search + sharded average precision; no DBA there
+        main_args = [a if not a.startswith("--dba=") else "--dba=0" for a in main_args]
+        one = subprocess.run([sys.executable, "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
+        assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-                          str(_free_port()), "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
+                          str(_free_port()), "-m"] + main_args, env=dict(env, ISX_EVAL_SHARDED=sharded), cwd=pkg, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
     assert pick(one.stdout) and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)

@@ -572,7 +572,8 @@ def test_streaming_ingest_matches_resident_path(monkeypatch):
                   "--batch=16", "--dba=3"]),
     ("regions", ["test.classif_regions_test", "--dataset=synthetic:CLICIDE_video_448:n=18:q=7:labels=3:size=288:struct=50", "--model=resnet50", "--device=0", "--dba=0"]),
 ])
-def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(tmp_path, which, main_args):
+@pytest.mark.parametrize("sharded", ["0", "1"])
+def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(tmp_path, which, main_args, sharded):
     """SURVEY 8e through the reference's CLI surface: `torch.distributed.run --nproc-per-node 2 -m test.<approach>_test` (both ranks on the box's one
     GPU over gloo: ISX_BENCH_ONE_DEVICE=1; RCCL replaces only the transport) splits queries and gallery over the ranks, gathers the descriptor rows
     and splits the metrics by query rows -- and prints exactly what one process prints from the same weights file: the kernels give an image the same
@@ -588,6 +589,8 @@ def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(tm
     weights = str(tmp_path / "w.pth.tar")
     torch.save(net.state_dict(), weights)
     main_args = main_args + ["--weights=" + weights]
+    if sharded == "1":                                           # the gallery stays sharded by rows (sharded search + isx_ap_shard_*); no DBA there
+        main_args = [a if not a.startswith("--dba=") else "--dba=0" for a in main_args]
     # OMP_NUM_THREADS=1 for both runs: torch.distributed.run sets it for its workers, and the SYNTHETIC images (host arithmetic of
     # utils.dataset.synthetic_image_set) differ in the last bit between thread counts -- the inputs, not the path, would differ
     env = dict(os.environ, ISX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
@@ -597,7 +600,7 @@ def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(tm
     one = subprocess.run([sys.executable, "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
+                          "-m"] + main_args, env=dict(env, ISX_EVAL_SHARDED=sharded), cwd=pkg, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
     assert len(pick(one.stdout)) >= 4 and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)
