@@ -97,7 +97,8 @@ def test_shard_head_worker_one_rank(tmp_path):
 
 
 @needs2
-def test_evaluation_main_over_rccl_prints_the_single_process_lines(tmp_path):
+@pytest.mark.parametrize("sharded", ["0", "1"])
+def test_evaluation_main_over_rccl_prints_the_single_process_lines(tmp_path, sharded):
     """`torch.distributed.run --nproc-per-node N -m test.classif_finetune_test` with one rank per GPU over RCCL (class scores as descriptors): the
     lines of one process, from the same weights file."""
     sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
@@ -108,8 +109,8 @@ def test_evaluation_main_over_rccl_prints_the_single_process_lines(tmp_path):
     weights = str(tmp_path / "w.pth.tar")
     torch.save(TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5).state_dict(), weights)
     args = ["test.classif_finetune_test", "--dataset=synthetic:CLICIDE_video_224sq:n=70:q=21:labels=5:size=224:struct=50", "--model=resnet50", "--device=0",
-            "--classify=True", "--batch=16", "--dba=3", "--weights=" + weights]
-    env = dict(_env(), OMP_NUM_THREADS="1")
+            "--classify=True", "--batch=16", "--dba=" + ("0" if sharded == "1" else "3"), "--weights=" + weights]
+    env = dict(_env(), OMP_NUM_THREADS="1", ISX_EVAL_SHARDED=sharded)
     pkg = os.path.join(ROOT, "instance-search_amd")
     one = subprocess.run([sys.executable, "-m"] + args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
