@@ -283,6 +283,8 @@ def compact_line(full, detail_file=None):
                        "identical_to_fp32_path", "includes"))
         if isinstance(sh.get("fp32_path"), dict):
             c["fp32_path"] = _pick(sh["fp32_path"], ("ms", "dist_per_s", "frac_of_f32_mfma_peak"))
+        if isinstance(sh.get("sharded_average_precision"), dict):
+            c["sharded_average_precision"] = _pick(sh["sharded_average_precision"], ("ms", "queries", "mAP"))
         line["retrieval_shard"] = c
     rg = full.get("extraction_regions")
     if isinstance(rg, dict):
@@ -674,7 +676,30 @@ def main():
             print("bench.py: WARNING isx_cosine_topk_fast differs from isx_cosine_topk on the shard workload", file=sys.stderr)
         assert ri.shape == (Ms, k) and int(ri.min()) >= 0 and int(ri.max()) < Ns * world
         flop = 2.0 * Ms * Ns * world * D
+        # full-rank average precision of the same queries WITHOUT gathering the gallery (isx_ap_shard_*: the ranks of the positives are counts that
+        # add over shards): labels as SURVEY 8d assigns them (row i of the whole gallery: i mod N / 10), 10 positives per query and shard
+        from utils.metrics import sharded_average_precisions
+        L = Ns * world // 10
+        glab_l = ((torch.arange(Ns, dtype=torch.int64) + rank * Ns) % L).to(torch.int32)
+        qlab_l = (torch.arange(Ms, dtype=torch.int64) % L).to(torch.int32)
+        gal32 = retrieval.ShardedGallery(Gs, idx_base=rank * Ns, fast=False)
+        sharded_average_precisions(Qs[:256], Gs, rank * Ns, qlab_l[:256], glab_l)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ta0 = time.perf_counter()
+        aps_ = gal32.average_precisions(Qs, qlab_l, glab_l)
+        torch.cuda.synchronize()
+        ap_ms = (time.perf_counter() - ta0) * 1e3
+        if world > 1:
+            tm_ = torch.tensor([ap_ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
+            ap_ms = float(tm_.item())
+        ap_valid = aps_[aps_ == aps_]
         return {"shape": [Ms, Ns * world, D], "gallery_rows_per_gpu": Ns, "k": k, "ms": ms,
+                "sharded_average_precision": {"ms": ap_ms, "queries": Ms, "mAP": float(ap_valid.mean()) if ap_valid.numel() else None,
+                                              "includes": "fp32 score rows of the shard (isx_cosine_sim, query blocks) + isx_ap_shard_positives + _hist + isx_ap_from_hist"
+                                                          + (" + all-gather of the positives' keys + all-reduce of the rank histograms" if world > 1 else "")},
                 "dist_per_s": Ms * Ns * world / (ms * 1e-3),
                 "tflops_end_to_end": flop / (ms * 1e-3) / 1e12,
                 "frac_of_f16_mfma_peak": flop / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS * world),
