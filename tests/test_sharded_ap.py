@@ -53,6 +53,10 @@ def test_cpu_restatement_equals_the_unsharded_evaluation(bounds, kth):
     want = MT._average_precisions(sim, qlab, glab, kth)
     got, _, _, n_lab = _sharded(sim, qlab, glab, bounds, kth)
     assert _same(got, want) and want.isnan().any() and int(n_lab.max()) > 5
+    # and the oracle's restatement of the reference loop on the canonically ranked list (oracle/isx_oracle.c, pinned by the reference's own function)
+    import oracle as O
+    ora = torch.from_numpy(O.average_precision(O.rank_full(sim.numpy()), qlab.numpy(), glab.numpy(), kth))
+    assert _same(got, ora)
 
 
 def _two_ranks(rank, world, port, out):
