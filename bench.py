@@ -678,12 +678,11 @@ def main():
         flop = 2.0 * Ms * Ns * world * D
         # full-rank average precision of the same queries WITHOUT gathering the gallery (isx_ap_shard_*: the ranks of the positives are counts that
         # add over shards): labels as SURVEY 8d assigns them (row i of the whole gallery: i mod N / 10), 10 positives per query and shard
-        from utils.metrics import sharded_average_precisions
         L = Ns * world // 10
         glab_l = ((torch.arange(Ns, dtype=torch.int64) + rank * Ns) % L).to(torch.int32)
         qlab_l = (torch.arange(Ms, dtype=torch.int64) % L).to(torch.int32)
         gal32 = retrieval.ShardedGallery(Gs, idx_base=rank * Ns, fast=False)
-        sharded_average_precisions(Qs[:256], Gs, rank * Ns, qlab_l[:256], glab_l)
+        gal32.average_precisions(Qs, qlab_l, glab_l)             # warm-up at full size: the 5 GB score block comes out of the caching allocator afterwards
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
