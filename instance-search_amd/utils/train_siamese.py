@@ -52,13 +52,40 @@ def similarity_matrix(a, b):
     return torch.mm(a, b.t())
 
 
+def dp_get_embeddings(get_embeddings, net, dataset, device, out_size):
+    """get_embeddings under data-parallel TRAINING: on the GPU every rank extracts a contiguous 1/P of the set and the descriptor rows are
+    all-gathered (the per-epoch embedding pass and the evaluations in between were run whole by every rank -- P times the work for the same
+    tensor).  The HIP path gives an image the same descriptor whatever batch it rides in, so the gathered slab is the single-process one bit for
+    bit: same mined negatives, same metrics on every rank.  CPU runs (torch's convolutions may pick kernels by batch size) keep the whole pass."""
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world == 1 or device < 0 or len(dataset) < world:
+        return get_embeddings(net, dataset, device, out_size)
+    rank = dist.get_rank()
+    bounds = [((len(dataset) * r) // world, (len(dataset) * (r + 1)) // world) for r in range(world)]
+    lo, hi = bounds[rank]
+    local = get_embeddings(net, dataset[lo:hi], device, out_size)
+    most = max(b - a for a, b in bounds)
+    pad = local.new_zeros((most, local.size(1)))
+    pad[:local.size(0)].copy_(local)
+    if dist.get_backend() == 'nccl':
+        out = pad.new_empty((world * most, local.size(1)))
+        dist.all_gather_into_tensor(out, pad)
+        parts = [out[r * most:r * most + (b - a)] for r, (a, b) in enumerate(bounds)]
+    else:
+        host = pad.cpu()
+        bufs = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(bufs, host)
+        parts = [bufs[r][:b - a].to(local.device) for r, (a, b) in enumerate(bounds)]
+    return torch.cat(parts, 0)
+
+
 def get_similarities(P, get_embeddings, net, dataset):
     """(n x n similarities of the dataset's descriptors, device).  Over utils.metrics.SIM_BUDGET_BYTES the matrix is
     returned as a SimilarityRows (row blocks on demand) -- train.siamese_descriptor.mine_epoch_negatives consumes both."""
     from . import metrics
     set_net_train(net, False)
     d, o = embeddings_device_dim(P, net, len(dataset), sim_matrix=True)
-    emb = get_embeddings(net, dataset, d, o)
+    emb = dp_get_embeddings(get_embeddings, net, dataset, d, o)
     n = emb.size(0)
     sim = SimilarityRows(emb) if n * n * 4 > metrics.SIM_BUDGET_BYTES else similarity_matrix(emb, emb)
     set_net_train(net, True, bn_train=P.train_bn)
@@ -68,8 +95,8 @@ def get_similarities(P, get_embeddings, net, dataset):
 def test_descriptor_net(P, get_embeddings, net, test_set, test_ref_set, kth=1):
     from .metrics import retrieval_metrics
     d, o = embeddings_device_dim(P, net, max(len(test_set), len(test_ref_set)))
-    m = retrieval_metrics(get_embeddings(net, test_set, d, o), get_embeddings(net, test_ref_set, d, o), test_set, test_ref_set, kth,
-                          with_sums=True)
+    m = retrieval_metrics(dp_get_embeddings(get_embeddings, net, test_set, d, o), dp_get_embeddings(get_embeddings, net, test_ref_set, d, o),
+                          test_set, test_ref_set, kth, with_sums=True)
     sum_neg = m['sum_all'] - m['sum_pos']
     sum_max = float(m['max_sim'].double().sum())
     lab_dict = dict((lab, {}) for _, lab, _ in test_set)
