@@ -97,6 +97,12 @@ def main():
     if rank == 0:
         us, ui = ops.cosine_topk(Qd, Gd, k)                  # unsharded, this GPU alone
         res["unsharded"] = (us.cpu(), ui.cpu())
+    # full-rank average precision without gathering the gallery (isx_ap_shard_*: all-gather of the positives' keys, all-reduce of the rank histograms)
+    glab = (torch.arange(N) % 97).to(torch.int32)
+    qlab = (torch.arange(M) % 97).to(torch.int32)
+    res["sharded_ap"] = R.ShardedGallery(Gd[lo:hi], lo).average_precisions(Qd, qlab, glab[lo:hi]).cpu()
+    if rank == 0:
+        res["unsharded_ap"] = ops.average_precision_sim(ops.cosine_sim(Qd, Gd), qlab.to(dev), glab.to(dev), 1).cpu()
     torch.cuda.synchronize()
     nc.close()
     # replicated gallery, queries split by rank

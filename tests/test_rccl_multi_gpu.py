@@ -55,6 +55,8 @@ def test_rccl_sharded_search_and_grad_allreduce(tmp_path):
             assert torch.equal(r[k]["w0"][n], r[0]["w0"][n])                   # broadcast: identical replicas
         assert torch.equal(r[k]["flat"], r[0]["flat"])                         # every rank holds the same summed gradient
     np.testing.assert_allclose(r[0]["flat"].numpy(), r[0]["ref_flat"].numpy(), rtol=2e-5, atol=2e-6)
+    for k in range(world):                                                      # sharded average precision == the unsharded kernel, float64 bits, every rank
+        assert torch.equal(torch.nan_to_num(r[k]["sharded_ap"], nan=-7.0), torch.nan_to_num(r[0]["unsharded_ap"], nan=-7.0)), k
     if "tree" in r[0]:
         for k in range(world):
             assert torch.equal(r[k]["tree"], r[0]["tree_ref"]), k                # TreeExchange over RCCL == the single-process tree sum, bit for bit
