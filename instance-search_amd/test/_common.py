@@ -107,6 +107,16 @@ def load_sets(dataset_full, labels, raw=False, lazy=None):
     else:
         ref = [(im, lab, f) for im, (f, lab) in zip(_decode_all(load, [f for f, _ in ref_files]), ref_files)]
     qry_files = [(f, lab) for f, lab in qry_files if lab in labels]
+    rank, world = dp_world()
+    if world > 1 and raw and qry_files:
+        # data-parallel evaluation: a rank classifies and embeds only ITS contiguous slice of the queries (dp_classify / dp_embeddings) -- only
+        # those files are decoded here; the others keep their place in the list (labels and paths are what the metrics read of them)
+        from train import _common as TC
+        lo, hi = dp_bounds(len(qry_files), world, rank)
+        mine = _decode_all(load, [f for f, _ in qry_files[lo:hi]])
+        first = mine[0] if mine else load(qry_files[0][0])
+        qry = [(mine[i - lo] if lo <= i < hi else TC.LazyImage(f, load, first.shape, first.dtype), lab, f) for i, (f, lab) in enumerate(qry_files)]
+        return qry, ref
     qry = [(im, lab, f) for im, (f, lab) in zip(_decode_all(load, [f for f, _ in qry_files]), qry_files)]
     return qry, ref
 

@@ -99,6 +99,11 @@ def usable_cpus():
                 n = min(n, max(1, int(float(quota) / period + 0.5)))
         except Exception:
             pass
+    # one rank per GPU on a node (torch.distributed.run sets LOCAL_WORLD_SIZE): the ranks share the container's CPUs
+    try:
+        n = max(1, n // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1'))))
+    except ValueError:
+        pass
     return max(1, n)
 
 

@@ -637,3 +637,45 @@ def test_classifier_scores_do_not_depend_on_the_batch():
         assert "_c_pad64" in lin.__dict__ and torch.equal(y0, ops.head_linear_any(r, lin.weight.detach(), lin.bias.detach()))
         lin.weight.mul_(2.0); lin.bias.mul_(2.0)
         assert torch.equal(lin(r), 2.0 * y0)
+
+
+def test_evaluation_main_two_ranks_on_a_folder_of_files(tmp_path):
+    """The same on a FOLDER dataset (image files, raw uint8 ingest, lazy gallery): under two ranks each decodes only its slice of the queries and of
+    the gallery files (decoder processes per rank), and rank 0 prints the single-process lines."""
+    import subprocess
+    import socket
+    from PIL import Image
+    from isx import backbones
+    from model.siamese import TuneClassif
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "instance-search_amd")
+    ds = tmp_path / "CLICIDE_video_224sq"
+    (ds / "test").mkdir(parents=True)
+    (tmp_path / "data").mkdir()
+    (tmp_path / "data" / "CLICIDE_224sq_train_ms.txt").write_text("0.485 0.456 0.406\n0.229 0.224 0.225\n")
+    rng = np.random.default_rng(2)
+    base = {lab: rng.integers(0, 256, (224, 224, 3)) for lab in "abcde"}
+    for lab in "abcde":
+        for i in range(15):
+            noisy = np.clip(base[lab] + rng.integers(-40, 41, (224, 224, 3)), 0, 255).astype(np.uint8)
+            Image.fromarray(noisy).save(ds / ("%s-%d.jpg" % (lab, i)), quality=92)
+        for i in range(3):
+            noisy = np.clip(base[lab] + rng.integers(-40, 41, (224, 224, 3)), 0, 255).astype(np.uint8)
+            Image.fromarray(noisy).save(ds / "test" / ("%s-q%d.jpg" % (lab, i)), quality=92)
+    torch.manual_seed(3)
+    weights = str(tmp_path / "w.pth.tar")
+    torch.save(TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5).state_dict(), weights)
+    args = ["test.classif_finetune_test", "--dataset=" + str(ds), "--model=resnet50", "--device=0", "--classify=False", "--batch=16", "--dba=0", "--weights=" + weights]
+    env = dict(os.environ, ISX_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", ISX_DECODE_PROCS="3", ISX_DECODE_FARM_MIN="4",
+               PYTHONPATH=pkg)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    one = subprocess.run([sys.executable, "-m"] + args, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          "-m"] + args, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
+    assert len(pick(one.stdout)) >= 4 and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)
+    assert "Descriptor (TEST): 15 / 15" in one.stdout                            # structured images: every query finds its instance
