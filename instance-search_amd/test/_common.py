@@ -336,7 +336,7 @@ def run_cli(argv, usage, spec, required, main, P):
     """getopt front-end shared by the four scripts.  `spec`: option name -> (kind, label) with
     kind in {'dataset','model','file','int','bool'}; returns after calling main(**values)."""
     try:
-        opts, _ = getopt.getopt(argv, '', ['help'] + [name + '=' for name in spec])
+        opts, _ = getopt.getopt(argv, '', ['help', 'sharded='] + [name + '=' for name in spec])
     except getopt.GetoptError:
         usage()
         sys.exit(2)
@@ -346,6 +346,9 @@ def run_cli(argv, usage, spec, required, main, P):
         if opt == '--help':
             usage()
             sys.exit()
+        if opt == '--sharded':                           # every main: keep the gallery sharded over the ranks of a torch.distributed.run launch
+            os.environ['ISX_EVAL_SHARDED'] = '1' if check_bool(arg, 'sharded', usage) else '0'
+            continue
         name = opt[2:]
         kind, label = spec[name]
         if kind == 'dataset':
@@ -417,5 +420,7 @@ O_DEVICE = '--device=\t<int>\tThe GPU device used for testing. If negative, CPU 
 O_DBA = ('--dba=\t<int>\tUse DBA with given k. If k = 0, do not use DBA. If k<0, use all neighbors within the '
          'same instance.\n')
 O_SLAB = ('--save-slab=\t<file>\t(extension) Also write the gallery descriptors to this slab file.\n'
-          '--gallery-slab=\t<file>\t(extension) Read the gallery descriptors from this slab file instead of extracting them.\n')
+          '--gallery-slab=\t<file>\t(extension) Read the gallery descriptors from this slab file instead of extracting them.\n'
+          '--sharded=\t<bool>\t(extension, under torch.distributed.run) Keep the gallery sharded by rows over the ranks instead of gathering it '
+          '(sharded search + sharded average precision; default: only beyond 64 GB).\n')
 O_BATCH = '--batch=\t<int>\tThe batch size to use.\n'

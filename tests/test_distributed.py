@@ -116,7 +116,7 @@ def test_evaluation_mains_under_a_two_rank_launch_print_the_single_process_lines
         one = subprocess.run([sys.executable, "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
         assert one.returncode == 0, one.stderr[-2000:]
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
-                          str(_free_port()), "-m"] + main_args, env=dict(env, ISX_EVAL_SHARDED=sharded), cwd=pkg, capture_output=True, text=True, timeout=900)
+                          str(_free_port()), "-m"] + main_args + ["--sharded=" + ("True" if sharded == "1" else "False")], env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
     assert pick(one.stdout) and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)
