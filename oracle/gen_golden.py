@@ -14,7 +14,8 @@ place and unmodified, with harness-side shims only:
 Closures that cannot be imported (train/*::get_embeddings -- module-level P)
 are replayed line by line on KD tensors, citing the lines.
 
-Usage:  python oracle/gen_golden.py      (writes tests/golden/)
+Usage:  python oracle/gen_golden.py      (writes tests/golden/; ISX_GOLDEN_OUT=<dir> writes elsewhere, e.g. to
+        compare a regeneration with the committed fixtures: tools/check_golden_regen.py)
 """
 import importlib.util
 import json
@@ -28,7 +29,7 @@ import torch.nn as nn
 
 sys.dont_write_bytecode = True
 R = "/root/reference"
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.environ.get("ISX_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
 def load(name, path):
@@ -361,7 +362,7 @@ def main():
             return last + [[idx, bool(is_final), len(batch)]]
         calls["%d_%d_%d" % (n, bs, cut)] = tg.fold_batches(f, [], list(range(n)), bs, cut_end=cut)
     host["fold_batches"] = calls
-    ts_mod = load("train_siamese", R + "/utils/train_siamese.py") if False else None  # imports utils pkg; restated instead
+    # utils/train_siamese.py (a14 / a15) is run by siamese_eval() below
     with open(os.path.join(OUT, "host_helpers.json"), "w") as fh:
         json.dump(host, fh, indent=1, sort_keys=True)
     print("golden fixtures written to", os.path.abspath(OUT))
@@ -457,6 +458,105 @@ def dba():
     npz("dba.npz", **out)
 
 
+def siamese_eval():
+    """a14 / a15: the reference's own utils/train_siamese.py (embeddings_device_dim :30-43, get_similarities :48-55,
+    test_descriptor_net :61-82), imported in place and run unmodified.  Its imports (`general`, `dataset`, `metrics`,
+    `model.nn_utils`) are the reference's files loaded as top-level modules, as the file itself expects (it puts utils/
+    on the path).  Harness-side shim only: descriptors handed over as KD tensors (torch-0.1.x keepdim reductions, stable
+    descending sort -> canonical tie order).  get_embeddings is the identity on the descriptor stored in each dataset
+    tuple, so the fixture pins everything AFTER the embedding pass: P@1 (kth 1 and 2), mAP, sum_pos, sum_neg, sum_max,
+    lab_dict (including the reference's `setdefault(lab, get(lab, 0) + 1)` counting quirk)."""
+    for name, path in (("general", "/utils/general.py"), ("dataset", "/utils/dataset.py"), ("metrics", "/utils/metrics.py")):
+        if name not in sys.modules:
+            load(name, R + path)
+    if "torchvision" not in sys.modules:
+        install_shims()
+    nn_utils = sys.modules["nn_utils"]
+    mod = types.ModuleType("model"); mod.nn_utils = nn_utils
+    sys.modules["model"] = mod; sys.modules["model.nn_utils"] = nn_utils
+    ts_mod = load("ref_train_siamese", R + "/utils/train_siamese.py")
+    cm = sys.modules["custom_modules"]
+
+    class P:
+        cuda_device, feature_dim, embeddings_cuda_size, train_bn = 0, 0, 2 ** 30, False
+
+    class Net(nn.Module):
+        def __init__(self, fs):
+            super().__init__()
+            self.features = nn.Sequential(nn.Conv2d(3, 4, 1), nn.BatchNorm2d(4))
+            self.feature_size = fs
+
+    class Bare(object):
+        pass
+
+    # ---- embeddings_device_dim: every branch of :30-43
+    dim_cases = []
+    for cuda_device, feature_dim, fs, n, sim_matrix in (
+            (0, 0, 32, 10, False), (0, 64, 32, 10, False), (3, -1, 2048, 1000, False), (-1, 32, 32, 10, False),
+            (0, 0, 32, 2 ** 23, False), (0, 0, 32, 2 ** 23 + 1, False),            # slab exactly at / just over the budget
+            (0, 0, 32, 16384, True), (0, 0, 32, 16385, True),                       # n x n exactly at / just over
+            (0, 128, None, 10, False), (0, 0, None, 10, False)):                    # a net without feature_size
+        P.cuda_device, P.feature_dim = cuda_device, feature_dim
+        net = Net(fs) if fs is not None else Bare()
+        dev, out = ts_mod.embeddings_device_dim(P, net, n, sim_matrix)
+        dim_cases.append({"cuda_device": cuda_device, "feature_dim": feature_dim, "feature_size": fs, "n": n,
+                          "sim_matrix": sim_matrix, "budget": P.embeddings_cuda_size, "device": dev, "out_size": out})
+
+    # ---- test_descriptor_net / get_similarities on the SURVEY 8d synthetic set (sigma = 4), D = 32
+    out = {}
+    meta = {"embeddings_device_dim": dim_cases, "runs": {}}
+    P.cuda_device, P.feature_dim = -1, 32
+    for tag, (N_, M_) in (("n100", (100, 20)), ("n1000", (1000, 50))):
+        sg = torch.Generator().manual_seed(0)
+        L_, D_ = N_ // 10, 32
+        cent = torch.randn(L_, D_, generator=sg)
+        gl = torch.arange(N_) % L_
+        ql = torch.arange(M_) % L_
+        G = cent[gl] + 4.0 * torch.randn(N_, D_, generator=sg)
+        Q = cent[ql] + 4.0 * torch.randn(M_, D_, generator=sg)
+        G = cm.NormalizeL2Fun().forward(G.as_subclass(KD)).as_subclass(torch.Tensor)
+        Q = cm.NormalizeL2Fun().forward(Q.as_subclass(KD)).as_subclass(torch.Tensor)
+        if tag == "n100":
+            ql = ql.clone(); ql[7] = 99                       # a query whose label is absent from the gallery (AP skipped, :31-32 of metrics)
+            G[13] = G[3]                                      # duplicated gallery rows: tied scores in every row
+        test_set = [(Q[i], "L%d" % int(l), None) for i, l in enumerate(ql)]
+        ref_set = [(G[i], "L%d" % int(l), None) for i, l in enumerate(gl)]
+        seen = []
+
+        def get_embeddings(net, dataset, device, out_size):
+            seen.append((len(dataset), device, out_size))
+            return torch.stack([x for x, _, _ in dataset]).as_subclass(KD)
+
+        net = Net(32)
+        out.update({"Q_" + tag: Q, "G_" + tag: G, "qlab_" + tag: np.array([int(l) for l in ql], np.int32),
+                    "glab_" + tag: gl.int()})
+        for kth in (1, 2):
+            # kth = 2 is the reference's train-against-train form (:113): queries drawn from the gallery itself
+            if kth == 2:
+                qs = [ref_set[i] for i in range(0, N_, 7)]
+                out["self_idx_" + tag] = np.arange(0, N_, 7, dtype=np.int64)
+            else:
+                qs = test_set
+            del seen[:]
+            prec1, correct, total, sum_pos, sum_neg, sum_max, mAP, lab_dict = ts_mod.test_descriptor_net(P, get_embeddings, net, qs, ref_set, kth)
+            key = "%s_kth%d" % (tag, kth)
+            out["sums_" + key] = np.array([float(sum_pos), float(sum_neg), float(sum_max)], np.float64)
+            out["sums_f32_" + key] = np.array([float(sum_pos), float(sum_neg), float(sum_max)], np.float32)
+            out["p1_" + key] = np.array([prec1, correct, total], np.float64)
+            out["map_" + key] = np.float64(mAP)
+            meta["runs"][key] = {"lab_dict": {k: dict(v) for k, v in lab_dict.items()}, "get_embeddings_calls": list(map(list, seen))}
+        # get_similarities (:48-55): eval mode for the pass, train mode with frozen BatchNorm afterwards
+        net.train()
+        sims, dev = ts_mod.get_similarities(P, get_embeddings, net, ref_set)
+        sims = sims.as_subclass(torch.Tensor)
+        out["selfsim_" + tag] = sims if N_ <= 100 else sims[::125]     # n1000: 8 of the 1000 rows keep the fixture small
+        meta["runs"][tag + "_get_similarities"] = {"device": dev, "net_training": bool(net.training),
+                                                   "bn_training": bool(net.features[1].training)}
+    npz("siamese_eval.npz", **out)
+    with open(os.path.join(OUT, "siamese_eval.json"), "w") as fh:
+        json.dump(meta, fh, indent=1, sort_keys=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "trunk":
         os.makedirs(OUT, exist_ok=True)
@@ -464,7 +564,11 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "dba":
         os.makedirs(OUT, exist_ok=True)
         dba()
+    elif len(sys.argv) > 1 and sys.argv[1] == "siamese_eval":
+        os.makedirs(OUT, exist_ok=True)
+        siamese_eval()
     else:
         main()
         trunk_block()
         dba()
+        siamese_eval()

@@ -431,6 +431,17 @@ def test_descriptor_head_golden_on_gpu(golden):
     assert int(g["feature_size"]) == D
 
 
+@pytest.mark.parametrize("tag,kth", [("n100", 1), ("n100", 2), ("n1000", 1), ("n1000", 2)])
+def test_descriptor_net_evaluation_on_gpu_matches_the_reference_run(golden, tag, kth):
+    """a15 on the GPU (isx_cosine_sim -> isx_topk_rows / isx_average_precision_sim / isx_masked_sums) against what the reference's
+    own utils/train_siamese.py:61-82 returned on the same descriptors (oracle/gen_golden.py::siamese_eval)."""
+    import json
+    from test_dropin_cpu import GOLDEN, check_siamese_eval_against_reference
+    g = golden("siamese_eval.npz")
+    meta = json.load(open(os.path.join(GOLDEN, "siamese_eval.json")))
+    check_siamese_eval_against_reference(g, meta, 0, tag, kth)
+
+
 def test_instance_avg_on_gpu_matches_reference_fixture(golden):
     """DBA on the GPU -- isx_cosine_sim + label masking + isx_topk_rows + weighted gather -- against the
     output of the reference's own test/instance_avg.py (fixture dba.npz)."""
