@@ -75,18 +75,21 @@ _HEAD_WS = {}
 
 
 def head_linear_applicable(rows, weight, any_width=False):
-    """any_width: N need not be a multiple of 64 (head_linear_any pads the weight's rows)."""
+    """any_width: N need not be a multiple of 64 nor K of 32 (head_linear_any pads the weight with zeros)."""
+    K = weight.size(1) if weight.dim() == 2 else 0
+    Kp = (K + 31) // 32 * 32 if any_width else K
     return (rows.is_cuda and rows.dtype == torch.float32 and weight.dtype == torch.float32 and weight.is_contiguous() and rows.dim() == 2
-            and weight.dim() == 2 and weight.size(1) % 32 == 0 and (any_width or weight.size(0) % 64 == 0) and 192 * weight.size(1) * 4 < 2 ** 32
+            and weight.dim() == 2 and Kp % 32 == 0 and Kp > 0 and (any_width or weight.size(0) % 64 == 0) and 192 * Kp * 4 < 2 ** 32
             and rows.size(0) < 2 ** 24)
 
 
 def pad_rows_to_64(weight, bias=None):
-    """(weight, bias) with the weight's rows and the bias padded with zeros to a multiple of 64 outputs (head_linear's tile height)."""
-    N = weight.size(0)
-    Np = (N + 63) // 64 * 64
-    wp = weight.new_zeros((Np, weight.size(1)))
-    wp[:N].copy_(weight.detach())
+    """(weight, bias) padded with zeros to the GEMM's granules: rows (output features) to a multiple of 64 (head_linear's tile height) and
+    -- for a weight whose K is not a multiple of 32 -- columns to a multiple of 32 (the k-tile)."""
+    N, K = weight.shape
+    Np, Kp = (N + 63) // 64 * 64, (K + 31) // 32 * 32
+    wp = weight.new_zeros((Np, Kp))
+    wp[:N, :K].copy_(weight.detach())
     bp = None
     if bias is not None:
         bp = bias.new_zeros((Np,))
@@ -95,16 +98,22 @@ def pad_rows_to_64(weight, bias=None):
 
 
 def head_linear_any(rows, weight, bias=None, padded=None):
-    """head_linear for any number of output features: rows of zeros pad the weight (and the bias) to a multiple of 64, the padding columns are
-    dropped.  Every output element is its own chain over K, so the padding changes no value.  `padded`: the (weight, bias) pair of pad_rows_to_64,
-    kept by the caller next to its weight (model/siamese.RowsLinear caches it per version of the parameter); None: padded here, per call.
+    """head_linear for any number of output features and any K: zeros pad the weight (and the bias) to a multiple of 64 outputs and of 32
+    inputs, the rows are padded with zero columns to the same K, the padding outputs are dropped.  Every output element is its own set of
+    k-ordered chains, and a zero product leaves a chain's value untouched (fma(0, 0, acc) == acc), so the padding changes no value: the
+    result is what the kernel would compute with a zero-filled k tail, still independent of the batch (no torch / hipBLASLt GEMM, whose
+    kernel choice depends on M).  `padded`: the (weight, bias) pair of pad_rows_to_64, kept by the caller next to its weight
+    (model/siamese.RowsLinear caches it per version of the parameter); None: padded here, per call.
     For the classifier layers of TuneClassif (2048 -> 464 class scores, reference model/siamese.py:28-32): a row's scores do not depend on the
     batch it is computed in, as with every other descriptor of the path."""
-    N = weight.size(0)
-    if N % 64 == 0:
+    N, K = weight.shape
+    if N % 64 == 0 and K % 32 == 0:
         return head_linear(rows, weight, bias)
     wp, bp = padded if padded is not None else pad_rows_to_64(weight, bias)
-    return head_linear(rows, wp, bp)[:, :N].contiguous()
+    if wp.size(1) != K:
+        rows = torch.nn.functional.pad(rows, (0, wp.size(1) - K))
+    y = head_linear(rows, wp, bp)
+    return y if N == wp.size(0) else y[:, :N].contiguous()
 
 
 def head_linear(rows, weight, bias=None):

@@ -85,6 +85,20 @@ _GEMM_1X1 = os.environ.get("ISX_CONV1X1", "1") != "0"
 _FUSE_EXPAND = os.environ.get("ISX_FUSE_EXPAND", "1") != "0"     # 0: conv2 and conv3 of the 64-channel bottlenecks as two kernels again
 _FUSED_STEM = os.environ.get("ISX_STEM", "1") != "0"       # 0: stem convolution back to MIOpen + the separate bias/ReLU/maxpool pass
 _FUSE_PROJECTION = os.environ.get("ISX_FUSE_PROJECTION", "1") != "0"     # last 1x1 conv + projection shortcut as one GEMM
+if not (_GEMM_1X1 and _FUSED_STEM and _FUSE_EXPAND and _FUSE_PROJECTION and _CONV3X3_MODE == "auto"):
+    import warnings
+    warnings.warn("libisx A/B switches are set (ISX_CONV1X1 / ISX_CONV3X3 / ISX_STEM / ISX_FUSE_EXPAND / ISX_FUSE_PROJECTION): some trunk "
+                  "convolutions run on MIOpen or unfused in this process -- a measurement aid, not the product path")
+
+# Convolutions that ran on torch's conv2d (MIOpen) on a GPU tensor in this process, as {(kernel, stride, Cin, Cout): calls}: the ResNet
+# trunks leave it empty (every layer is a libisx kernel); AlexNet's 11x11 / 5x5 layers and its 3x3 layers at 13x13 with Cin > 128, a 3x3
+# with Cin % 32 != 0, grouped / dilated convolutions and stand-alone strided 1x1 layers land here ("what still runs on MIOpen").
+TORCH_CONV_CALLS = {}
+
+
+def _note_torch_conv(c):
+    key = (tuple(c.kernel_size), tuple(c.stride), c.in_channels, c.out_channels)
+    TORCH_CONV_CALLS[key] = TORCH_CONV_CALLS.get(key, 0) + 1
 
 
 def _derived(owner, slot, sources, build):
@@ -155,6 +169,8 @@ class _ConvBiasAct(nn.Module):
                 residual = residual.contiguous(memory_format=torch.channels_last)
             return ops.conv1x1_nhwc(x, self.conv.weight, self.bias, residual, self.relu)
         y = self.conv(x)
+        if y.is_cuda:
+            _note_torch_conv(self.conv)
         if self.plain:
             return y
         if y.is_cuda and y.dtype == torch.float32 and not torch.is_grad_enabled():
@@ -192,6 +208,7 @@ class _StemConvPool(nn.Module):
                 # images up to 896 wide: convolution + bias + ReLU + pooling as ONE kernel, nothing in between touches memory
                 return ops.stem7x7_pool(x, c.w_ohwi(), c.bias)
             y = c.conv(x)
+            _note_torch_conv(c.conv)
             if y.is_contiguous(memory_format=torch.channels_last) and not y.is_contiguous():
                 return ops.bias_relu_maxpool(y, c.bias)
             return self.pool(ops_bias_act(y, c.bias, c.relu))

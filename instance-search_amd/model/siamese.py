@@ -353,17 +353,22 @@ def _apply_head(head, rows):
 def _linear_rows(rows, weight, bias, owner=None):
     """The descriptor head's Linear on GPU rows outside autograd: libisx's split-K GEMM (isx_head_linear_fwd_rows) -- the kernel the training step
     runs, so the per-epoch mining pass, the evaluation and the training forward of the same weights produce the same bits, and a descriptor does
-    not depend on the batch it was computed in.  Shapes the kernel does not cover (K % 32, N % 64) keep torch's GEMM."""
+    not depend on the batch it was computed in.  Shapes off the kernel's granules (N % 64, K % 32) run zero-padded on the SAME kernel
+    (ops.head_linear_any); anything the kernel cannot take at all (not fp32, K beyond the index range) raises IsxError: a GPU tensor never
+    falls to torch's GEMM here (no silent fallback)."""
     from isx import ops
+    from isx._lib import IsxError
     if not rows.is_contiguous():
         rows = rows.contiguous()
-    if ops.head_linear_applicable(rows, weight, any_width=True):
-        padded = None
-        if weight.size(0) % 64 and owner is not None:           # the padded copy lives with the module and follows its parameters (nn_utils._derived)
-            from .nn_utils import _derived
-            padded = _derived(owner, '_c_pad64', (weight,) + ((bias,) if bias is not None else ()), lambda: ops.pad_rows_to_64(weight, bias))
-        return ops.head_linear_any(rows, weight.detach(), bias.detach() if bias is not None else None, padded)
-    return F.linear(rows, weight, bias)
+    if not ops.head_linear_applicable(rows, weight, any_width=True):
+        raise IsxError("Linear on GPU rows %s (%s) x weight %s (%s): outside isx_head_linear_fwd_rows (fp32, contiguous weight, K < 2**22, "
+                       "rows < 2**24); run the module on the CPU (--device=-1) or cast to float32" %
+                       (tuple(rows.shape), rows.dtype, tuple(weight.shape), weight.dtype))
+    padded = None
+    if (weight.size(0) % 64 or weight.size(1) % 32) and owner is not None:   # the padded copy lives with the module and follows its parameters
+        from .nn_utils import _derived
+        padded = _derived(owner, '_c_pad64', (weight,) + ((bias,) if bias is not None else ()), lambda: ops.pad_rows_to_64(weight, bias))
+    return ops.head_linear_any(rows, weight.detach(), bias.detach() if bias is not None else None, padded)
 
 
 class RowsLinear(nn.Linear):

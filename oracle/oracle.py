@@ -31,10 +31,15 @@ def build(force=False):
 
 
 def lib():
+    """ISX_ORACLE_LIB: another build of the same source (tools/sanitize_cpu.sh loads the ASan + UBSan one)."""
     global _lib
     if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+        alt = os.environ.get("ISX_ORACLE_LIB")
+        if alt:
+            _lib = C.CDLL(alt)
+        else:
+            build()
+            _lib = C.CDLL(_SO)
     return _lib
 
 

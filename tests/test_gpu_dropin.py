@@ -221,7 +221,10 @@ def test_bench_size_step_is_batch_independent():
                 ops.gap_l2(net.features(x[i:i + chunk]), out=out[i:i + chunk])
         return out
 
+    from model import nn_utils
+    nn_utils.TORCH_CONV_CALLS.clear()
     full = descriptors(1024)
+    assert nn_utils.TORCH_CONV_CALLS == {}, "a ResNet trunk convolution ran on torch / MIOpen: %r" % (nn_utils.TORCH_CONV_CALLS,)
     assert torch.isfinite(full).all() and float((full.norm(dim=1) - 1).abs().max()) < 1e-5
     for chunk in (64, 256):
         assert torch.equal(descriptors(chunk), full), chunk
@@ -648,6 +651,33 @@ def test_classifier_scores_do_not_depend_on_the_batch():
         assert "_c_pad64" in lin.__dict__ and torch.equal(y0, ops.head_linear_any(r, lin.weight.detach(), lin.bias.detach()))
         lin.weight.mul_(2.0); lin.bias.mul_(2.0)
         assert torch.equal(lin(r), 2.0 * y0)
+
+
+def test_linear_rows_off_the_kernel_granules_stays_on_libisx():
+    """A Linear whose K is not a multiple of 32 (9216 + 4 inputs) or whose N is not a multiple of 64 runs zero-padded on the SAME split-K
+    kernel: batch-invariant, equal to the padded-by-hand call bit for bit, float64-close; a tensor the kernel cannot take at all raises
+    IsxError -- a GPU tensor never drops to torch's GEMM."""
+    from isx import ops
+    from isx._lib import IsxError
+    from model.siamese import RowsLinear, _linear_rows
+    torch.manual_seed(3)
+    for K, N in ((9216 + 4, 10), (9220, 128), (37, 64), (100, 17)):
+        lin = RowsLinear(K, N).cuda()
+        x = torch.randn(21, K, device="cuda")
+        with torch.no_grad():
+            y = lin(x)
+            Kp = (K + 31) // 32 * 32
+            wp, bp = ops.pad_rows_to_64(lin.weight, lin.bias)
+            assert wp.shape == ((N + 63) // 64 * 64, Kp) and "_c_pad64" in lin.__dict__
+            by_hand = ops.head_linear(torch.nn.functional.pad(x, (0, Kp - K)), wp, bp)[:, :N]
+            assert torch.equal(y, by_hand)
+            for bs in (1, 4):
+                assert torch.equal(torch.cat([lin(x[i:i + bs]) for i in range(0, 21, bs)], 0), y), (K, N, bs)
+            ref = torch.nn.functional.linear(x.double(), lin.weight.double(), lin.bias.double())
+        assert y.shape == (21, N) and float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    lin = RowsLinear(64, 64).cuda()
+    with pytest.raises(IsxError):
+        _linear_rows(torch.randn(3, 64, device="cuda").half(), lin.weight.half(), lin.bias.half())
 
 
 def test_evaluation_main_two_ranks_on_a_folder_of_files(tmp_path):
