@@ -264,7 +264,8 @@ def compact_line(full, detail_file=None):
     if isinstance(ro, dict):
         line["roofline"] = _pick(ro, ("family", "kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_unit",
                                       "traffic_over_algorithmic", "traffic_source", "share_of_step", "launches_per_step", "ms_per_step",
-                                      "algorithmic_flop_per_step", "algorithmic_bytes_per_step", "frac_of_per_launch_rooflines", "timing"))
+                                      "algorithmic_flop_per_step", "algorithmic_bytes_per_step", "frac_of_per_launch_rooflines", "timing", "hot_kernels",
+                                      "traffic_profile"))
         if isinstance(line["roofline"].get("traffic_source"), str):
             line["roofline"]["traffic_source"] = line["roofline"]["traffic_source"].split(":")[0]
     else:
@@ -315,7 +316,8 @@ def compact_line(full, detail_file=None):
     if "exchange_ms" in full:
         line["exchange_ms"] = full["exchange_ms"]
         line["exchange"] = _pick(full.get("exchange") or {}, ("query_allgather_ms", "result_allgather_merge_ms", "exposed_when_serialised_frac_of_step",
-                                                              "overlapped", "overlap_identical", "implementation"))
+                                                              "overlapped", "overlap_identical", "implementation", "communicators_in_data_path",
+                                                              "merged_lists_identical_to_unsharded_search"))
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         c = _pick(cb, ("error", "value", "unit", "cores", "kind", "sample", "cpu_model", "top1_matches_oracle_on_sample"))
@@ -349,14 +351,36 @@ def write_detail(full):
         return None
 
 
+def csrc_digest():
+    """sha256 (16 hex digits) over the kernel sources (instance-search_amd/csrc/*.{hip,hpp,cpp}, Makefile, include/isx.h): what a PMC profile is a
+    profile OF.  profiles/summarize_prof.py stamps it into roofline_traffic.json; a bench run whose sources hash differently reports the
+    traffic as null (`traffic_stale`) instead of bytes that belong to other kernels.  (The GPU box has no .git: a content hash, not a commit.)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "instance-search_amd", "csrc")
+    for path in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")) + glob.glob(os.path.join(csrc, "*.cpp"))
+                       + [os.path.join(csrc, "Makefile"), os.path.join(ROOT, "include", "isx.h")]):
+        h.update(os.path.basename(path).encode())
+        h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic():
     """HBM bytes measured with rocprofv3 PMC passes on an EARLIER run of this command (profiles/roofline_traffic.json, written
     by profiles/summarize_prof.py): a property of that profiled run, stamped with its source -- never of the run printing it."""
     path = os.path.join(ROOT, "profiles", "roofline_traffic.json")
     try:
-        return json.load(open(path))
+        t = json.load(open(path))
     except Exception:
         return {}
+    try:
+        t["fresh"] = bool(t.get("csrc_digest")) and t.get("csrc_digest") == csrc_digest()
+    except Exception:
+        t["fresh"] = False
+    if not t["fresh"]:                               # the kernels changed since the counters were read: no bytes rather than stale bytes
+        t = {"source": t.get("source"), "csrc_digest": t.get("csrc_digest"), "fresh": False, "kernels": {}, "regions_leg": {}}
+    return t
 
 
 def main():
@@ -513,6 +537,14 @@ def main():
 
     overlap = world > 1 and not args.no_overlap_exchange
     side = torch.cuda.Stream(device=dev) if world > 1 else None
+    if world > 1 and backend == "nccl":
+        # ONE communicator carries both all-gathers of the step (query rows, then the per-shard lists): libisx's own, opened here -- a collective, so
+        # every rank reaches it together, before any step.  If it cannot be opened on every rank the ranks agree (all-reduce MIN inside
+        # native_comm_for, one line on stderr) and BOTH all-gathers go through torch.distributed's communicator instead: still one communicator
+        # in the data path, and a scaling number rather than none.  ISX_REQUIRE_NATIVE_COMM=1 turns that into a non-zero exit.
+        if retrieval.exchange_backend(None, True).startswith("isx_") and retrieval.native_comm_for(None) is None \
+                and os.environ.get("ISX_REQUIRE_NATIVE_COMM", "0") == "1":
+            raise SystemExit("bench.py: libisx's RCCL communicator could not be opened on every rank (ISX_REQUIRE_NATIVE_COMM=1)")
     exch_ev = []
 
     def exchange(s, i):
@@ -597,6 +629,7 @@ def main():
         dt = float(tmax.item())
     assert out[1].shape == (M, k) and int(out[1].min()) >= 0
     overlap_identical = None
+    merge_identical = None
     if world > 1:
         # both schedules on the same inputs: the deferred exchange must return the bits of the in-line one
         o1 = step(False, False)
@@ -606,6 +639,23 @@ def main():
         flag = torch.tensor([1 if same else 0], device=dev, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         overlap_identical = bool(int(flag.item()) == 1)
+        # the merged lists of the P shards against ONE unsharded search over the whole gallery (every rank's shard gathered; galleries up to 200 k rows:
+        # the rehearsal sizes and the default 10 k rows per GPU at any N <= 8): the canonical order makes them the same bits
+        if Ng * world <= 200000:
+            whole = torch.empty((world * Ng, D), device=dev)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(whole, shard)
+            else:
+                parts = [torch.empty((Ng, D)) for _ in range(world)]
+                dist.all_gather(parts, shard.cpu())
+                whole = torch.cat(parts, 0).to(dev)
+            q_all = retrieval.gather_queries(q_local)
+            us, ui = ops.cosine_topk(q_all, whole, k)
+            same = bool(torch.equal(ui, o1[1]) and torch.equal(us.view(torch.int32), o1[0].view(torch.int32)))
+            flag = torch.tensor([1 if same else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            merge_identical = bool(int(flag.item()) == 1)
+            del whole
 
     # ---- instrumented pass (outside the timed region): per-launch HIP events of the hand-written kernels ----------
     trunk, ksteps = {}, 0
@@ -650,6 +700,8 @@ def main():
         gg = torch.Generator(device=dev).manual_seed(100 + rank)
         Gs = ops.l2norm_rows(torch.randn(Ns, D, device=dev, generator=gg))
 
+        event_ms = {}
+
         def time_search(fast):
             gal = retrieval.ShardedGallery(Gs, idx_base=rank * Ns, fast=fast)
             gal.search(Qs, k)                      # warm-up (fast: builds the cached fp16 image of the shard)
@@ -657,8 +709,11 @@ def main():
             if world > 1:
                 dist.barrier()
             ts0 = time.perf_counter()
+            ea_, eb_ = ev(), ev()
+            ea_.record()
             for _ in range(3):
                 res = gal.search(Qs, k)
+            eb_.record()
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -667,6 +722,7 @@ def main():
                 tm_ = torch.tensor([ms_], device=dev, dtype=torch.float64)
                 dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
                 ms_ = float(tm_.item())
+            event_ms[fast] = ea_.elapsed_time(eb_) / 3      # HIP events on the launch stream around the three searches (this rank)
             return ms_, res
 
         ms32, (rs32, ri32) = time_search(False)      # every score on the fp32 matrix cores
@@ -703,10 +759,10 @@ def main():
                 "tflops_end_to_end": flop / (ms * 1e-3) / 1e12,
                 "frac_of_f16_mfma_peak": flop / (ms * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS * world),
                 "path": "isx_cosine_topk_fast (fp16-MFMA filter + exact fp32 re-scoring, bit-identical results)",
-                "fp32_path": {"ms": ms32, "dist_per_s": Ms * Ns * world / (ms32 * 1e-3),
+                "fp32_path": {"ms": ms32, "event_ms_this_rank": event_ms.get(False), "dist_per_s": Ms * Ns * world / (ms32 * 1e-3),
                               "tflops_end_to_end": flop / (ms32 * 1e-3) / 1e12,
                               "frac_of_f32_mfma_peak": flop / (ms32 * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)},
-                "identical_to_fp32_path": identical,
+                "identical_to_fp32_path": identical, "event_ms_this_rank": event_ms.get(True),
                 "includes": "local top-k" + (" + %s all-gather of per-shard top-k + isx_topk_merge" % ("RCCL" if backend == "nccl" else backend) if world > 1 else "")}
 
     if not args.no_shard_bench:
@@ -1039,6 +1095,29 @@ def main():
         if fam:
             dom = max(fam, key=lambda n: share(fam[n]))
             line["roofline"] = dict(fam[dom], share_of_step=share(fam[dom]) / ms_per_step, family=dom)
+            # north_star's two NAMED kernels, inside the object the driver stores whole: the distance matmul with top-k ranking (the 10 k x 125 k x
+            # 2048 shard of BASELINE configs[4] = one GPU's share of 10 k x 1 M at 8 GPUs, all-fp32 MFMA, end to end incl. the selection kernels; the
+            # exact fp16-filter search of the same shard; the step's own 1024 x 10 k x 2048 GEMM) and the pooling kernel.  HIP events on the launch stream.
+            hot = {}
+            if isinstance(shard_result, dict) and "fp32_path" in shard_result:
+                f32 = shard_result["fp32_path"]
+                ms_e = f32.get("event_ms_this_rank") or f32["ms"]
+                fl = 2.0 * shard_result["shape"][0] * shard_result["gallery_rows_per_gpu"] * shard_result["shape"][2]
+                hot["cosine_topk_fp32"] = {"shape": [shard_result["shape"][0], shard_result["gallery_rows_per_gpu"], shard_result["shape"][2]], "k": k,
+                                           "ms": ms_e, "tflops": fl / (ms_e * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS,
+                                           "frac": fl / (ms_e * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "bound": "mfma",
+                                           "what": "isx_cosine_topk: fp32-MFMA score chunks + selection, end to end; 2*M*N*D FLOP credited"}
+                ms_f = shard_result.get("event_ms_this_rank") or shard_result["ms"]
+                hot["cosine_topk_fast"] = {"ms": ms_f, "identical": shard_result.get("identical_to_fp32_path"),
+                                           "frac_of_f16_peak": fl / (ms_f * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS}
+            if "cosine_gemm" in fam:
+                hot["cosine_gemm_step"] = _pick(fam["cosine_gemm"], ("shape", "launch_ms", "achieved", "frac"))
+            if "gap_l2" in fam:
+                hot["gap_l2"] = {"GB_s": fam["gap_l2"]["achieved"], "frac": fam["gap_l2"]["frac"], "ms": fam["gap_l2"]["launch_ms"],
+                                 "bytes_per_image": gap_bytes / B, "traffic": fam["gap_l2"].get("traffic")}
+            line["roofline"]["hot_kernels"] = hot
+            line["roofline"]["traffic_profile"] = {"csrc_digest_of_profile": traffic.get("csrc_digest"), "csrc_digest_now": csrc_digest(),
+                                                   "fresh": bool(traffic.get("fresh"))}
             for n, o in fam.items():
                 line["roofline_" + n] = o
         else:
@@ -1061,7 +1140,9 @@ def main():
             line["exchange_ms"] = tot
             line["exchange"] = dict(ex, exposed_when_serialised_frac_of_step=(tot / ms_per_step if tot is not None else None),
                                     overlapped=overlap, overlap_identical=overlap_identical,
-                                    implementation=retrieval.exchange_backend(None, True) + " + isx_topk_merge",
+                                    implementation=(("isx_comm_allgather_rows | " if retrieval.exchange_backend(None, True).startswith("isx_") else
+                                                     "torch.distributed all_gather_into_tensor | ") + retrieval.exchange_backend(None, True) + " + isx_topk_merge"),
+                                    communicators_in_data_path=1, merged_lists_identical_to_unsharded_search=merge_identical,
                                     legs="query all-gather | per-shard top-k all-gather x 2 + isx_topk_merge"
                                          + (" (with the score GEMM and the top-k between them on a second stream, behind the next step's trunk)" if overlap else ""),
                                     timing="HIP events on the launch stream, max over ranks, %d instrumented steps with the exchange in line" % ksteps)

@@ -321,6 +321,13 @@ int isx_comm_destroy(void* comm);
 int isx_shard_topk_allgather(void* comm, const float* s_local, const int64_t* i_local, int64_t M, int k, float* s_all,
                              int64_t* i_all, isx_stream_t stream);
 
+/* The OTHER all-gather of the sharded search, on the same communicator: data-parallel extraction leaves every rank with its own
+ * (rows, D) fp32 descriptor rows; the search needs the replicated query block (P * rows, D), rank-major (no reference counterpart: one
+ * device computes test_embeddings whole, test/classif_finetune_test.py:80).  One ncclAllGather on `stream`.  With the query gather and
+ * the result gather on ONE communicator and ONE stream, their order on every rank is program order -- no second communicator whose
+ * kernels could be scheduled in a different order on different ranks.  rows_all: (P * rows, D). */
+int isx_comm_allgather_rows(void* comm, const float* rows_local, int64_t rows, int64_t D, float* rows_all, isx_stream_t stream);
+
 /* ---- siamese triplet training step (next scope row) ------------------------------- */
 
 /* train/siamese_descriptor.py:94-128 (and siamese_regions.py:94-135): for every positive couple

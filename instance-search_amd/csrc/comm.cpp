@@ -112,3 +112,13 @@ ISX_API int isx_shard_topk_allgather(void* comm, const float* s_local, const int
     if (rc != ncclSuccess) return fail(r, "ncclGroupEnd", rc);
     return ISX_OK;
 }
+
+ISX_API int isx_comm_allgather_rows(void* comm, const float* rows_local, int64_t rows, int64_t D, float* rows_all, isx_stream_t stream) {
+    Rccl* r = rccl();
+    if (!r) return ISX_ERR_HIP;
+    if (!comm || rows < 0 || D < 1) { isx_set_error("isx_comm_allgather_rows: bad arguments"); return ISX_ERR_ARG; }
+    if (rows == 0) return ISX_OK;
+    if (!rows_local || !rows_all) { isx_set_error("isx_comm_allgather_rows: null pointer"); return ISX_ERR_ARG; }
+    ncclResult_t rc = r->AllGather(rows_local, rows_all, (size_t)rows * (size_t)D, ncclFloat32, (ncclComm_t)comm, (hipStream_t)stream);
+    return rc == ncclSuccess ? ISX_OK : fail(r, "ncclAllGather(rows)", rc);
+}

@@ -88,6 +88,7 @@ _SIGNATURES = {
     "isx_comm_init_rank": (C.c_int, [C.POINTER(VP), I32, I32, VP]),
     "isx_comm_destroy": (C.c_int, [VP]),
     "isx_shard_topk_allgather": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, VP]),
+    "isx_comm_allgather_rows": (C.c_int, [VP, VP, I64, I64, VP, VP]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))

@@ -760,6 +760,18 @@ def shard_topk_allgather(comm, nranks, s_local, i_local):
     return all_s, all_i
 
 
+def comm_allgather_rows(comm, nranks, rows_local, out=None):
+    """(P * rows, D) descriptor rows of every rank (rank-major) on libisx's communicator, on the current stream."""
+    rows_local = _f32(rows_local, "rows_local")
+    R, D = rows_local.shape
+    if out is None:
+        out = torch.empty((nranks * R, D), device=rows_local.device, dtype=torch.float32)
+    elif tuple(out.shape) != (nranks * R, D) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise _lib.IsxError("comm_allgather_rows: out must be a contiguous fp32 (%d, %d)" % (nranks * R, D))
+    check(lib().isx_comm_allgather_rows(comm, rows_local.data_ptr(), R, D, out.data_ptr(), _stream()), "isx_comm_allgather_rows")
+    return out
+
+
 # ---- training step (SURVEY 8f-1) -----------------------------------------------------------------------
 def mine_negatives(sim, labels, i1, i2, semi_hard, row_base=0):
     """neg index per positive couple (int64, -1 = none available).  sim: the N x N matrix, or rows

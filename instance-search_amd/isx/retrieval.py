@@ -86,6 +86,10 @@ class NativeComm(object):
         from . import ops
         return ops.shard_topk_allgather(self.handle, self.nranks, s, i)
 
+    def allgather_rows(self, rows):
+        from . import ops
+        return ops.comm_allgather_rows(self.handle, self.nranks, rows)
+
     def close(self):
         if self.handle:
             from . import ops
@@ -299,9 +303,16 @@ class ReplicatedGallery(object):
 
 def gather_queries(q_local, group=None):
     """Data-parallel extraction -> replicated query block: all-gather the per-rank descriptor
-    rows (rank order), equal row counts per rank."""
+    rows (rank order), equal row counts per rank.  GPU rows in an RCCL group travel on the SAME libisx communicator and stream as the result
+    exchange of the search that follows (isx_comm_allgather_rows, then isx_shard_topk_allgather): one communicator, program order on every
+    rank.  When the ranks agreed to stay on torch.distributed (native_comm_for -> None), gloo groups and CPU tensors, both all-gathers go
+    through torch.distributed -- again one communicator."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return q_local
+    if q_local.is_cuda and q_local.dtype == torch.float32 and exchange_backend(group).startswith("isx_"):
+        nc = native_comm_for(group)
+        if nc is not None:
+            return nc.allgather_rows(q_local.contiguous())
     P = dist.get_world_size(group)
     out = torch.empty((P * q_local.size(0), q_local.size(1)), dtype=q_local.dtype, device=q_local.device)
     dist.all_gather_into_tensor(out, q_local.contiguous(), group=group)

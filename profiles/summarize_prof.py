@@ -130,7 +130,9 @@ def main():
         src = ("profiles/%s_pmc_hbm.csv: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (kernel trace only) over one steady-state step "
                "of `python bench.py`, bytes = 2 x FETCH_SIZE + WRITE_SIZE, summed over the family's launches in the step; collected %s"
                % (tag, datetime.date.today().isoformat()))
-        json.dump({"source": src, "kernels": out}, open(os.path.join(HERE, "roofline_traffic.json"), "w"), indent=1)
+        sys.path.insert(0, os.path.dirname(HERE))
+        import bench                                  # csrc_digest(): the kernel sources these counters were read from
+        json.dump({"source": src, "csrc_digest": bench.csrc_digest(), "kernels": out}, open(os.path.join(HERE, "roofline_traffic.json"), "w"), indent=1)
     if len(sys.argv) >= 6:
         rows = list(csv.DictReader(open(find(sys.argv[5], "_counter_collection.csv"))))
         one = {}

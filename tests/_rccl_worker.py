@@ -105,6 +105,35 @@ def main():
         res["unsharded_ap"] = ops.average_precision_sim(ops.cosine_sim(Qd, Gd), qlab.to(dev), glab.to(dev), 1).cpu()
     torch.cuda.synchronize()
     nc.close()
+    # ---- the two all-gathers of the N > 1 bench step on ONE communicator: data-parallel query rows -> isx_comm_allgather_rows -> search of the own
+    #      shard -> isx_shard_topk_allgather -> merge, 12 steps alternating between the main stream and a side stream with the trunk's stand-in
+    #      (a large GEMM) running on the other one: every step must return the unsharded list ----
+    per = M // world
+    q_mine = Qd[rank * per:(rank + 1) * per].contiguous()
+    assert R.exchange_backend().startswith("isx_")
+    gal = R.ShardedGallery(Gd[lo:hi], lo, fast=False)
+    side = torch.cuda.Stream(device=dev)
+    busy = torch.randn(2048, 2048, device=dev)
+    pipe = []
+    for step in range(12):
+        stream = side if step % 2 else torch.cuda.current_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            q_all = R.gather_queries(q_mine)
+            s, i = gal.search(q_all, k)
+        other = torch.cuda.current_stream() if step % 2 else side
+        with torch.cuda.stream(other):
+            busy = busy @ busy * 1e-3
+        torch.cuda.current_stream().wait_stream(side)
+        pipe.append((s, i))
+    torch.cuda.synchronize()
+    assert all(torch.equal(i, pipe[0][1]) and torch.equal(s, pipe[0][0]) for s, i in pipe)
+    res["one_comm"] = (pipe[-1][0].cpu(), pipe[-1][1].cpu())
+    res["one_comm_rows"] = per * world
+    os.environ["ISX_NATIVE_COMM"] = "0"                                        # both all-gathers through torch.distributed: again one communicator
+    q_all_t = R.gather_queries(q_mine)
+    del os.environ["ISX_NATIVE_COMM"]
+    assert torch.equal(q_all_t, R.gather_queries(q_mine)) and torch.equal(q_all_t, Qd[:per * world])
     # replicated gallery, queries split by rank
     rs, ri = R.ReplicatedGallery(Gd).search(Qd, k)
     res["replicated"] = (rs.cpu(), ri.cpu())

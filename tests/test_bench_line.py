@@ -78,6 +78,34 @@ def test_compact_line_n2_shape():
     assert back["cpu_baseline"]["retrieval"]["unit"] == "distances/s" and "dropped_for_size" not in back
 
 
+def test_hot_kernels_ride_inside_roofline_and_stale_traffic_is_null():
+    """north_star's named kernels (distance matmul + top-k, pooling) are reported INSIDE `roofline` -- the object the driver stores whole -- and
+    HBM traffic from a PMC profile of OTHER kernel sources is reported as null, not as bytes."""
+    b = _bench()
+    full = json.loads(json.dumps(_full_records()[-1][1]))
+    full["roofline"]["hot_kernels"] = {
+        "cosine_topk_fp32": {"shape": [10000, 125000, 2048], "k": 100, "ms": 36.7, "tflops": 139.5, "peak": 157.3, "frac": 0.887, "bound": "mfma", "what": "w" * 110},
+        "cosine_topk_fast": {"ms": 6.24, "identical": True, "frac_of_f16_peak": 0.33},
+        "cosine_gemm_step": {"shape": [1024, 10000, 2048], "launch_ms": 0.32, "achieved": 131.0, "frac": 0.83},
+        "gap_l2": {"GB_s": 5450.0, "frac": 0.68, "ms": 0.077, "bytes_per_image": 409600.0, "traffic": None}}
+    full["roofline"]["traffic_profile"] = {"csrc_digest_of_profile": "0" * 16, "csrc_digest_now": "1" * 16, "fresh": False}
+    line = b.compact_line(full, "gpurun_out/bench_detail.json")
+    assert len(json.dumps(line)) <= 6144 and "dropped_for_size" not in line
+    hk = line["roofline"]["hot_kernels"]
+    assert hk["cosine_topk_fp32"]["frac"] == pytest.approx(0.887) and hk["cosine_topk_fp32"]["shape"] == [10000, 125000, 2048]
+    assert hk["cosine_topk_fast"]["identical"] is True and hk["gap_l2"]["frac"] == pytest.approx(0.68)
+    assert line["roofline"]["traffic_profile"]["fresh"] is False
+    # the digest is a function of the kernel sources only, and load_traffic() refuses a profile of other sources
+    d = b.csrc_digest()
+    assert len(d) == 16 and d == b.csrc_digest()
+    t = b.load_traffic()
+    prof = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
+    if prof.get("csrc_digest") == d:
+        assert t["fresh"] and t["kernels"]
+    else:
+        assert t["fresh"] is False and t["kernels"] == {} and t["regions_leg"] == {}
+
+
 def test_compact_line_safety_net_drops_optional_objects():
     b = _bench()
     full = json.loads(json.dumps(_full_records()[-1][1]))

@@ -89,11 +89,12 @@ def test_shard_bounds_cover_rows():
     ["test.classif_finetune_test", "--dataset=synthetic:CLICIDE_video_224sq:n=14:q=5:labels=3:size=224:struct=60", "--model=alexnet", "--device=-1", "--classify=False", "--batch=4", "--dba=2"],
     ["test.siamese_descriptor_test", "--dataset=synthetic:CLICIDE_video_224sq:n=11:q=4:labels=3:size=224:struct=60", "--model=alexnet", "--device=-1", "--feature-dim=16", "--batch=4", "--dba=0"],
 ])
-@pytest.mark.parametrize("sharded", ["0", "1"])
-def test_evaluation_mains_under_a_two_rank_launch_print_the_single_process_lines(tmp_path, main_args, sharded):
-    """`python -m torch.distributed.run --nproc-per-node 2 -m test.<approach>_test ...` (gloo, CPU): the ranks split queries and gallery, gather the
+@pytest.mark.parametrize("sharded,world", [("0", 2), ("1", 2), ("1", 8)])
+def test_evaluation_mains_under_a_multi_rank_launch_print_the_single_process_lines(tmp_path, main_args, sharded, world):
+    """`python -m torch.distributed.run --nproc-per-node N -m test.<approach>_test ...` (gloo, CPU): the ranks split queries and gallery, gather the
     descriptor rows, split the metrics by query rows -- rank 0 prints what ONE process prints (same counts; mAP to the printed digits), the other
-    rank prints nothing."""
+    ranks print nothing.  N = 8 (BASELINE configs[4]'s rank count): 4-5 queries and 11-14 gallery rows over eight ranks -- ranks WITHOUT a query,
+    shards of one or two rows."""
     import subprocess
     pkg = os.path.join(ROOT, "instance-search_amd")
     # both runs evaluate ONE network from a weights file: layers without a file are random-initialised, and torch seeds every process differently
@@ -115,8 +116,8 @@ def test_evaluation_mains_under_a_two_rank_launch_print_the_single_process_lines
         main_args = [a if not a.startswith("--dba=") else "--dba=0" for a in main_args]
         one = subprocess.run([sys.executable, "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
         assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
                           str(_free_port()), "-m"] + main_args + ["--sharded=" + ("True" if sharded == "1" else "False")], env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
-    pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
+    from _lines import printed_lines as pick
     assert pick(one.stdout) and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)

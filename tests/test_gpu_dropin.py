@@ -407,11 +407,36 @@ def test_bench_multi_rank_code_path_on_one_gpu():
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["exchange_ms"] > 0 and d["exchange"]["query_allgather_ms"] > 0 and d["exchange"]["result_allgather_merge_ms"] > 0
     assert d["exchange"]["overlapped"] is True and d["exchange"]["overlap_identical"] is True
+    assert d["exchange"]["merged_lists_identical_to_unsharded_search"] is True and d["exchange"]["communicators_in_data_path"] == 1
     # the serialised schedule stays available and prints the same fields
     out2 = subprocess.run(cmd + ["--no-overlap-exchange", "--no-cpu-baseline"], env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert out2.returncode == 0, out2.stderr[-2000:]
     d2 = json.loads([l for l in out2.stdout.splitlines() if l.startswith("{")][-1])
     assert d2["exchange"]["overlapped"] is False and d2["exchange"]["overlap_identical"] is True and "cpu_baseline" not in d2
+
+
+def test_bench_five_ranks_on_one_gpu():
+    """`python bench.py --gpus 5` with five ranks sharing cuda:0 over gloo -- as many ranks as this pool lets one card carry (its process guard
+    allows six GPU processes, and this pytest process is one of them; an 8-rank rehearsal on one GPU is refused by the pool, the 8-way merge
+    itself is covered in-process by test_topk_merge / test_sharded_ap and over gloo on the CPU).  An odd rank count: five query blocks gathered,
+    five shards searched, 5 x (M, 100) lists exchanged and merged -- the merged lists must be the UNSHARDED search's, bit for bit, and the
+    deferred schedule (exchange behind the next step's trunk) must return the bits of the in-line one."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ISX_BENCH_ONE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "5", "--steps", "2", "--warmup", "1", "--batch", "24",
+           "--gallery", "1500", "--no-cpu-baseline", "--no-shard-bench", "--no-regions-bench", "--ingest-images", "0"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 5 and d["config"]["ranks"] == 5 and d["config"]["gallery_rows_per_gpu"] == 1500 and d["value"] > 0
+    ex = d["exchange"]
+    assert ex["overlap_identical"] is True and ex["merged_lists_identical_to_unsharded_search"] is True and ex["communicators_in_data_path"] == 1
 
 
 def test_descriptor_head_golden_on_gpu(golden):
@@ -587,11 +612,13 @@ def test_streaming_ingest_matches_resident_path(monkeypatch):
     ("regions", ["test.classif_regions_test", "--dataset=synthetic:CLICIDE_video_448:n=18:q=7:labels=3:size=288:struct=50", "--model=resnet50", "--device=0", "--dba=0"]),
 ])
 @pytest.mark.parametrize("sharded", ["0", "1"])
-def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(tmp_path, which, main_args, sharded):
-    """SURVEY 8e through the reference's CLI surface: `torch.distributed.run --nproc-per-node 2 -m test.<approach>_test` (both ranks on the box's one
+def test_evaluation_mains_ranks_on_one_gpu_print_the_single_process_lines(tmp_path, which, main_args, sharded):
+    """SURVEY 8e through the reference's CLI surface: `torch.distributed.run --nproc-per-node N -m test.<approach>_test` (all ranks on the box's one
     GPU over gloo: ISX_BENCH_ONE_DEVICE=1; RCCL replaces only the transport) splits queries and gallery over the ranks, gathers the descriptor rows
     and splits the metrics by query rows -- and prints exactly what one process prints from the same weights file: the kernels give an image the same
-    descriptor (class scores included) whatever batch it rides in."""
+    descriptor (class scores included) whatever batch it rides in.  N = 2 and N = 5 in turn (five ranks + this process = the six GPU processes
+    the pool's process guard allows on one card; five does not divide 70, 21, 18 or 7: ragged slices on every rank)."""
+    world = "5" if (which == "finetune") == (sharded == "1") else "2"
     import subprocess
     import socket
     from isx import backbones
@@ -613,11 +640,11 @@ def test_evaluation_mains_two_ranks_on_one_gpu_print_the_single_process_lines(tm
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     one = subprocess.run([sys.executable, "-m"] + main_args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", world, "--master-addr", "127.0.0.1", "--master-port", str(port),
                           "-m"] + main_args, env=dict(env, ISX_EVAL_SHARDED=sharded), cwd=pkg, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
-    pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
-    assert len(pick(one.stdout)) >= 4 and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)
+    from _lines import printed_lines as pick
+    assert len(pick(one.stdout)) >= 4 and pick(two.stdout) == pick(one.stdout), (world, one.stdout, two.stdout)
 
 
 def test_classifier_scores_do_not_depend_on_the_batch():
@@ -717,6 +744,6 @@ def test_evaluation_main_two_ranks_on_a_folder_of_files(tmp_path):
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
                           "-m"] + args, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
-    pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
+    from _lines import printed_lines as pick
     assert len(pick(one.stdout)) >= 4 and pick(two.stdout) == pick(one.stdout), (one.stdout, two.stdout)
     assert "Descriptor (TEST): 15 / 15" in one.stdout                            # structured images: every query finds its instance

@@ -38,7 +38,7 @@ def _env():
 
 @needs2
 def test_rccl_sharded_search_and_grad_allreduce(tmp_path):
-    world = min(_n_gpus(), 4)
+    world = min(_n_gpus(), 8)
     out = str(tmp_path / "r")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rccl_worker.py"), out]
@@ -51,6 +51,9 @@ def test_rccl_sharded_search_and_grad_allreduce(tmp_path):
             s, i = r[k][name]
             assert torch.equal(i, ui), (k, name)                               # ranked lists: bit-exact, every rank, every exchange path
             assert torch.equal(s.view(torch.int32), us.view(torch.int32)), (k, name)
+        s, i = r[k]["one_comm"]                                                  # query gather + result gather on ONE communicator, two streams in turn
+        nq = r[k]["one_comm_rows"]
+        assert torch.equal(i, ui[:nq]) and torch.equal(s.view(torch.int32), us[:nq].view(torch.int32)), k
         for n in r[0]["w0"]:
             assert torch.equal(r[k]["w0"][n], r[0]["w0"][n])                   # broadcast: identical replicas
         assert torch.equal(r[k]["flat"], r[0]["flat"])                         # every rank holds the same summed gradient
@@ -71,9 +74,10 @@ def test_rccl_sharded_search_and_grad_allreduce(tmp_path):
 
 
 @needs2
-def test_bench_two_gpus_bare_command_line():
-    """`python bench.py --gpus 2` with nothing around it: self-launch, RCCL, one JSON line."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "64",
+def test_bench_all_gpus_bare_command_line():
+    """`python bench.py --gpus N` (N = every GPU of the box, at most 8) with nothing around it: self-launch, RCCL, one JSON line."""
+    n = min(_n_gpus(), 8)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--batch", "64",
            "--gallery", "4000", "--no-shard-bench"]
     p = subprocess.run(cmd, env=_env(), cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -81,7 +85,8 @@ def test_bench_two_gpus_bare_command_line():
     assert len(lines) == 2 and lines[0].startswith('{"bench_detail"') and len(lines[1]) <= 6144
     d = json.loads(lines[1])
     assert "isx_shard_topk_allgather" in d["exchange"]["implementation"] and d["exchange"]["overlap_identical"] is True
-    assert d["n_gpus"] == 2 and d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == 2 and d["value"] > 0
+    assert "isx_comm_allgather_rows" in d["exchange"]["implementation"] and d["exchange"]["communicators_in_data_path"] == 1
+    assert d["n_gpus"] == n and d["config"]["collective_backend"] == "nccl" and d["config"]["ranks"] == n and d["value"] > 0
 
 
 def test_shard_head_worker_one_rank(tmp_path):
@@ -106,7 +111,7 @@ def test_evaluation_main_over_rccl_prints_the_single_process_lines(tmp_path, sha
     sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
     from isx import backbones
     from model.siamese import TuneClassif
-    world = min(_n_gpus(), 4)
+    world = min(_n_gpus(), 8)
     torch.manual_seed(3)
     weights = str(tmp_path / "w.pth.tar")
     torch.save(TuneClassif(backbones.resnet50(pretrained=True, seed=0), 5).state_dict(), weights)
@@ -119,5 +124,5 @@ def test_evaluation_main_over_rccl_prints_the_single_process_lines(tmp_path, sha
     many = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port",
                            str(_free_port()), "-m"] + args, env=env, cwd=pkg, capture_output=True, text=True, timeout=900)
     assert many.returncode == 0, many.stderr[-2000:]
-    pick = lambda out: [l for l in out.splitlines() if l.startswith(("Classification", "Descriptor", "Testing", "Loading"))]
+    from _lines import printed_lines as pick
     assert len(pick(one.stdout)) >= 4 and pick(many.stdout) == pick(one.stdout), (one.stdout, many.stdout)

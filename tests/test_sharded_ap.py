@@ -78,6 +78,41 @@ def _two_ranks(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _eight_ranks(rank, world, port, out):
+    """Eight gloo ranks, rank 3 holding an EMPTY shard (N = 7 rows over ranks 0-2 and 4-7): sharded search + exchange + merge, and the sharded
+    average precision, against the unsharded evaluation."""
+    sys.path.insert(0, os.path.join(ROOT, "instance-search_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from isx import retrieval as R
+    from utils import metrics as MT
+    g = torch.Generator().manual_seed(1)
+    N = 203
+    G = torch.nn.functional.normalize(torch.randn(N, 16, generator=g), dim=1)
+    G[150] = G[7]                                            # a tie across shards
+    Q = torch.nn.functional.normalize(torch.randn(11, 16, generator=g), dim=1)
+    glab = torch.randint(0, 6, (N,), generator=g, dtype=torch.int32)
+    qlab = torch.randint(0, 7, (11,), generator=g, dtype=torch.int32)
+    cuts = [0, 40, 41, 90, 90, 120, 160, 161, N]             # rank 3: rows [90, 90)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    ap = MT.sharded_average_precisions(Q, G[lo:hi], lo, qlab, glab[lo:hi])
+    s, i = R.ShardedGallery(G[lo:hi], lo).search(Q, 10)
+    if rank == 0:
+        us, ui = R.local_topk(Q, G, 10, 0)
+        torch.save((ap, MT._average_precisions(Q @ G.t(), qlab, glab, 1), s, i, us, ui), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_gloo_ranks_one_of_them_empty_handed(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = str(tmp_path / "ap8.pt")
+    mp.spawn(_eight_ranks, args=(8, port, out), nprocs=8, join=True)
+    ap, want, s_, i_, us, ui = torch.load(out)
+    assert ap.shape == (11,) and _same(ap, want)
+    assert torch.equal(i_, ui) and torch.allclose(s_, us, rtol=0, atol=1e-6)
+
+
 def test_two_gloo_ranks_compute_the_unsharded_average_precisions(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     out = str(tmp_path / "ap.pt")
@@ -92,6 +127,8 @@ def test_two_gloo_ranks_compute_the_unsharded_average_precisions(tmp_path):
     (14, 97, 6, [(0, 30), (30, 31), (31, 97)]),
     (33, 4096, 40, [(0, 1024), (1024, 4096)]),
     (8, 200000, 2000, [(0, 50000), (50000, 120004), (120004, 200000)]),
+    # eight shards (BASELINE configs[4]'s rank count), one of them EMPTY, one a single row, boundaries off the 16-byte grid
+    (33, 40007, 97, [(0, 5001), (5001, 5001), (5001, 5002), (5002, 15000), (15000, 20003), (20003, 29999), (29999, 35000), (35000, 40007)]),
 ])
 @pytest.mark.parametrize("kth", [1, 2])
 def test_kernels_equal_the_unsharded_kernel_and_the_cpu_restatement(M, N, n_labels, bounds, kth):
