@@ -87,16 +87,33 @@ def parse():
 
 def self_launch(args):
     """`python bench.py --gpus N` from a bare command line: start the N ranks as CHILD processes of a parent that has
-    not touched the GPU (no torch import yet), relay their output and exit with their code."""
+    not touched the GPU (no torch import yet), one `python bench.py ...` per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its
+    environment -- what `torch.distributed.run` would set, without a launcher process in between (the launcher opens the GPU too, and a
+    GPU box of this pool admits six processes per card) -- relay their output and exit with the first non-zero code."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: required for RCCL across processes on this driver
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    env.update(WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)))
+             for r in range(args.gpus)]
+    code = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            rc = p.poll()
+            if rc is None:
+                continue
+            pending.remove(p)
+            if rc != 0 and code == 0:
+                code = rc
+                for q in pending:                      # a rank failed: the others would wait in a collective for ever
+                    q.terminate()
+        if pending:
+            time.sleep(0.05)
+    return code
 
 
 def build_net(name, dtype, device, channels_last=False, fold_bn=False):

@@ -417,8 +417,9 @@ def test_bench_multi_rank_code_path_on_one_gpu():
 
 def test_bench_five_ranks_on_one_gpu():
     """`python bench.py --gpus 5` with five ranks sharing cuda:0 over gloo -- as many ranks as this pool lets one card carry (its process guard
-    allows six GPU processes, and this pytest process is one of them; an 8-rank rehearsal on one GPU is refused by the pool, the 8-way merge
-    itself is covered in-process by test_topk_merge / test_sharded_ap and over gloo on the CPU).  An odd rank count: five query blocks gathered,
+    allows six GPU processes and this pytest process is one of them, which is why bench.py starts its ranks itself, without a launcher process;
+    an 8-rank rehearsal on one GPU is refused by the pool: measured, "7 processes had the GPU open (limit 6)".  The 8-way merge itself is covered
+    in-process by test_topk_merge / test_sharded_ap and with 8 gloo ranks on the CPU).  An odd rank count: five query blocks gathered,
     five shards searched, 5 x (M, 100) lists exchanged and merged -- the merged lists must be the UNSHARDED search's, bit for bit, and the
     deferred schedule (exchange behind the next step's trunk) must return the bits of the in-line one."""
     import json
@@ -616,9 +617,9 @@ def test_evaluation_mains_ranks_on_one_gpu_print_the_single_process_lines(tmp_pa
     """SURVEY 8e through the reference's CLI surface: `torch.distributed.run --nproc-per-node N -m test.<approach>_test` (all ranks on the box's one
     GPU over gloo: ISX_BENCH_ONE_DEVICE=1; RCCL replaces only the transport) splits queries and gallery over the ranks, gathers the descriptor rows
     and splits the metrics by query rows -- and prints exactly what one process prints from the same weights file: the kernels give an image the same
-    descriptor (class scores included) whatever batch it rides in.  N = 2 and N = 5 in turn (five ranks + this process = the six GPU processes
-    the pool's process guard allows on one card; five does not divide 70, 21, 18 or 7: ragged slices on every rank)."""
-    world = "5" if (which == "finetune") == (sharded == "1") else "2"
+    descriptor (class scores included) whatever batch it rides in.  N = 2 and N = 4 in turn (four ranks + their launcher + this process = the six GPU
+    processes the pool's process guard allows on one card; four does not divide 70, 21, 18 or 7: ragged slices on every rank)."""
+    world = "4" if (which == "finetune") == (sharded == "1") else "2"
     import subprocess
     import socket
     from isx import backbones
