@@ -27,7 +27,8 @@ __device__ __forceinline__ void conv3x3_tile(float* __restrict__ lds, const floa
     conv3x3_mainloop<TM, TN, BK, false, 2, CHUNK>(lds, x, M, Wt, N, g, m0, n0, acc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm_u = __builtin_amdgcn_readfirstlane(wave >> 1), wn_u = __builtin_amdgcn_readfirstlane(wave & 1);
-    conv_epilogue_buffers<TM, TN>(acc, C, res, bias, relu, m0, M, n0, N, N, 64 * TM, wm_u * (32 * TM), wn_u * (32 * TN), lane & 31, lane >> 5, mask);
+    // residual / mask look-ahead by register budget: gradient kernels (CHUNK == 0, 116 of 128 VGPRs) one tile at a time, 128x128 inference tiles two
+    conv_epilogue_buffers<TM, TN, (CHUNK == 0 || TM * TN < 4) ? 1 : 2>(acc, C, res, bias, relu, m0, M, n0, N, N, 64 * TM, wm_u * (32 * TM), wn_u * (32 * TN), lane & 31, lane >> 5, mask);
 }
 
 // workgroups per CU: 64x64 tiles 6; 128x64 4 (two-level: 126 VGPRs); 128x128 4 with one accumulator set (gradients), 2 with two (64 + 64 accumulator VGPRs)

@@ -77,6 +77,13 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
         }
     }
 
+    // larger convolution tiles: the residual of the WHOLE tile is requested in one go right behind the main loop, into the registers the first-level
+    // chains leave free, and consumed tile by tile as it arrives -- one round trip instead of TM x TN serialised ones (gemm_tile.hpp, epilogue_fetch).
+    // (Requested one k-tile earlier, under the last MFMAs, the 64 values of a 128x128 tile push the kernel past 256 VGPRs: 204 B of scratch.)
+    constexpr bool LATE_RES = (EPI == 2 && TM * TN == 4 && ISX_EPI_LOADS_FIRST);       // (128x64 tiles at their 128-register bound: 24-112 B of scratch with it)
+    float late_res[LATE_RES ? TM : 1][LATE_RES ? TN : 1][16];
+    const float* res_ptr = (EPI == 2) ? reinterpret_cast<const float*>(gflag) : nullptr;
+
     float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
     const int nk = (D + BK - 1) / BK;
     load_tile<ALIGNED, BM, BK>(Q, M, D, m0, 0, ra);
@@ -120,6 +127,22 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
         }
         if ((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2) add_chunk<TM, TN>(tot, acc);       // the last chunk
     }
+    // the TN bias values of this lane's columns BEFORE everything else of the epilogue: a bias load behind the residual requests would make the first
+    // add wait for all of them, and one between two tiles' stores would wait for those stores (vmcnt counts both on gfx9)
+    float bias_pre[TN];
+    if constexpr (EPI == 2) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ncol = (int)(n0 + wn_u * (32 * TN) + j * 32) + l31;
+            bias_pre[j] = ncol < N ? thr[ncol] : 0.0f;
+        }
+    }
+    if constexpr (LATE_RES) {
+        if (res_ptr) {
+            epilogue_fetch<TM, TN>(late_res, res_ptr, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31, half);
+            __builtin_amdgcn_sched_barrier(0);               // every load above the first store
+        }
+    }
     if constexpr (CHUNK != 0) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -130,7 +153,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
     // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (EPI == 3) {
         // backward.hip: C = (acc (+ add)) . [mask > 0];  thr = mask (M x N, layout of C) or null, gflag = add (float, layout of C) or null
-        conv_epilogue_buffers<TM, TN>(acc, C, reinterpret_cast<const float*>(gflag), nullptr, 0, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31,
+        conv_epilogue_buffers<TM, TN, 1>(acc, C, reinterpret_cast<const float*>(gflag), nullptr, 0, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31,
                                       half, thr);
         return;
     }
@@ -156,10 +179,10 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int ncol = (int)(n0 + wn_u * (32 * TN) + j * 32) + l31;
-                const float bias_v = ncol < N ? thr[ncol] : 0.0f;
+                const float bias_v = bias_pre[j];
                 const unsigned lo = conv_lane_off(ncol, N, wm_u * (32 * TM) + i * 32 + 4 * half, ldc);
                 float rv[16];
-                if (!PRE_RES && res) {
+                if (!PRE_RES && !LATE_RES && res) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
                         rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0));
@@ -168,6 +191,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
                 for (int e = 0; e < 16; ++e) {
                     float y = acc[i][j][e] + bias_v;
                     if (PRE_RES) { if (res) y += pre_res[e]; }
+                    else if (LATE_RES) { if (res) y += late_res[LATE_RES ? i : 0][LATE_RES ? j : 0][e]; }
                     else if (res) y += rv[e];
                     if (ngrp) y = fmaxf(y, 0.0f);
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rc, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0);

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, DUAL ? 2 : 4) void conv3x3_expand_kernel(const
             for (int j = 0; j < NJ; ++j) acc2[i][j] = acc2[i][j] + acc3[i][j];       // tot = (0 + chain_0) + chain_1
     }
     stamp(3);
-    conv_epilogue_buffers<2, NJ>(acc2, y, DUAL ? nullptr : res, b3, relu, m0, M, 0, COUT, COUT, 64, 0, wave_u * (32 * NJ), l31, half);
+    conv_epilogue_buffers<2, NJ, 2>(acc2, y, DUAL ? nullptr : res, b3, relu, m0, M, 0, COUT, COUT, 64, 0, wave_u * (32 * NJ), l31, half);
     if (STAMPS) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(4); }
 }
 
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_expand256_kernel(const float* 
             acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q0, acc2[1][0], 0, 0, 0);
             acc2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q1, acc2[1][1], 0, 0, 0);
         }
-        conv_epilogue_buffers<2, 2>(acc2, y, res, b3, relu, m0, M, 0, COUT, COUT, 256, wave_u * 64, p * 64, l31, half);
+        conv_epilogue_buffers<2, 2, 1>(acc2, y, res, b3, relu, m0, M, 0, COUT, COUT, 256, wave_u * 64, p * 64, l31, half);
     }
 }
 

@@ -137,12 +137,86 @@ __device__ __forceinline__ unsigned conv_lane_off(int64_t ncol, int64_t N, int r
 
 // Convolution epilogue of one wave's TM x TN accumulator tiles through BUFFER instructions: y = act(acc + bias[n] (+ residual)).
 // rc / rr: descriptors of the block tile's rows of C / the residual; row0 = the wave's first tile row (wave-uniform).
+#ifndef ISX_EPI_LOADS_FIRST
+#define ISX_EPI_LOADS_FIRST 1   // A/B (round 6): 1 = every residual / mask value of the wave's TM x TN tiles requested before the first store
+#endif
+// lane offset and SGPR row offsets of the 16 C elements a lane holds of one 32x32 MFMA tile
+__device__ __forceinline__ constexpr int mfma_row_of(int e) { return (e & 3) + 8 * (e >> 2); }
+
+// Residual (or mask) values of ALL of a wave's TM x TN accumulator tiles, requested back to back: ONE round trip to memory for the whole
+// epilogue.  (Round 6: the per-tile form -- 16 loads, s_waitcnt vmcnt(0), 16 stores, next tile -- serialised TM x TN round trips, and on gfx9
+// vmcnt counts stores too, so each wait also drained the previous tile's stores: four load + store latencies per 128x128 tile, as long as the
+// matrix work of a K = 128 tile.)  The caller issues this ahead of its last k-tile's MFMAs where the registers allow.
 template <int TM, int TN>
+__device__ __forceinline__ void epilogue_fetch(float (&rv)[TM][TN][16], const float* __restrict__ src, int64_t m0, int64_t M, int64_t n0, int64_t N, int64_t ldc,
+                                               int BM, int row0, int col0, int l31, int half) {
+    const auto rr = conv_tile_rsrc(src, m0, M, ldc, BM);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int ncol = (int)n0 + col0 + j * 32 + l31;
+            const unsigned lo = conv_lane_off(ncol, N, row0 + i * 32 + 4 * half, ldc);
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                rv[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(mfma_row_of(e) * ldc * 4), 0));
+        }
+}
+
+// Convolution epilogue of one wave's TM x TN accumulator tiles through BUFFER instructions: y = act(acc + bias[n] (+ residual)).
+// rc / rr: descriptors of the block tile's rows of C / the residual; row0 = the wave's first tile row (wave-uniform).
+// AHEAD: how many of the TM x TN tiles have their residual (or mask) values requested before the first of them is stored -- 16 VGPRs each.
+// TM x TN (default): one round trip for the whole epilogue; kernels at their register bound pass fewer (the fused expand kernel at 106 of 128
+// VGPRs: 2; the gradient kernels, which read a mask: 1, and with residual AND mask the per-tile form).  The bias values are always read first: a
+// bias load issued between two tiles' stores waits for those stores (vmcnt counts both on gfx9).
+template <int TM, int TN, int AHEAD = TM * TN>
 __device__ __forceinline__ void conv_epilogue_buffers(const f32x16 (&acc)[TM][TN], float* __restrict__ C, const float* __restrict__ res,
                                                       const float* __restrict__ bias, int relu, int64_t m0, int64_t M, int64_t n0, int64_t N,
                                                       int64_t ldc, int BM, int row0, int col0, int l31, int half, const float* __restrict__ mask = nullptr) {
     // bias == nullptr: no bias;  mask (same layout as C): y = mask > 0 ? y : 0 (backward of the ReLU whose OUTPUT is `mask`, backward.hip)
     const auto rc = conv_tile_rsrc(C, m0, M, ldc, BM);
+    float bias_pre[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ncol = (int)n0 + col0 + j * 32 + l31;
+        bias_pre[j] = (bias && ncol < N) ? bias[ncol] : 0.0f;
+    }
+    if (ISX_EPI_LOADS_FIRST && !(res && mask)) {
+        // one operand stream besides the accumulators (residual OR mask, or none): fetch AHEAD tiles' worth, then add / select / store them
+        constexpr int NT = TM * TN, STEP = AHEAD < 1 ? 1 : (AHEAD > NT ? NT : AHEAD);
+        const float* src = res ? res : mask;
+        const auto rr = conv_tile_rsrc(src ? src : C, m0, M, ldc, BM);
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += STEP) {
+            float rv[STEP][16];
+            if (src) {
+#pragma unroll
+                for (int t = t0; t < t0 + STEP && t < NT; ++t) {
+                    const int i = t / TN, j = t % TN;
+                    const unsigned lo = conv_lane_off((int)n0 + col0 + j * 32 + l31, N, row0 + i * 32 + 4 * half, ldc);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        rv[t - t0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(mfma_row_of(e) * ldc * 4), 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);           // keep the batch's loads above its first store
+            }
+#pragma unroll
+            for (int t = t0; t < t0 + STEP && t < NT; ++t) {
+                const int i = t / TN, j = t % TN;
+                const unsigned lo = conv_lane_off((int)n0 + col0 + j * 32 + l31, N, row0 + i * 32 + 4 * half, ldc);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = src ? rv[t - t0][e] : 0.0f;
+                    float y = acc[i][j][e] + bias_pre[j];
+                    if (res) y += v;
+                    if (relu) y = fmaxf(y, 0.0f);
+                    if (mask) y = v > 0.0f ? y : 0.0f;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rc, lo, (unsigned)(mfma_row_of(e) * ldc * 4), 0);
+                }
+            }
+        }
+        return;
+    }
     const auto rr = conv_tile_rsrc(res ? res : C, m0, M, ldc, BM);
     const auto rm = conv_tile_rsrc(mask ? mask : C, m0, M, ldc, BM);
 #pragma unroll
@@ -150,7 +224,7 @@ __device__ __forceinline__ void conv_epilogue_buffers(const f32x16 (&acc)[TM][TN
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int ncol = (int)n0 + col0 + j * 32 + l31;
-            const float bias_v = (bias && ncol < N) ? bias[ncol] : 0.0f;
+            const float bias_v = bias_pre[j];
             const unsigned lo = conv_lane_off(ncol, N, row0 + i * 32 + 4 * half, ldc);
             float rv[16], mv[16];
             if (res) {
