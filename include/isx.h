@@ -359,6 +359,14 @@ int isx_triplet_loss_bwd_dev(const float* anchor, const float* pos, const float*
                              float scale, const float* scale_dev, int normalized, float* g_anchor, float* g_pos, float* g_neg,
                              isx_stream_t stream);
 
+/* The same loss for ALL micro-batches ("leaves") of an optimizer step in ONE launch (utils/train_general.py:51-61 runs criterion + backward once per
+ * micro-batch: model/custom_modules.py:153-203 each time).  d: (leaves * 3 k, D), leaf by leaf the k anchor rows, the k positive rows, the k
+ * negative rows (the order the reference's batch carries them, train/siamese_descriptor.py:112-128).  loss_leaf[l] = the leaf's row losses added in
+ * row order (before any averaging); dd (same shape as d) = the gradient rows, each row as isx_triplet_loss_bwd forms it with
+ * scale = scale_a * scale_b (1 / k when the loss is averaged, times the weight of the leaf in the mini-batch). */
+int isx_triplet_leaves(const float* d, int leaves, int k, int D, float margin, int normalized, float scale_a, float scale_b, float* loss_leaf,
+                       float* dd, isx_stream_t stream);
+
 /* model/custom_modules.py:59-67 NormalizeL2Fun.backward: with n2 = sum_j x_j^2 + eps and c = sum_j x_j dy_j,
  * dx = (n2 dy - x c) / (n2 sqrt(n2)).  x, dy, dx: (B, D). */
 int isx_l2norm_rows_bwd(const float* x, const float* dy, int64_t B, int64_t D, float eps, float* dx, isx_stream_t stream);

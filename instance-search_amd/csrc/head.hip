@@ -39,6 +39,11 @@ static int head_splits(int64_t K) {
 #ifndef ISX_LB_HEADFWD
 #define ISX_LB_HEADFWD 2
 #endif
+#ifndef ISX_SGD_AHEAD
+#define ISX_SGD_AHEAD 1         // MFMA tiles of the fused gradient + SGD kernel whose w / momentum values are requested before the first store.  MEASURED (round 6,
+                                // tools/head_lab.py, 192 x 100352 x 2048): 1 tile / 3 workgroups per CU 0.954 ms (3.45 TB/s), 2 tiles / 3 WG 0.957, all 4 tiles / 2 WG 0.996 --
+                                // bytes in flight are not what holds the kernel at 3.4 TB/s (torch's fused elementwise SGD moves the same read + write mix at 3.7)
+#endif
 #ifndef ISX_LB_SGD
 #define ISX_LB_SGD 3
 #endif
@@ -214,32 +219,51 @@ __global__ __launch_bounds__(256, ISX_LB_SGD) void head_sgd_kernel(const float* 
         }
     }
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5); one 32-bit lane offset per MFMA tile
-    // into the tile's rows of w / mom (buffer instructions: rows past N and columns past K fall outside the descriptor)
+    // into the tile's rows of w / mom (buffer instructions: rows past N and columns past K fall outside the descriptor).
+    // The kernel is HBM-bound (w and momentum read + written: 3.3 GB per step): what it needs is BYTES IN FLIGHT.  Round 5 read and wrote one MFMA
+    // tile at a time -- 16 + 16 loads, a wait for them AND for the previous tile's stores (one counter on gfx9), 32 stores -- i.e. 8 KB in flight per
+    // wave and four load + store round trips per workgroup.  ISX_SGD_AHEAD tiles (default: all TM x TN) are requested before the first store.
     const float one_minus_damp = 1.0f - sp.dampening;
+    constexpr int NT = TM * TN, STEP = ISX_SGD_AHEAD < 1 ? 1 : (ISX_SGD_AHEAD > NT ? NT : ISX_SGD_AHEAD);
+    const bool need_m = sp.use_momentum && !sp.first;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int t0 = 0; t0 < NT; t0 += STEP) {
+        float wv[STEP][16], mv[STEP][16];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+        for (int t = t0; t < t0 + STEP && t < NT; ++t) {
+            const int i = t / TN, j = t % TN;
             const int64_t col = k0 + wn_u * (32 * TN) + j * 32 + l31;
             const unsigned lo = conv_lane_off(col, K, wm_u * (32 * TM) + i * 32 + 4 * half, K);
-            float wv[16], mv[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) wv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0));
-            if (sp.use_momentum && !sp.first) {
+            for (int e = 0; e < 16; ++e) wv[t - t0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0));
+        }
+        if (need_m) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmom, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0));
+            for (int t = t0; t < t0 + STEP && t < NT; ++t) {
+                const int i = t / TN, j = t % TN;
+                const int64_t col = k0 + wn_u * (32 * TN) + j * 32 + l31;
+                const unsigned lo = conv_lane_off(col, K, wm_u * (32 * TM) + i * 32 + 4 * half, K);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mv[t - t0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmom, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0));
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // the batch's loads above its first store
+#pragma unroll
+        for (int t = t0; t < t0 + STEP && t < NT; ++t) {
+            const int i = t / TN, j = t % TN;
+            const int64_t col = k0 + wn_u * (32 * TN) + j * 32 + l31;
+            const unsigned lo = conv_lane_off(col, K, wm_u * (32 * TM) + i * 32 + 4 * half, K);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 float g = acc[i][j][e];
-                if (sp.weight_decay != 0.0f) g = g + sp.weight_decay * wv[e];
+                if (sp.weight_decay != 0.0f) g = g + sp.weight_decay * wv[t - t0][e];
                 float upd = g;
                 if (sp.use_momentum) {
-                    const float buf = sp.first ? g : sp.momentum * mv[e] + one_minus_damp * g;
+                    const float buf = sp.first ? g : sp.momentum * mv[t - t0][e] + one_minus_damp * g;
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, buf), rmom, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0);
                     upd = sp.nesterov ? g + sp.momentum * buf : buf;
                 }
-                const float nw = wv[e] - sp.lr * upd;
+                const float nw = wv[t - t0][e] - sp.lr * upd;
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nw), rw, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0);
             }
         }

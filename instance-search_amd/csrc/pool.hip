@@ -163,6 +163,12 @@ __global__ __launch_bounds__(kGapThreads) void gap_l2_kernel(const float* __rest
 // 16-B loads (fully coalesced rows of C floats; no LDS needed), so the pooled values have the same
 // summation order as the NCHW kernel and the oracle.
 constexpr int kNhwcThreads = 512;
+#ifndef ISX_GAP_UNROLL
+#define ISX_GAP_UNROLL 7        // positions requested per thread before the first is added (A/B)
+#endif
+#ifndef ISX_GAP_NT
+#define ISX_GAP_NT 0            // A/B: non-temporal loads of the feature map
+#endif
 
 template <int QPT>
 __global__ __launch_bounds__(kNhwcThreads) void gap_l2_nhwc_kernel(const float* __restrict__ fmap, int C, int HW, float eps,
@@ -173,13 +179,19 @@ __global__ __launch_bounds__(kNhwcThreads) void gap_l2_nhwc_kernel(const float* 
     float4 acc[QPT];
 #pragma unroll
     for (int q = 0; q < QPT; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 7
+#pragma unroll ISX_GAP_UNROLL
     for (int p = 0; p < HW; ++p) {
 #pragma unroll
         for (int q = 0; q < QPT; ++q) {
             const int c4 = threadIdx.x + q * kNhwcThreads;
             if (c4 < nq) {
+#if ISX_GAP_NT
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                const f4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(img) + ((int64_t)p * nq + c4));      // read once: do not keep the map in the caches
+                const float4 v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+#else
                 const float4 v = img[(int64_t)p * nq + c4];
+#endif
                 acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w;
             }
         }

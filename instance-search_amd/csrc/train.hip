@@ -78,9 +78,61 @@ __global__ __launch_bounds__(256) void triplet_bwd_kernel(const float* __restric
     }
 }
 
+// The triplet loss of ALL micro-batches ("leaves") of an optimizer step in one launch (round 6): d holds, leaf by leaf, the k anchor rows, the k
+// positive rows and the k negative rows of the leaf (the layout the head engine produces: 3 k rows per leaf).  One workgroup per leaf, one wave per
+// triplet row in turn: the row's loss exactly as triplet_fwd_kernel forms it, its three gradient rows exactly as triplet_bwd_kernel forms them
+// (scale = scale_a * scale_b, the product the per-leaf path forms from 1 / k and autograd's grad_output), and the leaf's loss = the rows' losses
+// added in row order.  Replaces, per leaf: forward launch, torch's sum, backward launch and four copies -- 8 x 36 us of a 11 ms step.
+__global__ __launch_bounds__(256) void triplet_leaves_kernel(const float* __restrict__ d, int k, int D, float margin, int normalized, float scale_a,
+                                                             float scale_b, float* __restrict__ loss_leaf, float* __restrict__ dd) {
+    extern __shared__ float rows[];                                   // k row losses
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * 3 * k;
+    const float scale = scale_a * scale_b;
+    for (int r = wave; r < k; r += 4) {
+        const float *a = d + (base + r) * D, *p = d + (base + k + r) * D, *n = d + (base + 2 * k + r) * D;
+        float s = 0.0f;
+        for (int j = lane; j < D; j += 64) {
+            if (normalized) s += a[j] * n[j] - a[j] * p[j];
+            else { const float dp = a[j] - p[j], dn = a[j] - n[j]; s += dp * dp - dn * dn; }
+        }
+        s = wave_sum(s);
+        float l = normalized ? s + margin : (s + 2.0f * margin) * 0.5f;
+        l = l > 0.0f ? l : 0.0f;
+        if (lane == 0) rows[r] = l;
+        const bool on = l > 0.0f;
+        float *ga = dd + (base + r) * D, *gp = dd + (base + k + r) * D, *gn = dd + (base + 2 * k + r) * D;
+        for (int j = lane; j < D; j += 64) {
+            const float av = a[j], pv = p[j], nv = n[j];
+            float x = nv - pv, y, z;
+            if (normalized) { y = -av; z = av; } else { y = pv - av; z = av - nv; }
+            ga[j] = on ? x * scale : 0.0f;
+            gp[j] = on ? y * scale : 0.0f;
+            gn[j] = on ? z * scale : 0.0f;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int r = 0; r < k; ++r) t += rows[r];
+        loss_leaf[blockIdx.x] = t;
+    }
+}
+
 }  // namespace isx
 
 using namespace isx;
+
+ISX_API int isx_triplet_leaves(const float* d, int leaves, int k, int D, float margin, int normalized, float scale_a, float scale_b,
+                               float* loss_leaf, float* dd, isx_stream_t stream) {
+    ISX_REQUIRE(leaves >= 0 && k > 0 && k <= 8192 && D > 0, "isx_triplet_leaves: bad shape leaves=%d k=%d D=%d (k <= 8192)", leaves, k, D);
+    if (leaves == 0) return ISX_OK;
+    ISX_REQUIRE(d && loss_leaf && dd && dd != d, "isx_triplet_leaves: null pointer or dd aliases d");
+    hipLaunchKernelGGL(triplet_leaves_kernel, dim3((unsigned)leaves), dim3(256), (size_t)k * sizeof(float), (hipStream_t)stream, d, k, D, margin, normalized,
+                       scale_a, scale_b, loss_leaf, dd);
+    ISX_CHECK_LAUNCH("isx_triplet_leaves");
+    return ISX_OK;
+}
 
 ISX_API int isx_mine_negatives(const float* sim, int64_t N, const int32_t* labels, const int64_t* i1, const int64_t* i2,
                                int64_t n_couples, int semi_hard, int64_t* neg, isx_stream_t stream) {

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "isx_ap_shard_positives": (C.c_int, [VP, I64, I64, I64, VP, VP, I32, VP, VP, VP]),
     "isx_ap_shard_hist": (C.c_int, [VP, I64, I64, I64, VP, I32, VP, VP]),
     "isx_ap_from_hist": (C.c_int, [VP, I32, VP, I64, I32, VP, VP]),
+    "isx_triplet_leaves": (C.c_int, [VP, I32, I32, I32, C.c_float, I32, C.c_float, C.c_float, VP, VP, VP]),
     "isx_comm_unique_id_bytes": (C.c_int, []),
     "isx_comm_unique_id": (C.c_int, [VP]),
     "isx_comm_init_rank": (C.c_int, [C.POINTER(VP), I32, I32, VP]),

@@ -819,6 +819,21 @@ def triplet_loss_grads(anchor, pos, neg, loss_rows, scale, normalized=True, scal
     return ga, gp, gn
 
 
+def triplet_leaves(d_all, leaves, margin, normalized=True, scale_a=1.0, scale_b=1.0):
+    """Triplet loss + gradient of every micro-batch of a step in one launch (isx_triplet_leaves).  d_all: (leaves * 3 k, D), per leaf the anchor,
+    positive and negative rows.  Returns (per-leaf sum of the row losses (leaves,), gradient rows like d_all scaled by scale_a * scale_b)."""
+    d_all = _f32(d_all, "d_all")
+    R, D = d_all.shape
+    if leaves <= 0 or R % (3 * leaves):
+        raise _lib.IsxError("triplet_leaves: %d rows do not split into %d leaves of 3 k rows" % (R, leaves))
+    k = R // (3 * leaves)
+    loss = torch.empty((leaves,), device=d_all.device, dtype=torch.float32)
+    dd = torch.empty_like(d_all)
+    check(lib().isx_triplet_leaves(d_all.data_ptr(), leaves, k, D, float(margin), 1 if normalized else 0, float(scale_a), float(scale_b),
+                                   loss.data_ptr(), dd.data_ptr(), _stream()), "isx_triplet_leaves")
+    return loss, dd
+
+
 # ---- half-precision filter path (csrc/fast.hip) ----------------------------------------------------
 def rows_to_f16(x):
     """(h (B,D) float16, norm2 (B) upper bound of the squared row norm, amax (B) max |x|)."""

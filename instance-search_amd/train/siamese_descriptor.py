@@ -133,6 +133,12 @@ def train_siam_triplets_pos_couples(net, train_set, testset_tuple, criterion, op
     def create_loss(out, labels_list):
         return criterion(*out), None
 
+    # the loss IS the triplet criterion on the net's three outputs: the step may evaluate it for all its micro-batches in one launch
+    # (utils/train_general._Stepper._leaves_batched -> isx_triplet_leaves), same values per row
+    from model.custom_modules import TripletLoss
+    if type(criterion) is TripletLoss:
+        create_loss.triplet = criterion
+
     return train_gen(train_type, P, test_print_descriptor, get_embeddings, net, couples, testset_tuple, optimizer, create_epoch,
                      create_batch, create_loss, best_score=best_score)
 

@@ -207,6 +207,26 @@ class _Stepper(object):
             from model.siamese import _SplitRows
             shard = sink.shard_for(head.lin.weight) if sink is not None else None
             d_all, hctx = head.forward(y_all, shard=shard, leaf_ids=list(sink.leaf_ids) if shard is not None else None)
+            trip = getattr(self.make_loss, 'triplet', None)
+            if trip is not None and nb == 3 and d_all.is_cuda and getattr(P, 'train_loss_batched', True):
+                # the training script declared its loss to be THE triplet criterion on (anchor, positive, negative) and nothing else
+                # (`create_loss.triplet = criterion`): all L micro-batches in one launch (isx_triplet_leaves) -- per row the arithmetic of the
+                # criterion's own kernels, the leaf's loss = its rows' losses in row order -- instead of L x (forward, sum, backward, four copies)
+                from isx import ops
+                share = k / float(mini_size)
+                per_leaf, dd = ops.triplet_leaves(d_all, L, trip.margin, trip.normalized, (1.0 / k) if trip.size_average else 1.0,
+                                                  share if P.train_loss_avg else 1.0)
+                if trip.size_average:
+                    per_leaf = per_leaf / k
+                if P.train_loss_avg:
+                    per_leaf = per_leaf * share
+                losses.extend(per_leaf.unbind(0))
+                dy_all = head.backward(hctx, dd, L, sink, flat_all, self.flat.slices)
+                ph.__exit__()
+                if eng is not None:
+                    with _phase("suffix_backward"):
+                        eng.backward(saved, dy_all, leaves=L, leaf_grads=(flat_all, self.flat.slices))
+                return flat_all, losses
             dd = torch.empty_like(d_all)
             for j in range(L):
                 d = d_all[j * rows:(j + 1) * rows].detach().requires_grad_(True)

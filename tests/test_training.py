@@ -367,6 +367,39 @@ def test_mining_and_triplet_kernels(golden):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("L,k,D", [(8, 8, 2048), (3, 5, 100), (1, 1, 64), (2, 13, 2052)])
+def test_triplet_loss_of_all_micro_batches_in_one_launch(L, k, D):
+    """isx_triplet_leaves against the per-micro-batch path it replaces (TripletLoss module: isx_triplet_loss_fwd + torch sum + isx_triplet_loss_bwd_dev
+    per leaf, the weight of the leaf handed over by autograd): gradient rows BIT-identical, per-leaf losses equal to the oracle's rows added in row
+    order, for both loss forms, averaged or not."""
+    from isx import ops
+    from model.custom_modules import TripletLoss
+    rng = np.random.default_rng(L * 100 + k)
+    d = O.l2norm_rows(rng.standard_normal((L * 3 * k, D), dtype=np.float32))
+    d[k:k + max(1, k // 2)] = O.l2norm_rows(d[:max(1, k // 2)] + 0.01 * rng.standard_normal((max(1, k // 2), D), dtype=np.float32))    # easy positives: clamped rows
+    dev = torch.from_numpy(d).cuda()
+    share = k / float(L * k)
+    for normalized in (True, False):
+        for avg in (True, False):
+            loss, dd = ops.triplet_leaves(dev, L, 0.1, normalized, (1.0 / k) if avg else 1.0, share)
+            want_dd = torch.empty_like(dev)
+            for j in range(L):
+                leaf = dev[j * 3 * k:(j + 1) * 3 * k].detach().requires_grad_(True)
+                a, p, n = leaf[:k], leaf[k:2 * k], leaf[2 * k:]
+                obj = TripletLoss(0.1, avg, normalized)(a, p, n) * share
+                obj.backward()
+                want_dd[j * 3 * k:(j + 1) * 3 * k] = leaf.grad
+                _, rows, _, _, _ = O.triplet_loss(d[j * 3 * k:j * 3 * k + k], d[j * 3 * k + k:j * 3 * k + 2 * k], d[j * 3 * k + 2 * k:(j + 1) * 3 * k], 0.1, normalized, avg)
+                got_rows = ops.triplet_loss_rows(a.detach(), p.detach(), n.detach(), 0.1, normalized).cpu().numpy()
+                acc = np.float32(0)
+                for r in got_rows:
+                    acc = np.float32(acc + r)
+                assert float(loss[j]) == float(acc)                              # the kernel's own rows, added in row order
+                np.testing.assert_allclose(float(loss[j]), rows.sum(), rtol=1e-5, atol=1e-6)
+            assert torch.equal(dd, want_dd), (normalized, avg)
+
+
+@pytest.mark.gpu
 def test_training_epoch_on_gpu_reduces_loss():
     from train import siamese_descriptor as sd
     from utils.dataset import synthetic_image_set
