@@ -137,6 +137,9 @@ __device__ __forceinline__ unsigned conv_lane_off(int64_t ncol, int64_t N, int r
 
 // Convolution epilogue of one wave's TM x TN accumulator tiles through BUFFER instructions: y = act(acc + bias[n] (+ residual)).
 // rc / rr: descriptors of the block tile's rows of C / the residual; row0 = the wave's first tile row (wave-uniform).
+#ifndef ISX_RES_NT
+#define ISX_RES_NT 0            // A/B: aux bits of the residual loads of the convolution epilogues (2 = nt: a residual is read once)
+#endif
 #ifndef ISX_EPI_LOADS_FIRST
 #define ISX_EPI_LOADS_FIRST 1   // A/B (round 6): 1 = every residual / mask value of the wave's TM x TN tiles requested before the first store
 #endif
@@ -159,7 +162,7 @@ __device__ __forceinline__ void epilogue_fetch(float (&rv)[TM][TN][16], const fl
             const unsigned lo = conv_lane_off(ncol, N, row0 + i * 32 + 4 * half, ldc);
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-                rv[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(mfma_row_of(e) * ldc * 4), 0));
+                rv[i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(mfma_row_of(e) * ldc * 4), ISX_RES_NT));
         }
 }
 
@@ -196,7 +199,7 @@ __device__ __forceinline__ void conv_epilogue_buffers(const f32x16 (&acc)[TM][TN
                     const unsigned lo = conv_lane_off((int)n0 + col0 + j * 32 + l31, N, row0 + i * 32 + 4 * half, ldc);
 #pragma unroll
                     for (int e = 0; e < 16; ++e)
-                        rv[t - t0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(mfma_row_of(e) * ldc * 4), 0));
+                        rv[t - t0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr, lo, (unsigned)(mfma_row_of(e) * ldc * 4), ISX_RES_NT));
                 }
                 __builtin_amdgcn_sched_barrier(0);           // keep the batch's loads above its first store
             }

@@ -44,6 +44,9 @@ static int head_splits(int64_t K) {
                                 // tools/head_lab.py, 192 x 100352 x 2048): 1 tile / 3 workgroups per CU 0.954 ms (3.45 TB/s), 2 tiles / 3 WG 0.957, all 4 tiles / 2 WG 0.996 --
                                 // bytes in flight are not what holds the kernel at 3.4 TB/s (torch's fused elementwise SGD moves the same read + write mix at 3.7)
 #endif
+#ifndef ISX_SGD_NT
+#define ISX_SGD_NT 2            // (0.957 -> 0.932 ms, round 6; A/B: 0) aux bits of the w / momentum loads and stores of the fused SGD epilogue (2 = nt: read once, written once per step)
+#endif
 #ifndef ISX_LB_SGD
 #define ISX_LB_SGD 3
 #endif
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256, ISX_LB_SGD) void head_sgd_kernel(const float* 
             const int64_t col = k0 + wn_u * (32 * TN) + j * 32 + l31;
             const unsigned lo = conv_lane_off(col, K, wm_u * (32 * TM) + i * 32 + 4 * half, K);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) wv[t - t0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0));
+            for (int e = 0; e < 16; ++e) wv[t - t0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), ISX_SGD_NT));
         }
         if (need_m) {
 #pragma unroll
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256, ISX_LB_SGD) void head_sgd_kernel(const float* 
                 const int64_t col = k0 + wn_u * (32 * TN) + j * 32 + l31;
                 const unsigned lo = conv_lane_off(col, K, wm_u * (32 * TM) + i * 32 + 4 * half, K);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) mv[t - t0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmom, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0));
+                for (int e = 0; e < 16; ++e) mv[t - t0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rmom, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), ISX_SGD_NT));
             }
         }
         __builtin_amdgcn_sched_barrier(0);                   // the batch's loads above its first store
@@ -260,11 +263,11 @@ __global__ __launch_bounds__(256, ISX_LB_SGD) void head_sgd_kernel(const float* 
                 float upd = g;
                 if (sp.use_momentum) {
                     const float buf = sp.first ? g : sp.momentum * mv[t - t0][e] + one_minus_damp * g;
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, buf), rmom, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, buf), rmom, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), ISX_SGD_NT);
                     upd = sp.nesterov ? g + sp.momentum * buf : buf;
                 }
                 const float nw = wv[t - t0][e] - sp.lr * upd;
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nw), rw, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, nw), rw, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * K * 4), ISX_SGD_NT);
             }
         }
     }

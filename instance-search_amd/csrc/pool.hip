@@ -166,11 +166,15 @@ constexpr int kNhwcThreads = 512;
 #ifndef ISX_GAP_UNROLL
 #define ISX_GAP_UNROLL 7        // positions requested per thread before the first is added (A/B)
 #endif
-#ifndef ISX_GAP_NT
-#define ISX_GAP_NT 0            // A/B: non-temporal loads of the feature map
+#ifndef ISX_GAP_NT_BYTES
+#define ISX_GAP_NT_BYTES (192ll << 20)     // maps above this size are read with NON-TEMPORAL loads (isx_gap_l2_nhwc); A/B: 0 = always, a huge value = never
 #endif
 
-template <int QPT>
+// NT: the map is read with non-temporal loads.  A map that cannot stay in the 256 MB Infinity Cache anyway (the bench step's 1024 x 2048 x 7 x 7 is
+// 401 MB) streams through faster when its lines are not allocated on the way: 73.8 -> 62.8 us back to back = 5.7 -> 6.7 TB/s (0.71 -> 0.83 of 8 TB/s), and
+// 110 -> 63 us when other data went through the caches in between, as in the step; a map that fits (256 images, 100 MB) and is re-read hot loses
+// (17.9 -> 26.4 us), hence the size switch in the launcher (tools/gap_lab.py; round 6).  Same arithmetic, same order.
+template <int QPT, bool NT>
 __global__ __launch_bounds__(kNhwcThreads) void gap_l2_nhwc_kernel(const float* __restrict__ fmap, int C, int HW, float eps,
                                                                    float* __restrict__ y) {
     __shared__ float red[kNhwcThreads / 64];
@@ -185,13 +189,14 @@ __global__ __launch_bounds__(kNhwcThreads) void gap_l2_nhwc_kernel(const float* 
         for (int q = 0; q < QPT; ++q) {
             const int c4 = threadIdx.x + q * kNhwcThreads;
             if (c4 < nq) {
-#if ISX_GAP_NT
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                const f4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(img) + ((int64_t)p * nq + c4));      // read once: do not keep the map in the caches
-                const float4 v = make_float4(t4[0], t4[1], t4[2], t4[3]);
-#else
-                const float4 v = img[(int64_t)p * nq + c4];
-#endif
+                float4 v;
+                if constexpr (NT) {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    const f4v t4 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(img) + ((int64_t)p * nq + c4));
+                    v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                } else {
+                    v = img[(int64_t)p * nq + c4];
+                }
                 acc[q].x += v.x; acc[q].y += v.y; acc[q].z += v.z; acc[q].w += v.w;
             }
         }
@@ -414,9 +419,18 @@ ISX_API int isx_gap_l2_nhwc(const float* fmap, int64_t B, int C, int H, int W, f
         return launch_l2norm(y, nullptr, B, C, eps, y, st);
     }
     const int nq = C / 4;
-    if (nq <= kNhwcThreads) hipLaunchKernelGGL(gap_l2_nhwc_kernel<1>, dim3((unsigned)B), dim3(kNhwcThreads), 0, st, fmap, C, HW, eps, y);
-    else if (nq <= 2 * kNhwcThreads) hipLaunchKernelGGL(gap_l2_nhwc_kernel<2>, dim3((unsigned)B), dim3(kNhwcThreads), 0, st, fmap, C, HW, eps, y);
-    else hipLaunchKernelGGL(gap_l2_nhwc_kernel<4>, dim3((unsigned)B), dim3(kNhwcThreads), 0, st, fmap, C, HW, eps, y);
+    const bool nt = (int64_t)B * C * HW * 4 > (int64_t)ISX_GAP_NT_BYTES;
+    const dim3 grid((unsigned)B), block(kNhwcThreads);
+    if (nq <= kNhwcThreads) {
+        if (nt) hipLaunchKernelGGL((gap_l2_nhwc_kernel<1, true>), grid, block, 0, st, fmap, C, HW, eps, y);
+        else hipLaunchKernelGGL((gap_l2_nhwc_kernel<1, false>), grid, block, 0, st, fmap, C, HW, eps, y);
+    } else if (nq <= 2 * kNhwcThreads) {
+        if (nt) hipLaunchKernelGGL((gap_l2_nhwc_kernel<2, true>), grid, block, 0, st, fmap, C, HW, eps, y);
+        else hipLaunchKernelGGL((gap_l2_nhwc_kernel<2, false>), grid, block, 0, st, fmap, C, HW, eps, y);
+    } else {
+        if (nt) hipLaunchKernelGGL((gap_l2_nhwc_kernel<4, true>), grid, block, 0, st, fmap, C, HW, eps, y);
+        else hipLaunchKernelGGL((gap_l2_nhwc_kernel<4, false>), grid, block, 0, st, fmap, C, HW, eps, y);
+    }
     ISX_CHECK_LAUNCH("isx_gap_l2_nhwc");
     return ISX_OK;
 }
