@@ -2,7 +2,7 @@
 # The rocprofv3 passes behind profiles/<tag>_* (run on the GPU box: gpurun -- bash tools/profile_round.sh r03).  Counter passes are runs of their
 # own with --kernel-trace only (gpurun refuses --pmc combined with the sys / hip / hsa trace domains).
 set -e
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 REPO=$(pwd)
 mkdir -p $OUT
@@ -38,6 +38,9 @@ with open("$OUT/summaries/${TAG}_regions_kernel_stats.csv", "w") as o:
 PY
 # siamese training on the reference's configuration (layer4 trained): which kernels run in the step (tools/bench_train.py)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- python3 tools/bench_train.py --configs reference --epochs 3 > $OUT/train.log 2>&1
+mkdir -p $OUT/summaries
+TRACE=$(ls $OUT/train/*/*kernel_trace.csv $OUT/train/*kernel_trace.csv 2>/dev/null | head -1)
+[ -n "$TRACE" ] && python3 tools/train_step_trace.py $TRACE $OUT/summaries/${TAG}_train_step_launches.csv || true      # one steady step's launches, in order
 rm -f $OUT/train/*/*kernel_trace.csv $OUT/train/*kernel_trace.csv
 python3 - <<PY
 import csv, glob
