@@ -58,6 +58,10 @@ def test_argument_validation_without_gpu():
     assert lib.isx_head_linear_dgrad(None, 64, 2048, None, 100, None, None) == -1 and b"K % 64" in lib.isx_last_error()
     assert lib.isx_colsum_leaves(None, 0, 24, 2048, None, None) == 0 and lib.isx_l2norm_rows_bwd(None, None, 0, 16, 1e-10, None, None) == 0
     assert lib.isx_tree_sum_rows(None, 17, 8, 8, None, None) == -1 and b"1 <= L <= 16" in lib.isx_last_error() and lib.isx_tree_sum_rows(None, 4, 8, 0, None, None) == 0
+    # round-6 entries: the step's triplet loss in one launch
+    assert lib.isx_triplet_leaves(None, 2, 0, 64, 0.1, 1, 1.0, 1.0, None, None, None) == -1 and b"bad shape" in lib.isx_last_error()
+    assert lib.isx_triplet_leaves(None, 2, 8, 64, 0.1, 1, 1.0, 1.0, None, None, None) == -1 and b"null pointer" in lib.isx_last_error()
+    assert lib.isx_triplet_leaves(None, 0, 8, 64, 0.1, 1, 1.0, 1.0, None, None, None) == 0
     # empty problems are no-ops
     assert lib.isx_l2norm_rows(None, 0, 16, 1e-10, None, None) == 0
     assert lib.isx_cosine_sim(None, 0, None, 0, 8, None, None) == 0
