@@ -29,6 +29,18 @@
 
 namespace isx {
 
+#ifndef ISX_STAMPS
+#define ISX_STAMPS 0            // lab builds only (tools/build_variant.sh stamps -DISX_STAMPS=1, tools/conv_phase_lab.py): wave 0 of every workgroup of the
+#endif                          // convolution GEMM records the shader clock at its phase boundaries into the buffer set by isx_debug_set_stamps
+#if ISX_STAMPS
+__device__ unsigned long long* g_stamps = nullptr;
+#define ISX_STAMP(i) do { if (g_stamps && threadIdx.x == 0) g_stamps[(int64_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define ISX_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define ISX_STAMP(i) do { } while (0)
+#define ISX_STAMP_DRAIN() do { } while (0)
+#endif
+
 // Block tile (64*TM) x (64*TN): 4 waves as 2x2, each wave TM x TN MFMA tiles of 32x32.
 // EPI: 0 = store scores, 1 = top-k filter (thr, gflag, ngrp), 2 = 1x1-convolution epilogue: thr = bias[n],
 // gflag = residual (float, same layout as C) or null, ngrp = relu flag
@@ -80,17 +92,19 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
     // larger convolution tiles: the residual of the WHOLE tile is requested in one go right behind the main loop, into the registers the first-level
     // chains leave free, and consumed tile by tile as it arrives -- one round trip instead of TM x TN serialised ones (gemm_tile.hpp, epilogue_fetch).
     // (Requested one k-tile earlier, under the last MFMAs, the 64 values of a 128x128 tile push the kernel past 256 VGPRs: 204 B of scratch.)
-    constexpr bool LATE_RES = (EPI == 2 && TM * TN == 4 && ISX_EPI_LOADS_FIRST);       // (128x64 tiles at their 128-register bound: 24-112 B of scratch with it)
+    constexpr bool LATE_RES = (EPI == 2 && TM * TN == 4 && ISX_EPI_LOADS_FIRST && !ISX_EPI_LDS);       // (128x64 tiles at their 128-register bound: 24-112 B of scratch with it)
     float late_res[LATE_RES ? TM : 1][LATE_RES ? TN : 1][16];
     const float* res_ptr = (EPI == 2) ? reinterpret_cast<const float*>(gflag) : nullptr;
 
     float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
     const int nk = (D + BK - 1) / BK;
+    if (EPI == 2) ISX_STAMP(0);
     load_tile<ALIGNED, BM, BK>(Q, M, D, m0, 0, ra);
     load_tile<ALIGNED, BN, BK>(G, N, D, n0, 0, rb);
     store_tile<BM, BK>(As, ra);
     store_tile<BN, BK>(Bs, rb);
     __syncthreads();
+    if (EPI == 2) ISX_STAMP(1);
 
     const float* a_base = As + half * LDA + wm * (32 * TM) + l31;
     const float* b_base = Bs + half * LDB + wn * (32 * TN) + l31;
@@ -127,6 +141,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
         }
         if ((PINNED && ISX_FOLD_INTERLEAVE) || ISX_FOLD_INTERLEAVE >= 2) add_chunk<TM, TN>(tot, acc);       // the last chunk
     }
+    if (EPI == 2) ISX_STAMP(2);
     // the TN bias values of this lane's columns BEFORE everything else of the epilogue: a bias load behind the residual requests would make the first
     // add wait for all of them, and one between two tiles' stores would wait for those stores (vmcnt counts both on gfx9)
     float bias_pre[TN];
@@ -141,6 +156,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
         if (res_ptr) {
             epilogue_fetch<TM, TN>(late_res, res_ptr, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31, half);
             __builtin_amdgcn_sched_barrier(0);               // every load above the first store
+            if (ISX_STAMPS) { ISX_STAMP_DRAIN(); ISX_STAMP(3); }
         }
     }
     if constexpr (CHUNK != 0) {
@@ -163,6 +179,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
         if ((N & 3) == 0 && (ldc & 3) == 0 && (((uintptr_t)C | (uintptr_t)(res ? res : C) | (uintptr_t)thr) & 15) == 0) {        // uniform
             conv_epilogue_lds<TM, TN>(acc, lds + (threadIdx.x >> 6) * (32 * TM) * (32 * TN + 4), C, res, thr, ngrp, m0, M, n0, N, ldc, BM, wm_u * (32 * TM),
                                       wn_u * (32 * TN), lane);
+            if (ISX_STAMPS) { ISX_STAMP(3); ISX_STAMP(4); ISX_STAMP_DRAIN(); ISX_STAMP(5); }      // (the LDS epilogue's residual wait is inside it: stamp 3 = 4)
             return;
         }
     }
@@ -198,6 +215,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
                 }
             }
         }
+        if (ISX_STAMPS) { ISX_STAMP(4); ISX_STAMP_DRAIN(); ISX_STAMP(5); }
         return;
     }
     if (EPI == 0 && (int64_t)BM * ldc * 4 < (1ll << 32)) {
@@ -684,3 +702,10 @@ ISX_API int isx_cosine_topk(const float* Q, int64_t M, const float* G, int64_t N
     j.ws = ws; j.ws_bytes = ws_bytes; j.st = st;
     return run_topk_chunks(j);
 }
+
+#if ISX_STAMPS
+// lab builds only: where the convolution GEMM's workgroups record their phase stamps (8 x u64 per workgroup); nullptr = off
+extern "C" __attribute__((visibility("default"))) int isx_debug_set_stamps(unsigned long long* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(isx::g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#endif
