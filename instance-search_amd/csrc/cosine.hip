@@ -29,6 +29,12 @@
 
 namespace isx {
 
+#ifndef ISX_A_NT
+#define ISX_A_NT 0              // A/B (round 6): aux bits of the ACTIVATION operand loads of the convolution GEMM (2 = nt)
+#endif
+#ifndef ISX_ST_NT
+#define ISX_ST_NT 0             // A/B (round 6): aux bits of the convolution GEMM's output stores (2 = nt)
+#endif
 #ifndef ISX_STAMPS
 #define ISX_STAMPS 0            // lab builds only (tools/build_variant.sh stamps -DISX_STAMPS=1, tools/conv_phase_lab.py): wave 0 of every workgroup of the
 #endif                          // convolution GEMM records the shader clock at its phase boundaries into the buffer set by isx_debug_set_stamps
@@ -99,7 +105,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
     float4 ra[BM * BK / 1024], rb[BN * BK / 1024];
     const int nk = (D + BK - 1) / BK;
     if (EPI == 2) ISX_STAMP(0);
-    load_tile<ALIGNED, BM, BK>(Q, M, D, m0, 0, ra);
+    load_tile<ALIGNED, BM, BK, (EPI == 2 ? ISX_A_NT : 0)>(Q, M, D, m0, 0, ra);
     load_tile<ALIGNED, BN, BK>(G, N, D, n0, 0, rb);
     store_tile<BM, BK>(As, ra);
     store_tile<BN, BK>(Bs, rb);
@@ -119,7 +125,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
     auto body = [&](int kt, auto zero_c) {
         const bool more = (kt + 1 < nk);
         if (more) {
-            load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
+            load_tile<ALIGNED, BM, BK, (EPI == 2 ? ISX_A_NT : 0)>(Q, M, D, m0, (kt + 1) * BK, ra);
             load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
         }
         mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc, totp);
@@ -211,7 +217,7 @@ __device__ __forceinline__ void cosine_gemm_tile(float* __restrict__ lds, const 
                     else if (LATE_RES) { if (res) y += late_res[LATE_RES ? i : 0][LATE_RES ? j : 0][e]; }
                     else if (res) y += rv[e];
                     if (ngrp) y = fmaxf(y, 0.0f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rc, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, y), rc, lo, (unsigned)(((e & 3) + 8 * (e >> 2)) * ldc * 4), ISX_ST_NT);
                 }
             }
         }
@@ -322,9 +328,13 @@ template <bool ALIGNED>
 __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_persist_kernel(const float* __restrict__ Q, int64_t M, const float* __restrict__ G, int64_t N, int D,
                                                                                 float* __restrict__ C, int64_t ldc, TileMap tm, int ntiles, TileMap tm_small,
                                                                                 int64_t m_split, const float* __restrict__ bias, const float* __restrict__ res,
-                                                                                int relu) {
+                                                                                int relu, int* __restrict__ tickets) {
+    // tickets != nullptr (ISX_CONV_PERSIST=2, round 6): the next tile is DRAWN, not strided -- one counter per XCD (8 ints, zeroed by the launcher), a
+    // workgroup on XCD x = blockIdx & 7 takes the next undone tile of x's own contiguous range, so that the dispatcher's dynamic balance is kept and the
+    // tiles of an XCD still share their operands in its L2.  The ticket is drawn at the top of a tile and has landed by its epilogue.
     constexpr int TM = 2, TN = 2, BK = 16, BM = 128, BN = 128, LDA = BM + lds_pad(BK), LDB = BN + lds_pad(BK), CHUNK = kConvChunk;
     __shared__ float lds[BK * (LDA + LDB)];
+    __shared__ int s_next;
     float* As = lds;
     float* Bs = lds + BK * LDA;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -345,11 +355,13 @@ __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_persist_kernel
         load_tile<ALIGNED, BM, BK>(Q, M, D, (int64_t)tile_m * BM, 0, ra);
         load_tile<ALIGNED, BN, BK>(G, N, D, (int64_t)tile_n * BN, 0, rb);
     }
-    for (; t < ntiles; t += (int)gridDim.x) {
+    while (t < ntiles) {
         const int64_t m0 = (int64_t)tile_m * BM, n0 = (int64_t)tile_n * BN;
         f32x16 acc[TM][TN], tot[CHUNK ? TM : 1][CHUNK ? TN : 1];
         zero_tiles(acc);
         zero_tiles(tot);
+        int drawn = 0;                                                       // thread 0: requested now, consumed in the last k-tile (the atomic's round trip hides behind the main loop)
+        if (tickets && threadIdx.x == 0) drawn = atomicAdd(tickets + ((int)blockIdx.x & 7), 1);
         store_tile<BM, BK>(As, ra);
         store_tile<BN, BK>(Bs, rb);
         __syncthreads();
@@ -361,6 +373,7 @@ __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_persist_kernel
                 load_tile<ALIGNED, BM, BK>(Q, M, D, m0, (kt + 1) * BK, ra);
                 load_tile<ALIGNED, BN, BK>(G, N, D, n0, (kt + 1) * BK, rb);
             }
+            if (!more && tickets && threadIdx.x == 0) s_next = ((int)blockIdx.x & 7) + 8 * ((int)(gridDim.x >> 3) + drawn);       // published by the barrier below
             mfma_ktile_sel<TM, TN, BK, LDA, LDB, PINNED, decltype(zero_c)::value>(a_base, b_base, pins, acc, totp);
             __syncthreads();
             if (more) {
@@ -385,13 +398,15 @@ __global__ __launch_bounds__(256, ISX_WG_PER_CU_128) void conv1x1_persist_kernel
                 for (int j = 0; j < TN; ++j) acc[i][j] = tot[i][j];
         }
         // the next tile's first operands: on their way while this tile's epilogue runs (every wave has left the LDS: the loop ended on a barrier)
-        const int tn = t + (int)gridDim.x;
+        int tn = t + (int)gridDim.x;
+        if (tickets) tn = __builtin_amdgcn_readfirstlane(s_next);
         if (tn < ntiles) {
             tile_of_block(tm, tile_m, tile_n, tn, ntiles);
             load_tile<ALIGNED, BM, BK>(Q, M, D, (int64_t)tile_m * BM, 0, ra);
             load_tile<ALIGNED, BN, BK>(G, N, D, (int64_t)tile_n * BN, 0, rb);
         }
         conv_epilogue_buffers<TM, TN>(acc, C, res, bias, relu, m0, M, n0, N, ldc, BM, wm_u * (32 * TM), wn_u * (32 * TN), l31, half);
+        t = tn;
     }
     // rows past the last whole round of 128x128 tiles: 64x64 tiles (conv1x1_tail_kernel's scheme), spread over the same workgroups
     const int nsmall = tm_small.tiles_m * tm_small.tiles_n;
@@ -509,7 +524,8 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
     // A/B (round 5), OFF by default: persistent workgroups with the next tile's first operands prefetched across the epilogue are
     // 4 % SLOWER on the ten 1x1 shapes of the lab (11.37 vs 10.90 ms; 128 -> 512 + residual 1.10 vs 1.07): the hardware dispatcher's dynamic
     // placement of one workgroup per tile beats the static walk, and the pipeline fill of a tile is not what the short-K layers wait for.
-    static const bool use_persist = [] { const char* e = getenv("ISX_CONV_PERSIST"); return e && e[0] == '1'; }();
+    static const int persist_mode = [] { const char* e = getenv("ISX_CONV_PERSIST"); return e ? atoi(e) : 0; }();      // 1 = strided tiles (round 5), 2 = drawn tiles (round 6)
+    static const bool use_persist = persist_mode == 1 || persist_mode == 2;
     if (epi == 2 && best == 0 && use_persist && (g_force_cfg < 0 || g_force_cfg == 0)) {
         TileMap tmap, small;
         tmap.m_active = small.m_active = nullptr;
@@ -519,8 +535,14 @@ static int launch_gemm_any(const float* Q, int64_t M, const float* G, int64_t N,
         const int slots = 256 * ISX_WG_PER_CU_128;
         const int want = ntiles + small.tiles_m * small.tiles_n;
         const dim3 grid((unsigned)(want < slots ? want : slots)), block(256);
-        if (aligned) hipLaunchKernelGGL((conv1x1_persist_kernel<true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tmap, ntiles, small, split, thr, (const float*)gmax, relu);
-        else hipLaunchKernelGGL((conv1x1_persist_kernel<false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tmap, ntiles, small, split, thr, (const float*)gmax, relu);
+        int* tickets = nullptr;
+        if (persist_mode == 2 && grid.x % 8 == 0) {                           // A/B only: the counters live in a lazily allocated device buffer, zeroed per launch
+            static int* g_tickets = nullptr;
+            if (!g_tickets && hipMalloc((void**)&g_tickets, 64) != hipSuccess) g_tickets = nullptr;
+            if (g_tickets && hipMemsetAsync(g_tickets, 0, 64, st) == hipSuccess) tickets = g_tickets;
+        }
+        if (aligned) hipLaunchKernelGGL((conv1x1_persist_kernel<true>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tmap, ntiles, small, split, thr, (const float*)gmax, relu, tickets);
+        else hipLaunchKernelGGL((conv1x1_persist_kernel<false>), grid, block, 0, st, Q, M, G, N, D, C, ldc, tmap, ntiles, small, split, thr, (const float*)gmax, relu, tickets);
         ISX_CHECK_LAUNCH("conv1x1_persist");
         return ISX_OK;
     }

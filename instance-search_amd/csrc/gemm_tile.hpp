@@ -56,7 +56,8 @@ __device__ __forceinline__ auto uniform_rsrc(const void* base, int64_t nbytes) {
 
 // ROWS x BK k = ROWS*CH float4; thread t takes idx = j*256 + t: row = idx/CH, chunk = idx%CH.
 // ALIGNED: 16-B aligned rows AND D a multiple of BK (unconditional 16-B loads); otherwise scalar loads with a zero-filled k tail.
-template <bool ALIGNED, int ROWS, int BK>
+// AUX: cache-policy bits of the buffer loads of the ALIGNED path (0 = default, 2 = nt: a stream that no later access of this CU re-reads)
+template <bool ALIGNED, int ROWS, int BK, int AUX = 0>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t rows, int D, int64_t row0, int k0,
                                           float4 (&reg)[ROWS * BK / 1024]) {
     constexpr int CH = BK / 4;               // 16-B chunks per staged row
@@ -70,7 +71,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int64_t r
         for (int j = 0; j < ROWS * CH / 256; ++j) {
             const int idx = j * 256 + threadIdx.x;
             const unsigned vo = (unsigned)(idx / CH) * (unsigned)D * 4u + (unsigned)((idx % CH) << 4);
-            reg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)k0 * 4u, 0));
+            reg[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)k0 * 4u, AUX));
         }
         return;
     }
