@@ -70,6 +70,19 @@ def main():
     res = {}
     if os.environ.get("ISX_WORKER_CASE") == "shard_head":                       # one-rank rehearsal of the last section on a one-GPU box
         shard_head_case(rank, world, dev, res)
+        # libisx's OWN RCCL communicator, on whatever number of ranks there is (one, on a one-GPU box): librccl bound by dlopen next to the copy
+        # torch uses, unique id through the torch group, ncclCommInitRank, both all-gathers of the data path launched on the caller's stream, destroy
+        g0 = torch.Generator().manual_seed(5)
+        rows = torch.randn(37, 2048, generator=g0).to(dev)
+        s0 = torch.randn(37, 100, generator=g0).to(dev)
+        i0 = torch.randint(0, 1 << 40, (37, 100), generator=g0).to(dev)
+        nc = R.NativeComm()
+        allr = ops.comm_allgather_rows(nc.handle, nc.nranks, rows)
+        as_, ai_ = ops.shard_topk_allgather(nc.handle, nc.nranks, s0, i0)
+        torch.cuda.synchronize()
+        res["native_rows_ok"] = bool(torch.equal(allr[rank * 37:(rank + 1) * 37], rows) and allr.shape == (world * 37, 2048))
+        res["native_topk_ok"] = bool(torch.equal(as_[rank], s0) and torch.equal(ai_[rank], i0) and as_.shape == (world, 37, 100))
+        nc.close()
         torch.save(res, "%s.%d" % (out, rank))
         return dist.destroy_process_group()
     # ---- sharded gallery search: torch.distributed (RCCL) exchange and libisx's own RCCL communicator ----

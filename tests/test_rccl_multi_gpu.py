@@ -90,7 +90,8 @@ def test_bench_all_gpus_bare_command_line():
 
 
 def test_shard_head_worker_one_rank(tmp_path):
-    """The sharded-head section of the worker on ONE rank (an RCCL group of one): keeps that code exercised on a one-GPU box."""
+    """The sharded-head section of the worker on ONE rank (an RCCL group of one): keeps that code exercised on a one-GPU box -- and opens libisx's own
+    RCCL communicator there (one rank) and runs both data-path all-gathers on it: the library binding the N > 1 bench relies on, short of a second GPU."""
     if _n_gpus() < 1:
         pytest.skip("no GPU")
     out = str(tmp_path / "r")
@@ -101,6 +102,8 @@ def test_shard_head_worker_one_rank(tmp_path):
     r = torch.load(out + ".0")
     y_ref, dx_ref, w_ref = r["shard_ref"]
     assert torch.equal(r["shard_y"], y_ref) and torch.equal(r["shard_dx"], dx_ref) and torch.equal(r["shard_w"], w_ref)
+    # libisx's own RCCL communicator (dlopen of librccl, ncclCommInitRank, isx_comm_allgather_rows, isx_shard_topk_allgather) works in this process
+    assert r["native_rows_ok"] and r["native_topk_ok"]
 
 
 @needs2
