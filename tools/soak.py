@@ -1,7 +1,9 @@
 """Randomised soak test (not part of the suite): many random shapes through the kernels with bit-exact comparisons.
-    python scratch/soak.py [seconds]"""
+    python tools/soak.py [seconds]"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, "/root/repo/instance-search_amd"); sys.path.insert(0, "/root/repo/oracle")
+import os
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_ROOT, "instance-search_amd")); sys.path.insert(0, os.path.join(_ROOT, "oracle"))
 from isx import ops
 import oracle as O
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
