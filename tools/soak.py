@@ -9,13 +9,13 @@ import oracle as O
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(time.time()))
 g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
-t0 = time.time(); n = {"fast": 0, "conv1": 0, "conv3": 0, "dual": 0, "topk": 0, "sel": 0, "stem": 0, "pool": 0, "region": 0, "dba": 0, "gemm": 0, "ap": 0}
+t0 = time.time(); n = {"fast": 0, "conv1big": 0, "conv1": 0, "conv3": 0, "dual": 0, "topk": 0, "sel": 0, "stem": 0, "pool": 0, "region": 0, "dba": 0, "gemm": 0, "ap": 0}
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 last = t0
 while time.time() - t0 < budget:
     if time.time() - last > 60:                      # a line a minute: gpurun takes seven silent minutes for a hang
         last = time.time(); print("... %.0f s" % (last - t0), n, flush=True)
-    kind = rng.integers(0, 12)
+    kind = rng.integers(0, 13)
     if len(sys.argv) > 2: kind = int(rng.choice([int(v) for v in sys.argv[2].split(',')]))      # restrict to some kinds: soak.py 300 0,11
     if kind == 11:     # sort-free AP vs full sort + AP (float64, bit for bit), any number of positives per query, tied scores
         M = int(rng.integers(1, 60)); N = int(rng.integers(10, 70000)); L = int(rng.integers(1, max(2, N // int(rng.integers(1, 40))) + 1)); kth = int(rng.integers(1, 4))
@@ -38,6 +38,19 @@ while time.time() - t0 < budget:
         a = ops.cosine_topk(Q, G, k, idx_base=ib); b = ops.cosine_topk_fast(Q, G, k, idx_base=ib, gallery_f16=ops.gallery_to_f16(G) if rng.integers(2) else None)
         assert torch.equal(a[1], b[1]) and torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), ("fast", M, N, D, k, mode)
         n["fast"] += 1
+    elif kind == 12:   # conv1x1 on FORCED 128x128 tiles (the whole-tile residual fetch of round 6, ragged last tile rows / columns) vs oracle
+        from isx._lib import lib
+        M = int(rng.integers(1, 6000)); Cin = int(rng.choice([32, 64, 128])); Cout = int(rng.choice([36, 64, 128, 130, 256]))
+        x = np.maximum(rng.standard_normal((M, Cin), dtype=np.float32), 0); w = rng.standard_normal((Cout, Cin), dtype=np.float32) * 0.1
+        b = rng.standard_normal(Cout, dtype=np.float32); res = rng.integers(2); relu = bool(rng.integers(2))
+        r = rng.standard_normal((M, Cout), dtype=np.float32) if res else None
+        lib().isx_debug_set_gemm_cfg(0)
+        try:
+            y = ops.conv1x1_nhwc(dev(x).view(1, M, 1, Cin).permute(0, 3, 1, 2), dev(w), dev(b), dev(r).view(1, M, 1, Cout).permute(0, 3, 1, 2) if res else None, relu)
+        finally:
+            lib().isx_debug_set_gemm_cfg(-1)
+        assert np.array_equal(y.permute(0, 2, 3, 1).reshape(M, Cout).cpu().numpy(), O.conv1x1_nhwc(x, w, b, r, relu)), ("conv1big", M, Cin, Cout, res)
+        n["conv1big"] += 1
     elif kind == 1:    # conv1x1 vs oracle
         M = int(rng.integers(1, 3000)); Cin = int(rng.choice([4, 32, 64, 100, 256, 512])); Cout = int(rng.choice([4, 36, 64, 128, 130, 512]))
         x = np.maximum(rng.standard_normal((M, Cin), dtype=np.float32), 0); w = rng.standard_normal((Cout, Cin), dtype=np.float32) * 0.1
